@@ -1,0 +1,181 @@
+/* mikrylov.h -- C ABI of libmikrylov.so, the MI355X (gfx950) Krylov inner-loop engine.
+ *
+ * The reference (PythonOptimizers/pykrylov) is pure Python and has no FFI of its own;
+ * its extension point is the duck-typed operator protocol `y = op * x`
+ * (pykrylov/linop/linop.py:356-369) and the solver protocol
+ * `Solver(op, **kw).solve(rhs, **kw)` (pykrylov/generic/generic.py:65-98).
+ * Each entry point below names the reference code whose work it takes over.  The
+ * Python package `pykrylov_amd` binds these with ctypes (INTEGRATION.md shows the
+ * stub a reference maintainer would add).
+ *
+ * Conventions: every function returns 0 on success and a negative mk_status on
+ * failure (text via mk_last_error()); no C++ exception crosses the boundary; all
+ * "_dev" pointers are device (HBM) addresses obtained from mk_malloc; host arrays are
+ * borrowed for the duration of the call only; one host thread per process drives one
+ * device (one process per GPU).  Vectors are contiguous fp64, indices int32.
+ */
+#ifndef MIKRYLOV_H
+#define MIKRYLOV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_VERSION 100
+
+typedef enum {
+    MK_OK = 0,
+    MK_ERR_HIP = -1,        /* a HIP runtime call failed (no GPU, OOM, launch failure) */
+    MK_ERR_ARG = -2,        /* bad argument (null pointer, negative size, shape mismatch) */
+    MK_ERR_STATE = -3,      /* call out of order (e.g. iterate before setup) */
+    MK_ERR_COMM = -4,       /* RCCL failure or communicator missing */
+    MK_ERR_UNSUPPORTED = -5
+} mk_status;
+
+/* ------------------------------------------------------------------ context ---- */
+int mk_version(void);
+/* Bind the calling process to `device`, create the compute stream.  Idempotent. */
+int mk_init(int device);
+int mk_shutdown(void);
+const char *mk_last_error(void);
+/* name: at least 256 bytes.  Any out pointer may be NULL. */
+int mk_device_info(char *name, int *compute_units, size_t *hbm_bytes);
+int mk_sync(void);
+
+/* ------------------------------------------------------------------ memory ----- */
+int mk_malloc(void **dptr, size_t bytes);
+int mk_free(void *dptr);
+int mk_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int mk_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int mk_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
+int mk_memset(void *dst_dev, int byte, size_t bytes);
+
+/* ------------------------------------------------------------------ CSR -------- */
+/* The device-resident operator behind `linop.LinearOperator`: replaces the user
+ * `matvec` callable of pykrylov/linop/linop.py:114,:289 (Pysparse in
+ * examples/demo_common.py:15-16).  Canonical CSR: sorted columns, no duplicates. */
+typedef struct mk_csr mk_csr;
+
+int mk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *indptr_host,
+                  const int32_t *indices_host, const double *data_host, mk_csr **out);
+int mk_csr_destroy(mk_csr *A);
+int mk_csr_shape(const mk_csr *A, int64_t *nrows, int64_t *ncols, int64_t *nnz);
+/* Copy the arrays back (any pointer may be NULL). */
+int mk_csr_download(const mk_csr *A, int32_t *indptr_host, int32_t *indices_host, double *data_host);
+/* B = A^T as a new canonical CSR built on the device (operator `.T`, linop.py:148-171;
+ * feeds `A.T * u` of pykrylov/lls/lsqr.py:200,264). */
+int mk_csr_transpose(const mk_csr *A, mk_csr **out);
+/* Synthetic matrices generated directly in HBM.  Rows
+ * [row_begin,row_end) of the global matrix, global column ids.
+ * poisson2d: 5-point, m x m grid (the matrix of pykrylov/gallery/gallery.py:10-29).
+ * poisson3d: 7-point, nx x ny x nz grid, x fastest. */
+int mk_csr_poisson2d(int64_t m, int64_t row_begin, int64_t row_end, mk_csr **out);
+int mk_csr_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t row_begin, int64_t row_end, mk_csr **out);
+
+/* y = A x   (K1; `self.op * p`, pykrylov/cg/cg.py:115 and every other solver).
+ * Per row the products are added left to right with one rounding per multiply and per
+ * add, so the result is bit-identical to a scalar CSR loop. */
+int mk_spmv(const mk_csr *A, const double *x_dev, double *y_dev);
+
+/* ------------------------------------------------------------------ BLAS-1 ----- */
+/* K2/K3/K4 of SURVEY.md section 2.2: np.dot / np.linalg.norm / in-place updates of the
+ * solver loops (e.g. pykrylov/cg/cg.py:117,130-131,146,150-151).  Deterministic
+ * fixed-tree reductions; results returned to the host. */
+int mk_dot(int64_t n, const double *x_dev, const double *y_dev, double *result_host);
+int mk_nrm2(int64_t n, const double *x_dev, double *result_host);
+int mk_axpy(int64_t n, double alpha, const double *x_dev, double *y_dev);               /* y += alpha*x   */
+int mk_axpby(int64_t n, double alpha, const double *x_dev, double beta, double *y_dev); /* y = alpha*x + beta*y */
+int mk_scal(int64_t n, double alpha, double *x_dev);                                    /* x *= alpha     */
+
+/* ------------------------------------------------------------------ comm ------- */
+/* Row-partitioned multi-GPU execution (one process per GPU, RCCL over xGMI).
+ * unique_id: 128 bytes from mk_comm_unique_id on rank 0, broadcast by the caller. */
+int mk_comm_unique_id(void *id128);
+int mk_comm_init(int nranks, int rank, const void *id128);
+int mk_comm_destroy(void);
+int mk_comm_info(int *nranks, int *rank);
+/* Attach an exchange plan to a local matrix whose columns are already remapped to
+ * [local rows | halo]: before each SpMV the `send_count[r]` entries `send_idx`
+ * (local indices, grouped by destination rank) go to rank r and `recv_count[r]` entries
+ * arrive into the halo region in rank order.  mode 0 = halo send/recv, 1 = allgather
+ * (then the matrix keeps global column ids and every rank owns `n_local` rows, the
+ * last rank possibly fewer). */
+int mk_csr_set_exchange(mk_csr *A, int mode, int64_t n_local, int64_t n_halo, const int64_t *send_count,
+                        const int64_t *recv_count, const int32_t *send_idx_host);
+/* x_ext_dev has n_local + n_halo entries (mode 0) or the global length (mode 1). */
+int mk_exchange(const mk_csr *A, double *x_ext_dev);
+
+/* ------------------------------------------------------------------ solvers ---- */
+typedef enum {
+    MK_CG = 1,        /* pykrylov/cg/cg.py:46-165            */
+    MK_BICGSTAB = 2,  /* pykrylov/bicgstab/bicgstab.py:43-151 */
+    MK_CGS = 3,       /* pykrylov/cgs/cgs.py:40-123           */
+    MK_TFQMR = 4,     /* pykrylov/tfqmr/tfqmr.py:39-159       */
+    MK_MINRES = 5,    /* pykrylov/minres/minres.py:115-410    */
+    MK_SYMMLQ = 6     /* pykrylov/symmlq/symmlq.py:65-400     */
+} mk_solver_kind;
+
+typedef struct {
+    int32_t struct_size;      /* = sizeof(mk_params) */
+    int32_t kind;             /* mk_solver_kind */
+    double abstol;            /* generic.py:74 */
+    double reltol;            /* generic.py:75 */
+    int64_t matvec_max;       /* cg.py:82 (default 2n is applied by the caller) */
+    int32_t check_curvature;  /* cg.py:67 */
+    int32_t has_shift;        /* symmlq.py:92-93: shift None vs value */
+    double shift;             /* minres.py:122, symmlq.py:92 */
+    double rtol;              /* minres.py:126, symmlq.py:90 */
+    double etol;              /* minres.py:127 */
+    int64_t itnlim;           /* minres.py:125 */
+    int32_t window;           /* minres.py:130 */
+    int32_t reserved;
+} mk_params;
+
+typedef struct {
+    int32_t struct_size;
+    int32_t halted;           /* the loop condition of the reference became false */
+    int64_t nMatvec;
+    int64_t itn;
+    int64_t hist_len;         /* entries available through mk_solver_history */
+    int32_t converged;
+    int32_t definite;         /* cg.py:162 */
+    int32_t istop;            /* minres.py:87-98, symmlq.py:99-109 */
+    int32_t reserved;
+    double residNorm;
+    double residNorm0;
+    double threshold;
+    double Anorm, Acond, Arnorm, ynorm, xnorm;
+    double aux[8];
+} mk_result;
+
+typedef struct mk_solver mk_solver;
+
+int mk_solver_create(const mk_csr *A, const mk_params *params, mk_solver **out);
+int mk_solver_destroy(mk_solver *s);
+/* Everything before the `while` loop of the reference's solve().  rhs_dev has n_local
+ * entries; guess_dev may be NULL (x0 = 0).  Neither is modified. */
+int mk_solver_setup(mk_solver *s, const double *rhs_dev, const double *guess_dev);
+/* Run at most max_iters further passes of the loop body entirely on the device (no
+ * host round trip per iteration); stops early when the reference's loop condition
+ * fails.  iters_done may be NULL. */
+int mk_solver_iterate(mk_solver *s, int64_t max_iters, int64_t *iters_done);
+/* Everything after the loop (e.g. SYMMLQ's CG-point transfer) + result scalars. */
+int mk_solver_finish(mk_solver *s, mk_result *res);
+int mk_solver_x(const mk_solver *s, const double **x_dev);
+int mk_solver_history(const mk_solver *s, double *hist_host, int64_t cap);
+/* Other device vectors of the loop by solver-specific index (CG: 0 = r, 1 = p, the
+ * direction stored as `infiniteDescent`, cg.py:122).  len may be NULL. */
+int mk_solver_vector(const mk_solver *s, int index, const double **v_dev, int64_t *len);
+/* Device time of the last mk_solver_iterate call (HIP events on the solver's stream)
+ * and the accumulated time/launch count of its SpMV kernel. */
+int mk_solver_timing(const mk_solver *s, double *iterate_ms, double *spmv_ms, int64_t *spmv_launches);
+/* One-shot convenience: setup + iterate(until halted) + finish. */
+int mk_solver_solve(mk_solver *s, const double *rhs_dev, const double *guess_dev, mk_result *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIKRYLOV_H */

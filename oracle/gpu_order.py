@@ -1,0 +1,94 @@
+"""NumPy restatement of the device's fixed summation trees.   TEST INFRASTRUCTURE ONLY.
+
+The device never sums in NumPy's (pairwise / BLAS) order, which is the only source of
+difference between the GPU solvers and the oracle (all other arithmetic rounds identically).
+Restating the tree lets tests demand BIT equality instead of a tolerance:
+
+stream kernels (csrc/mk_device.h `mk_stream_kernel`):
+    lane g of S = grid*256 lanes adds elements 2q, 2q+1 for q = g, g+S, ... in order (the odd
+    tail element goes to lane (n//2) % S); then per wave64 a shuffle-down tree 32,16,...,1; the 4
+    wave sums of a workgroup are added in order; workgroup partials are added by `mk_total`:
+    lane t takes partials t, t+256, ... then the same workgroup tree.
+"""
+import numpy as np
+
+BLOCK = 256
+MAXP = 1024
+
+
+def _wave_tree(v):
+    """v: (..., 64) -> lane-0 result of the shuffle-down tree with offsets 32..1."""
+    v = v.copy()
+    for off in (32, 16, 8, 4, 2, 1):
+        shifted = np.concatenate([v[..., off:], v[..., -off:] * 0 + v[..., -off:]], axis=-1)
+        # lanes >= 64-off read their own value; only lane 0's chain matters
+        v = v + shifted
+    return v[..., 0]
+
+
+def _block_sum(vals):
+    """vals: (nblocks, 256) per-lane values -> (nblocks,) workgroup sums in device order."""
+    w = _wave_tree(vals.reshape(vals.shape[0], 4, 64))          # (nblocks, 4)
+    return ((w[:, 0] + w[:, 1]) + w[:, 2]) + w[:, 3]
+
+
+def total(partials):
+    """mk_total: lane t adds slots t, t+256, ... sequentially, then the workgroup tree."""
+    p = np.asarray(partials, dtype=np.float64)
+    padded = np.zeros(((len(p) + BLOCK - 1) // BLOCK) * BLOCK)
+    padded[:len(p)] = p
+    lanes = np.zeros(BLOCK)
+    for chunk in padded.reshape(-1, BLOCK):
+        lanes = lanes + chunk
+    return float(_block_sum(lanes[None, :])[0])
+
+
+def grid_stream(n):
+    g = max(1, (n + 2 * BLOCK - 1) // (2 * BLOCK))
+    return min(g, MAXP)
+
+
+def stream_partials(a, b):
+    """Per-workgroup partial sums of sum(a*b) as mk_stream_kernel<MkOpDot> produces them."""
+    n = len(a)
+    grid = grid_stream(n)
+    S = grid * BLOCK
+    prod = np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64)
+    npair = n // 2
+    acc = np.zeros(S)
+    steps = (npair + S - 1) // S if npair else 0
+    for s in range(steps):
+        q0 = s * S
+        cnt = min(S, npair - q0)
+        seg = prod[2 * q0: 2 * (q0 + cnt)].reshape(cnt, 2)
+        acc[:cnt] = acc[:cnt] + seg[:, 0]
+        acc[:cnt] = acc[:cnt] + seg[:, 1]
+    if n & 1:
+        g = npair % S
+        acc[g] = acc[g] + prod[n - 1]
+    return _block_sum(acc.reshape(grid, BLOCK))
+
+
+def stream_dot(a, b):
+    if len(a) == 0:
+        return 0.0
+    return total(stream_partials(a, b))
+
+
+def grid_spmv(ntiles):
+    return min(max(1, ntiles), MAXP)
+
+
+def spmv_partials(w, y, ntiles):
+    """Per-workgroup partial sums of sum(w*y) when the dot is fused into the SpMV kernel: lane t of
+    workgroup b owns rows 256*tile + t for tile = b, b+grid, ... and adds w[r]*y[r] in that order."""
+    n = len(w)
+    grid = grid_spmv(ntiles)
+    prod = np.zeros(ntiles * BLOCK)
+    prod[:n] = np.asarray(w, dtype=np.float64) * np.asarray(y, dtype=np.float64)
+    prod = prod.reshape(ntiles, BLOCK)
+    acc = np.zeros((grid, BLOCK))
+    for tile in range(ntiles):
+        b = tile % grid
+        acc[b] = acc[b] + prod[tile]
+    return _block_sum(acc)

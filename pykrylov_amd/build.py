@@ -1,0 +1,68 @@
+"""Build libmikrylov.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m pykrylov_amd.build [--force] [--verbose]
+
+The shared object is placed next to this file so that it travels with the source tree.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmikrylov.so")
+OBJDIR = os.path.join(HERE, "build")
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "-ffp-contract=off",          # one rounding per multiply and per add, like the NumPy expressions replaced
+    "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
+]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "mikrylov.h")]
+    os.makedirs(OBJDIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in srcs:
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0 or (verbose and out.strip()):
+            sys.stderr.write(out)
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed on %s\n" % src)
+    if failed:
+        raise RuntimeError("libmikrylov build failed")
+    stale = [o for o in glob.glob(os.path.join(OBJDIR, "*.o")) if o not in objs]
+    for o in stale:
+        os.remove(o)
+    if force or procs or _newer(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,195 @@
+// mk_cg.hip -- conjugate gradients, device resident.   Reference: pykrylov/cg/cg.py:46-165.
+//
+// One pass of the reference loop (cg.py:113-158) = three kernels:
+//   K1  Ap = A p ; partial sums of <p, Ap>                          (cg.py:115-117)
+//   K2  alpha = ry / pAp ; x += alpha p ; r += alpha Ap ; partial sums of <r, r>   (cg.py:119-146)
+//   K3  beta = ry' / ry ; p = beta p - r ; residNorm, history, loop test           (cg.py:149-158, :113)
+// Algorithmic traffic per pass: B_spmv + (32n read + 16n write) + (16n read + 8n write)
+//   = B_spmv + 72n bytes (the reference's op count gives B_spmv + 104n).
+#include "mk_solver.h"
+
+namespace {
+
+enum { S_RY0 = 0, S_RY1 = 1, S_THRESH = 2, S_RESID = 3, S_RESID0 = 4, S_PAP = 5 };
+
+struct CgSpmvEpi {
+    static constexpr int NACC = 1, SLOT0 = 0;
+    const double *p;
+    double *Ap;
+    __device__ void prologue(double *) {}
+    __device__ double xin(double v) const { return v; }
+    __device__ void row(int64_t r, double s, double *acc) {
+        Ap[r] = s;
+        acc[0] += p[r] * s;
+    }
+};
+
+struct CgUpdateXR {
+    static constexpr int NACC = 1, SLOT0 = 1;
+    const double *part;
+    int np;
+    double *scal;
+    MkStatus *st;
+    int par, check_curv;
+    const double *p, *Ap;
+    double *x, *r;
+    double alpha;
+    bool bad;
+    __device__ bool prologue(double *s4, bool lead) {
+        const double pAp = mk_total(part, np, s4);
+        const double ry = scal[S_RY0 + par];
+        bad = check_curv && (pAp <= 0.0);                 // cg.py:119-124
+        alpha = ry / pAp;                                 // cg.py:127
+        if (lead) {
+            st->nMatvec += 1;                             // cg.py:116
+            scal[S_PAP] = pAp;
+            if (bad) st->definite = 0;
+        }
+        return bad;
+    }
+    __device__ bool skip() const { return bad; }
+    __device__ void pair(int64_t i, double *acc) {
+        const double2 pv = mk_ld2(p, i), av = mk_ld2(Ap, i);
+        double2 xv = mk_ld2(x, i), rv = mk_ld2(r, i);
+        xv.x = xv.x + alpha * pv.x;                       // cg.py:130
+        xv.y = xv.y + alpha * pv.y;
+        rv.x = rv.x + alpha * av.x;                       // cg.py:131
+        rv.y = rv.y + alpha * av.y;
+        mk_st2(x, i, xv);
+        mk_st2(r, i, rv);
+        acc[0] += rv.x * rv.x;                            // cg.py:146
+        acc[0] += rv.y * rv.y;
+    }
+    __device__ void one(int64_t i, double *acc) {
+        x[i] = x[i] + alpha * p[i];
+        const double rv = r[i] + alpha * Ap[i];
+        r[i] = rv;
+        acc[0] += rv * rv;
+    }
+};
+
+struct CgUpdateP {
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *part;
+    int np;
+    double *scal;
+    MkStatus *st;
+    double *hist;
+    int par;
+    int64_t matvec_max;
+    const double *r;
+    double *p;
+    double beta;
+    __device__ bool prologue(double *s4, bool lead) {
+        const double ry_next = mk_total(part + MK_MAXP, np, s4);
+        const double ry = scal[S_RY0 + par];
+        beta = ry_next / ry;                              // cg.py:149
+        const double resid = fabs(__dsqrt_rn(ry_next));   // cg.py:154
+        const bool go = (resid > scal[S_THRESH]) && (st->nMatvec < matvec_max);   // cg.py:113
+        if (lead) {
+            scal[S_RY0 + (par ^ 1)] = ry_next;            // cg.py:153
+            scal[S_RESID] = resid;
+            hist[st->hist_len % MK_HIST_RING] = resid;    // cg.py:155
+            st->hist_len += 1;
+            st->itn += 1;
+        }
+        return !go;
+    }
+    __device__ bool skip() const { return false; }
+    __device__ void pair(int64_t i, double *) {
+        const double2 rv = mk_ld2(r, i);
+        double2 pv = mk_ld2(p, i);
+        pv.x = beta * pv.x - rv.x;                        // cg.py:150-151 (p *= beta; p -= r)
+        pv.y = beta * pv.y - rv.y;
+        mk_st2(p, i, pv);
+    }
+    __device__ void one(int64_t i, double *) { p[i] = beta * p[i] - r[i]; }
+};
+
+// everything between the initial <r, y> and the loop header (cg.py:99-113)
+__global__ __launch_bounds__(MK_BLOCK) void cg_init_kernel(const double *part, int np, double *scal, MkStatus *st,
+                                                           double *hist, MkHalt halt, double abstol, double reltol,
+                                                           int64_t matvec_max, int64_t nmv0) {
+    __shared__ double s4[4];
+    const double ry = mk_total(part + MK_MAXP, np, s4);
+    if (threadIdx.x == 0) {
+        const double resid0 = fabs(__dsqrt_rn(ry));
+        const double rel = reltol * resid0;
+        const double thresh = (rel > abstol) ? rel : abstol;   // max(abstol, reltol*residNorm0)
+        scal[S_RY0] = ry;
+        scal[S_THRESH] = thresh;
+        scal[S_RESID] = resid0;
+        scal[S_RESID0] = resid0;
+        hist[0] = resid0;
+        st->hist_len = 1;
+        st->nMatvec = nmv0;
+        st->itn = 0;
+        st->definite = 1;
+        halt.out(!((resid0 > thresh) && (nmv0 < matvec_max)));
+    }
+}
+
+struct CgSolver : mk_solver {
+    double *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr;
+
+    int setup(const double *rhs, const double *guess) override {
+        if (!d_x) {
+            int rc;
+            if ((rc = alloc_vec(&d_x, nx)) || (rc = alloc_vec(&d_r, n)) || (rc = alloc_vec(&d_p, nx)) ||
+                (rc = alloc_vec(&d_Ap, n)))
+                return rc;
+        }
+        int64_t nmv0 = 0;
+        mk_launch_stream(this, MkOpNegCopy{rhs, d_r}, n);                   // r = -rhs          cg.py:85
+        if (guess) {
+            MK_HIP(hipMemcpyAsync(d_x, guess, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+            int rc = exchange(d_x);
+            if (rc != MK_OK) return rc;
+            mk_launch_spmv(this, d_x, MkPlainEpi{d_Ap}, false);             // r += A x          cg.py:86-88
+            mk_launch_stream(this, MkOpAddTo<1>{d_Ap, d_r}, n);
+            nmv0 = 1;
+        } else {
+            MK_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)nx, stream));
+        }
+        mk_launch_stream(this, MkOpDot<1>{d_r, d_r}, n);                    // ry = <r, r>       cg.py:99
+        int rc = allreduce(1, 1);
+        if (rc != MK_OK) return rc;
+        hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_stream, d_scal, d_status,
+                           d_hist, next_halt(), prm.abstol, prm.reltol, prm.matvec_max, nmv0);
+        mk_launch_stream(this, MkOpNegCopy{d_r, d_p}, n);                   // p = -r            cg.py:104
+        return MK_OK;
+    }
+
+    int enqueue_pass() override {
+        const int par = (int)(it & 1);
+        int rc = exchange(d_p);
+        if (rc != MK_OK) return rc;
+        mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap});
+        if ((rc = allreduce(0, 1)) != MK_OK) return rc;
+        mk_launch_stream(this, CgUpdateXR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_p, d_Ap, d_x,
+                                          d_r, 0.0, false}, n);
+        if ((rc = allreduce(1, 1)) != MK_OK) return rc;
+        mk_launch_stream(this, CgUpdateP{d_part, np_stream, d_scal, d_status, d_hist, par, prm.matvec_max, d_r, d_p,
+                                         0.0}, n);
+        return MK_OK;
+    }
+
+    int finish(mk_result *res) override {
+        int rc = poll();
+        if (rc != MK_OK) return rc;
+        fill_result(res);
+        res->residNorm = h_scal[S_RESID];
+        res->residNorm0 = h_scal[S_RESID0];
+        res->threshold = h_scal[S_THRESH];
+        res->converged = (h_scal[S_RESID] <= h_scal[S_THRESH]) ? 1 : 0;     // cg.py:161
+        res->aux[0] = h_scal[S_PAP];
+        return MK_OK;
+    }
+
+    const double *x() const override { return d_x; }
+    const double *vector(int i) const override { return i == 0 ? d_r : (i == 1 ? d_p : nullptr); }
+};
+
+}  // namespace
+
+mk_solver *mk_make_cg() { return new CgSolver(); }

@@ -1,0 +1,197 @@
+// mk_comm.hip -- multi-GPU plumbing: one process per GPU, RCCL over xGMI.
+//
+// The reference is single-process; this file is new design.  Two collectives
+// exist on the solver path: (C1) the exchange of the SpMV input vector -- neighbour
+// send/recv of exactly the off-rank entries a rank's rows reference ("halo", the path that
+// fits the xGMI budget) or a full all-gather (the general path north_star names) -- and
+// (C2) a sum all-reduce of the per-workgroup partial sums of every dot product.
+// RCCL is bound at run time with dlopen so that single-GPU use needs no RCCL at all and so
+// that the process shares whichever librccl.so.1 PyTorch may already have loaded.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "mk_solver.h"
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl g_rccl;
+ncclComm_t g_comm = nullptr;
+int g_nranks = 1, g_rank = 0;
+
+int load_rccl() {
+    if (g_rccl.handle) return MK_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return mk_fail(MK_ERR_COMM, "cannot dlopen librccl.so.1: %s", dlerror());
+#define MK_SYM(field, name)                                                        \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(h, name);                         \
+    if (!g_rccl.field) return mk_fail(MK_ERR_COMM, "librccl lacks symbol %s", name)
+    MK_SYM(GetUniqueId, "ncclGetUniqueId");
+    MK_SYM(CommInitRank, "ncclCommInitRank");
+    MK_SYM(CommDestroy, "ncclCommDestroy");
+    MK_SYM(AllReduce, "ncclAllReduce");
+    MK_SYM(AllGather, "ncclAllGather");
+    MK_SYM(Send, "ncclSend");
+    MK_SYM(Recv, "ncclRecv");
+    MK_SYM(GroupStart, "ncclGroupStart");
+    MK_SYM(GroupEnd, "ncclGroupEnd");
+    MK_SYM(GetErrorString, "ncclGetErrorString");
+#undef MK_SYM
+    g_rccl.handle = h;
+    return MK_OK;
+}
+
+#define MK_NCCL(expr)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t _r = (expr);                                                                      \
+        if (_r != ncclSuccess)                                                                         \
+            return mk_fail(MK_ERR_COMM, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r),     \
+                           __FILE__, __LINE__);                                                        \
+    } while (0)
+
+__global__ __launch_bounds__(MK_BLOCK) void pack_kernel(int64_t cnt, const int32_t *__restrict__ idx,
+                                                        const double *__restrict__ x, double *__restrict__ buf) {
+    for (int64_t k = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * MK_BLOCK)
+        buf[k] = x[idx[k]];
+}
+
+}  // namespace
+
+int mk_comm_active() { return g_comm != nullptr && g_nranks > 1; }
+
+int mk_comm_allreduce_sum(double *buf, int64_t count, hipStream_t stream) {
+    if (!g_comm) return mk_fail(MK_ERR_COMM, "all-reduce without a communicator");
+    MK_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_comm, stream));
+    return MK_OK;
+}
+
+extern "C" int mk_comm_unique_id(void *id128) {
+    MK_ARG(id128 != nullptr);
+    int rc = load_rccl();
+    if (rc != MK_OK) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    MK_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return MK_OK;
+}
+
+extern "C" int mk_comm_init(int nranks, int rank, const void *id128) {
+    MK_REQUIRE_INIT();
+    MK_ARG(nranks >= 1 && rank >= 0 && rank < nranks && id128);
+    if (g_comm) return mk_fail(MK_ERR_STATE, "mk_comm_init: communicator already exists");
+    int rc = load_rccl();
+    if (rc != MK_OK) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    MK_NCCL(g_rccl.CommInitRank(&g_comm, nranks, id, rank));
+    g_nranks = nranks;
+    g_rank = rank;
+    return MK_OK;
+}
+
+extern "C" int mk_comm_destroy(void) {
+    if (g_comm) {
+        if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+        g_rccl.CommDestroy(g_comm);
+        g_comm = nullptr;
+    }
+    g_nranks = 1;
+    g_rank = 0;
+    return MK_OK;
+}
+
+extern "C" int mk_comm_info(int *nranks, int *rank) {
+    if (nranks) *nranks = g_nranks;
+    if (rank) *rank = g_rank;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_set_exchange(mk_csr *A, int mode, int64_t n_local, int64_t n_halo, const int64_t *send_count,
+                                   const int64_t *recv_count, const int32_t *send_idx_host) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A && (mode == 0 || mode == 1) && n_local >= 0 && n_halo >= 0);
+    MK_ARG(n_local == A->nrows);
+    MK_ARG(n_local + n_halo == A->ncols);     // columns are already remapped to [local | halo]
+    MkExchange &ex = A->ex;
+    ex.n_local = n_local;
+    ex.n_halo = n_halo;
+    ex.send_count.assign(g_nranks, 0);
+    ex.recv_count.assign(g_nranks, 0);
+    ex.send_off.assign(g_nranks + 1, 0);
+    ex.recv_off.assign(g_nranks + 1, 0);
+    if (mode == 0) {
+        MK_ARG(send_count && recv_count);
+        for (int r = 0; r < g_nranks; ++r) {
+            MK_ARG(send_count[r] >= 0 && recv_count[r] >= 0);
+            ex.send_count[r] = send_count[r];
+            ex.recv_count[r] = recv_count[r];
+            ex.send_off[r + 1] = ex.send_off[r] + send_count[r];
+            ex.recv_off[r + 1] = ex.recv_off[r] + recv_count[r];
+        }
+        MK_ARG(ex.recv_off[g_nranks] == n_halo);
+        MK_ARG(ex.send_count[g_rank] == 0 && ex.recv_count[g_rank] == 0);
+        ex.send_total = ex.send_off[g_nranks];
+        if (ex.send_total > 0) {
+            MK_ARG(send_idx_host != nullptr);
+            MK_HIP(hipMalloc((void **)&ex.d_send_idx, sizeof(int32_t) * (size_t)ex.send_total));
+            MK_HIP(hipMalloc((void **)&ex.d_send_buf, sizeof(double) * (size_t)ex.send_total));
+            MK_HIP(hipMemcpy(ex.d_send_idx, send_idx_host, sizeof(int32_t) * (size_t)ex.send_total,
+                             hipMemcpyHostToDevice));
+        }
+    } else {
+        // all-gather: every rank contributes exactly n_halo / nranks entries (the last rank's tail is padding)
+        MK_ARG(n_halo % g_nranks == 0 && n_halo / g_nranks >= n_local);
+    }
+    ex.mode = mode;
+    return MK_OK;
+}
+
+extern "C" int mk_exchange(const mk_csr *A, double *x_ext) {
+    MK_ARG(A && x_ext);
+    const MkExchange &ex = A->ex;
+    if (ex.mode < 0) return MK_OK;
+    hipStream_t st = mk_ctx().stream;
+    if (ex.mode == 1) {
+        if (!g_comm) return mk_fail(MK_ERR_COMM, "all-gather exchange without a communicator");
+        const size_t cnt = (size_t)(ex.n_halo / g_nranks);
+        MK_NCCL(g_rccl.AllGather(x_ext, x_ext + ex.n_local, cnt, ncclDouble, g_comm, st));
+        return MK_OK;
+    }
+    if (ex.n_halo == 0 && ex.send_total == 0) return MK_OK;
+    if (!g_comm) return mk_fail(MK_ERR_COMM, "halo exchange without a communicator");
+    if (ex.send_total > 0) {
+        int grid = (int)((ex.send_total + MK_BLOCK - 1) / MK_BLOCK);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, ex.send_total, ex.d_send_idx, x_ext,
+                           ex.d_send_buf);
+    }
+    MK_NCCL(g_rccl.GroupStart());
+    for (int r = 0; r < g_nranks; ++r) {
+        if (ex.send_count[r] > 0)
+            MK_NCCL(g_rccl.Send(ex.d_send_buf + ex.send_off[r], (size_t)ex.send_count[r], ncclDouble, r, g_comm, st));
+        if (ex.recv_count[r] > 0)
+            MK_NCCL(g_rccl.Recv(x_ext + ex.n_local + ex.recv_off[r], (size_t)ex.recv_count[r], ncclDouble, r, g_comm,
+                                st));
+    }
+    MK_NCCL(g_rccl.GroupEnd());
+    return MK_OK;
+}

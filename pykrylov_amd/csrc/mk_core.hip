@@ -1,0 +1,479 @@
+// mk_core.hip -- context, memory, CSR container, standalone SpMV / BLAS-1 entry points and
+// the on-device matrix generators of libmikrylov (C ABI in include/mikrylov.h).
+#include <stdarg.h>
+
+#include "mk_solver.h"
+
+// ======================================================================================
+// context
+// ======================================================================================
+MkContext &mk_ctx() {
+    static MkContext ctx;
+    return ctx;
+}
+
+int mk_fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    mk_ctx().last_error = buf;
+    return code;
+}
+
+static int *g_halt0 = nullptr;   // two zero ints: "never halted" flags for standalone kernels
+
+extern "C" int mk_version(void) { return MK_VERSION; }
+
+extern "C" const char *mk_last_error(void) { return mk_ctx().last_error.c_str(); }
+
+extern "C" int mk_init(int device) {
+    MkContext &c = mk_ctx();
+    if (c.ready && c.device == device) return MK_OK;
+    if (c.ready) return mk_fail(MK_ERR_STATE, "mk_init: already bound to device %d", c.device);
+    int count = 0;
+    MK_HIP(hipGetDeviceCount(&count));
+    if (count <= 0) return mk_fail(MK_ERR_HIP, "mk_init: no HIP device visible");
+    MK_ARG(device >= 0 && device < count);
+    MK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_init: device is %s; this library is built for gfx950 only",
+                       prop.gcnArchName);
+    c.num_cu = prop.multiProcessorCount;
+    MK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    MK_HIP(hipHostMalloc((void **)&c.h_scratch, sizeof(double) * MK_MAXP * MK_NDOT, hipHostMallocDefault));
+    MK_HIP(hipMalloc((void **)&c.d_scratch, sizeof(double) * MK_MAXP * MK_NDOT));
+    MK_HIP(hipMalloc((void **)&g_halt0, 2 * sizeof(int)));
+    MK_HIP(hipMemset(g_halt0, 0, 2 * sizeof(int)));
+    c.device = device;
+    c.ready = true;
+    return MK_OK;
+}
+
+extern "C" int mk_shutdown(void) {
+    MkContext &c = mk_ctx();
+    if (!c.ready) return MK_OK;
+    hipStreamSynchronize(c.stream);
+    hipFree(g_halt0);
+    g_halt0 = nullptr;
+    hipFree(c.d_scratch);
+    hipHostFree(c.h_scratch);
+    hipStreamDestroy(c.stream);
+    c = MkContext();
+    return MK_OK;
+}
+
+extern "C" int mk_device_info(char *name, int *compute_units, size_t *hbm_bytes) {
+    MK_REQUIRE_INIT();
+    hipDeviceProp_t prop;
+    MK_HIP(hipGetDeviceProperties(&prop, mk_ctx().device));
+    if (name) snprintf(name, 256, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return MK_OK;
+}
+
+extern "C" int mk_sync(void) {
+    MK_REQUIRE_INIT();
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    return MK_OK;
+}
+
+// ======================================================================================
+// memory
+// ======================================================================================
+extern "C" int mk_malloc(void **dptr, size_t bytes) {
+    MK_REQUIRE_INIT();
+    MK_ARG(dptr != nullptr);
+    MK_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return MK_OK;
+}
+
+extern "C" int mk_free(void *dptr) {
+    if (!dptr) return MK_OK;
+    MK_REQUIRE_INIT();
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    MK_HIP(hipFree(dptr));
+    return MK_OK;
+}
+
+extern "C" int mk_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    MK_REQUIRE_INIT();
+    if (!bytes) return MK_OK;
+    MK_ARG(dst && src);
+    MK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, mk_ctx().stream));
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    return MK_OK;
+}
+
+extern "C" int mk_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    MK_REQUIRE_INIT();
+    if (!bytes) return MK_OK;
+    MK_ARG(dst && src);
+    MK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, mk_ctx().stream));
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    return MK_OK;
+}
+
+extern "C" int mk_memcpy_d2d(void *dst, const void *src, size_t bytes) {
+    MK_REQUIRE_INIT();
+    if (!bytes) return MK_OK;
+    MK_ARG(dst && src);
+    MK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, mk_ctx().stream));
+    return MK_OK;
+}
+
+extern "C" int mk_memset(void *dst, int byte, size_t bytes) {
+    MK_REQUIRE_INIT();
+    if (!bytes) return MK_OK;
+    MK_ARG(dst != nullptr);
+    MK_HIP(hipMemsetAsync(dst, byte, bytes, mk_ctx().stream));
+    return MK_OK;
+}
+
+// ======================================================================================
+// CSR container
+// ======================================================================================
+int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out) {
+    MK_ARG(out != nullptr);
+    MK_ARG(nrows >= 0 && ncols >= 0 && nnz >= 0);
+    if (nnz > 2147483647LL || ncols > 2147483647LL)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr: nnz=%lld / ncols=%lld exceed the int32 index range",
+                       (long long)nnz, (long long)ncols);
+    mk_csr *A = new mk_csr();
+    A->nrows = nrows;
+    A->ncols = ncols;
+    A->nnz = nnz;
+    A->ntiles = (nrows + MK_ROWS_PER_TILE - 1) / MK_ROWS_PER_TILE;
+    hipError_t e1 = hipMalloc((void **)&A->d_indptr, sizeof(int32_t) * (size_t)(nrows + 1));
+    hipError_t e2 = hipMalloc((void **)&A->d_indices, sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    hipError_t e3 = hipMalloc((void **)&A->d_data, sizeof(double) * (size_t)(nnz ? nnz : 1));
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        mk_csr_destroy(A);
+        return mk_fail(MK_ERR_HIP, "mk_csr: hipMalloc failed for nrows=%lld nnz=%lld", (long long)nrows,
+                       (long long)nnz);
+    }
+    *out = A;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *indptr,
+                             const int32_t *indices, const double *data, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(indptr != nullptr && (nnz == 0 || (indices && data)));
+    MK_ARG(indptr[0] == 0 && (int64_t)indptr[nrows] == nnz);
+    mk_csr *A = nullptr;
+    int rc = mk_csr_alloc(nrows, ncols, nnz, &A);
+    if (rc != MK_OK) return rc;
+    hipStream_t st = mk_ctx().stream;
+    MK_HIP(hipMemcpyAsync(A->d_indptr, indptr, sizeof(int32_t) * (size_t)(nrows + 1), hipMemcpyHostToDevice, st));
+    if (nnz) {
+        MK_HIP(hipMemcpyAsync(A->d_indices, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, st));
+        MK_HIP(hipMemcpyAsync(A->d_data, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, st));
+    }
+    MK_HIP(hipStreamSynchronize(st));
+    *out = A;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_destroy(mk_csr *A) {
+    if (!A) return MK_OK;
+    if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+    hipFree(A->d_indptr);
+    hipFree(A->d_indices);
+    hipFree(A->d_data);
+    hipFree(A->ex.d_send_idx);
+    hipFree(A->ex.d_send_buf);
+    delete A;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_shape(const mk_csr *A, int64_t *nrows, int64_t *ncols, int64_t *nnz) {
+    MK_ARG(A != nullptr);
+    if (nrows) *nrows = A->nrows;
+    if (ncols) *ncols = A->ncols;
+    if (nnz) *nnz = A->nnz;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_download(const mk_csr *A, int32_t *indptr, int32_t *indices, double *data) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr);
+    hipStream_t st = mk_ctx().stream;
+    if (indptr)
+        MK_HIP(hipMemcpyAsync(indptr, A->d_indptr, sizeof(int32_t) * (size_t)(A->nrows + 1), hipMemcpyDeviceToHost, st));
+    if (indices && A->nnz)
+        MK_HIP(hipMemcpyAsync(indices, A->d_indices, sizeof(int32_t) * (size_t)A->nnz, hipMemcpyDeviceToHost, st));
+    if (data && A->nnz)
+        MK_HIP(hipMemcpyAsync(data, A->d_data, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    return MK_OK;
+}
+
+// ======================================================================================
+// standalone SpMV and BLAS-1
+// ======================================================================================
+static MkHalt never_halt() { return MkHalt{g_halt0, 0}; }
+
+extern "C" int mk_spmv(const mk_csr *A, const double *x, double *y) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A && x && y);
+    if (A->nrows == 0) return MK_OK;
+    MkPlainEpi epi{y};
+    hipLaunchKernelGGL(mk_spmv_kernel<MkPlainEpi>, dim3(mk_grid_spmv(A->ntiles)), dim3(MK_BLOCK), 0, mk_ctx().stream,
+                       mk_view(A), x, epi, never_halt(), mk_ctx().d_scratch);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void mk_finalize_kernel(const double *part, int np, double *out, int do_sqrt) {
+    __shared__ double s4[4];
+    const double t = mk_total(part, np, s4);
+    if (threadIdx.x == 0) out[0] = do_sqrt ? __dsqrt_rn(t) : t;
+}
+
+static int dot_impl(int64_t n, const double *x, const double *y, double *result, int do_sqrt) {
+    MK_REQUIRE_INIT();
+    MK_ARG(n >= 0 && result && (n == 0 || (x && y)));
+    MkContext &c = mk_ctx();
+    if (n == 0) {
+        *result = 0.0;
+        return MK_OK;
+    }
+    const int grid = mk_grid_stream(n);
+    MkOpDot<0> op{x, y};
+    hipLaunchKernelGGL(mk_stream_kernel<MkOpDot<0>>, dim3(grid), dim3(MK_BLOCK), 0, c.stream, op, n, never_halt(),
+                       c.d_scratch);
+    hipLaunchKernelGGL(mk_finalize_kernel, dim3(1), dim3(MK_BLOCK), 0, c.stream, c.d_scratch, grid,
+                       c.d_scratch + MK_MAXP, do_sqrt);
+    MK_HIP(hipMemcpyAsync(c.h_scratch, c.d_scratch + MK_MAXP, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipStreamSynchronize(c.stream));
+    *result = c.h_scratch[0];
+    return MK_OK;
+}
+
+extern "C" int mk_dot(int64_t n, const double *x, const double *y, double *result) {
+    return dot_impl(n, x, y, result, 0);
+}
+
+extern "C" int mk_nrm2(int64_t n, const double *x, double *result) { return dot_impl(n, x, x, result, 1); }
+
+struct OpAxpby {   // y = alpha*x + beta*y  (mode 0), y += alpha*x (mode 1), x *= alpha (mode 2)
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *x;
+    double *y;
+    double alpha, beta;
+    int mode;
+    __device__ bool prologue(double *, bool) { return false; }
+    __device__ bool skip() const { return false; }
+    __device__ double f(double a, double b) const {
+        if (mode == 1) return b + alpha * a;
+        if (mode == 2) return b * alpha;
+        return alpha * a + beta * b;
+    }
+    __device__ void pair(int64_t i, double *) {
+        double2 a = (mode == 2) ? double2{0.0, 0.0} : mk_ld2(x, i);
+        double2 b = mk_ld2(y, i);
+        b.x = f(a.x, b.x);
+        b.y = f(a.y, b.y);
+        mk_st2(y, i, b);
+    }
+    __device__ void one(int64_t i, double *) { y[i] = f(mode == 2 ? 0.0 : x[i], y[i]); }
+};
+
+static int axpby_impl(int64_t n, double alpha, const double *x, double beta, double *y, int mode) {
+    MK_REQUIRE_INIT();
+    MK_ARG(n >= 0 && (n == 0 || y) && (n == 0 || mode == 2 || x));
+    if (n == 0) return MK_OK;
+    OpAxpby op{x, y, alpha, beta, mode};
+    hipLaunchKernelGGL(mk_stream_kernel<OpAxpby>, dim3(mk_grid_stream(n)), dim3(MK_BLOCK), 0, mk_ctx().stream, op, n,
+                       never_halt(), mk_ctx().d_scratch);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
+extern "C" int mk_axpy(int64_t n, double alpha, const double *x, double *y) { return axpby_impl(n, alpha, x, 0.0, y, 1); }
+extern "C" int mk_axpby(int64_t n, double alpha, const double *x, double beta, double *y) {
+    return axpby_impl(n, alpha, x, beta, y, 0);
+}
+extern "C" int mk_scal(int64_t n, double alpha, double *x) { return axpby_impl(n, alpha, nullptr, 0.0, x, 2); }
+
+// ======================================================================================
+// synthetic matrices generated in HBM
+// ======================================================================================
+// number of stored entries in rows [0, r) of the 5-point m x m Laplacian
+__host__ __device__ static inline int64_t p2d_prefix(int64_t r, int64_t m) {
+    const int64_t n = m * m;
+    int64_t c = 5 * r;
+    c -= (r < m ? r : m);                                 // rows on the bottom edge (gy == 0)
+    c -= (r > n - m ? r - (n - m) : 0);                   // rows on the top edge (gy == m-1)
+    c -= (r + m - 1) / m;                                 // gx == 0
+    c -= r / m;                                           // gx == m-1
+    return c;
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void gen_poisson2d(int64_t m, int64_t r_begin, int64_t r_end, int32_t *indptr,
+                                                          int32_t *indices, double *data) {
+    const int64_t base = p2d_prefix(r_begin, m);
+    for (int64_t r = r_begin + (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r <= r_end;
+         r += (int64_t)gridDim.x * MK_BLOCK) {
+        int64_t p = p2d_prefix(r, m) - base;
+        indptr[r - r_begin] = (int32_t)p;
+        if (r == r_end) break;
+        const int64_t gx = r % m, gy = r / m;
+        if (gy > 0) { indices[p] = (int32_t)(r - m); data[p++] = -1.0; }
+        if (gx > 0) { indices[p] = (int32_t)(r - 1); data[p++] = -1.0; }
+        indices[p] = (int32_t)r; data[p++] = 4.0;
+        if (gx < m - 1) { indices[p] = (int32_t)(r + 1); data[p++] = -1.0; }
+        if (gy < m - 1) { indices[p] = (int32_t)(r + m); data[p++] = -1.0; }
+    }
+}
+
+__host__ __device__ static inline int64_t p3d_prefix(int64_t r, int64_t nx, int64_t ny, int64_t nz) {
+    const int64_t pl = nx * ny, n = pl * nz;
+    const int64_t zc = r / pl, rem = r % pl;
+    int64_t c = 7 * r;
+    c -= (r < pl ? r : pl);                               // gz == 0
+    c -= (r > n - pl ? r - (n - pl) : 0);                 // gz == nz-1
+    c -= zc * nx + (rem < nx ? rem : nx);                 // gy == 0
+    c -= zc * nx + (rem > pl - nx ? rem - (pl - nx) : 0); // gy == ny-1
+    c -= (r + nx - 1) / nx;                               // gx == 0
+    c -= r / nx;                                          // gx == nx-1
+    return c;
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void gen_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t r_begin,
+                                                          int64_t r_end, int32_t *indptr, int32_t *indices,
+                                                          double *data) {
+    const int64_t pl = nx * ny;
+    const int64_t base = p3d_prefix(r_begin, nx, ny, nz);
+    for (int64_t r = r_begin + (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r <= r_end;
+         r += (int64_t)gridDim.x * MK_BLOCK) {
+        int64_t p = p3d_prefix(r, nx, ny, nz) - base;
+        indptr[r - r_begin] = (int32_t)p;
+        if (r == r_end) break;
+        const int64_t gx = r % nx, gy = (r / nx) % ny, gz = r / pl;
+        if (gz > 0) { indices[p] = (int32_t)(r - pl); data[p++] = -1.0; }
+        if (gy > 0) { indices[p] = (int32_t)(r - nx); data[p++] = -1.0; }
+        if (gx > 0) { indices[p] = (int32_t)(r - 1); data[p++] = -1.0; }
+        indices[p] = (int32_t)r; data[p++] = 6.0;
+        if (gx < nx - 1) { indices[p] = (int32_t)(r + 1); data[p++] = -1.0; }
+        if (gy < ny - 1) { indices[p] = (int32_t)(r + nx); data[p++] = -1.0; }
+        if (gz < nz - 1) { indices[p] = (int32_t)(r + pl); data[p++] = -1.0; }
+    }
+}
+
+extern "C" int mk_csr_poisson2d(int64_t m, int64_t row_begin, int64_t row_end, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(m >= 1 && row_begin >= 0 && row_begin <= row_end && row_end <= m * m);
+    const int64_t nnz = p2d_prefix(row_end, m) - p2d_prefix(row_begin, m);
+    mk_csr *A = nullptr;
+    int rc = mk_csr_alloc(row_end - row_begin, m * m, nnz, &A);
+    if (rc != MK_OK) return rc;
+    const int64_t rows = row_end - row_begin + 1;
+    int grid = (int)((rows + MK_BLOCK - 1) / MK_BLOCK);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(gen_poisson2d, dim3(grid), dim3(MK_BLOCK), 0, mk_ctx().stream, m, row_begin, row_end,
+                       A->d_indptr, A->d_indices, A->d_data);
+    MK_HIP(hipGetLastError());
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    *out = A;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t row_begin, int64_t row_end,
+                                mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(nx >= 1 && ny >= 1 && nz >= 1 && row_begin >= 0 && row_begin <= row_end && row_end <= nx * ny * nz);
+    const int64_t nnz = p3d_prefix(row_end, nx, ny, nz) - p3d_prefix(row_begin, nx, ny, nz);
+    mk_csr *A = nullptr;
+    int rc = mk_csr_alloc(row_end - row_begin, nx * ny * nz, nnz, &A);
+    if (rc != MK_OK) return rc;
+    const int64_t rows = row_end - row_begin + 1;
+    int grid = (int)((rows + MK_BLOCK - 1) / MK_BLOCK);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(gen_poisson3d, dim3(grid), dim3(MK_BLOCK), 0, mk_ctx().stream, nx, ny, nz, row_begin, row_end,
+                       A->d_indptr, A->d_indices, A->d_data);
+    MK_HIP(hipGetLastError());
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    *out = A;
+    return MK_OK;
+}
+
+// ======================================================================================
+// transpose (K1T support): B = A^T with rows of B sorted by original row index
+// ======================================================================================
+__global__ __launch_bounds__(MK_BLOCK) void tr_count(int64_t nnz, const int32_t *indices, int32_t *count) {
+    for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * MK_BLOCK)
+        atomicAdd(&count[indices[j] + 1], 1);
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void tr_scatter(int64_t nrows, const int32_t *indptr, const int32_t *indices,
+                                                       const double *data, int32_t *cursor, int32_t *t_indices,
+                                                       double *t_data) {
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK)
+        for (int32_t j = indptr[r]; j < indptr[r + 1]; ++j) {
+            const int32_t dst = atomicAdd(&cursor[indices[j]], 1);
+            t_indices[dst] = (int32_t)r;
+            t_data[dst] = data[j];
+        }
+}
+
+// arrival order of the atomics is arbitrary: restore ascending original-row order per segment
+__global__ __launch_bounds__(MK_BLOCK) void tr_sort_segments(int64_t ncols, const int32_t *t_indptr, int32_t *t_indices,
+                                                             double *t_data) {
+    for (int64_t c = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * MK_BLOCK) {
+        const int32_t lo = t_indptr[c], hi = t_indptr[c + 1];
+        for (int32_t i = lo + 1; i < hi; ++i) {
+            const int32_t ki = t_indices[i];
+            const double vi = t_data[i];
+            int32_t j = i - 1;
+            while (j >= lo && t_indices[j] > ki) {
+                t_indices[j + 1] = t_indices[j];
+                t_data[j + 1] = t_data[j];
+                --j;
+            }
+            t_indices[j + 1] = ki;
+            t_data[j + 1] = vi;
+        }
+    }
+}
+
+extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A && out);
+    mk_csr *B = nullptr;
+    int rc = mk_csr_alloc(A->ncols, A->nrows, A->nnz, &B);
+    if (rc != MK_OK) return rc;
+    hipStream_t st = mk_ctx().stream;
+    const size_t pbytes = sizeof(int32_t) * (size_t)(A->ncols + 1);
+    MK_HIP(hipMemsetAsync(B->d_indptr, 0, pbytes, st));
+    int g1 = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
+    g1 = g1 < 1 ? 1 : (g1 > 65536 ? 65536 : g1);
+    hipLaunchKernelGGL(tr_count, dim3(g1), dim3(MK_BLOCK), 0, st, A->nnz, A->d_indices, B->d_indptr);
+    // exclusive scan of the column counts on the host (one-off, ncols ints)
+    std::vector<int32_t> h((size_t)A->ncols + 1);
+    MK_HIP(hipMemcpyAsync(h.data(), B->d_indptr, pbytes, hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    for (int64_t c = 0; c < A->ncols; ++c) h[c + 1] += h[c];
+    MK_HIP(hipMemcpyAsync(B->d_indptr, h.data(), pbytes, hipMemcpyHostToDevice, st));
+    int32_t *cursor = nullptr;
+    MK_HIP(hipMalloc((void **)&cursor, pbytes));
+    MK_HIP(hipMemcpyAsync(cursor, h.data(), pbytes, hipMemcpyHostToDevice, st));
+    int g2 = (int)((A->nrows + MK_BLOCK - 1) / MK_BLOCK);
+    g2 = g2 < 1 ? 1 : (g2 > 65536 ? 65536 : g2);
+    hipLaunchKernelGGL(tr_scatter, dim3(g2), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data,
+                       cursor, B->d_indices, B->d_data);
+    int g3 = (int)((A->ncols + MK_BLOCK - 1) / MK_BLOCK);
+    g3 = g3 < 1 ? 1 : (g3 > 65536 ? 65536 : g3);
+    hipLaunchKernelGGL(tr_sort_segments, dim3(g3), dim3(MK_BLOCK), 0, st, A->ncols, B->d_indptr, B->d_indices,
+                       B->d_data);
+    MK_HIP(hipGetLastError());
+    MK_HIP(hipStreamSynchronize(st));
+    MK_HIP(hipFree(cursor));
+    *out = B;
+    return MK_OK;
+}

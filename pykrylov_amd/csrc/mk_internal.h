@@ -1,0 +1,138 @@
+// mk_internal.h -- shared host/device plumbing of libmikrylov (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mikrylov.h"
+
+// --------------------------------------------------------------------------------------
+// geometry shared by every kernel
+// --------------------------------------------------------------------------------------
+constexpr int MK_BLOCK = 256;         // 4 wave64 per workgroup
+constexpr int MK_WAVE = 64;
+constexpr int MK_MAXP = 1024;         // partial-sum slots per reduction (= max grid of a producer)
+constexpr int MK_ROWS_PER_TILE = 256; // SpMV: one row per thread in the row-sum phase
+constexpr int MK_SPMV_TILE = 2048;    // SpMV: products staged in LDS per pass (16 KiB)
+constexpr int MK_NSCAL = 64;          // device scalar file per solver
+constexpr int MK_NDOT = 4;            // reduction slots per solver (MK_MAXP doubles each)
+
+// --------------------------------------------------------------------------------------
+// host context
+// --------------------------------------------------------------------------------------
+struct MkContext {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int num_cu = 0;
+    std::string last_error;
+    // pinned staging for scalar read-backs
+    double *h_scratch = nullptr;     // MK_MAXP * MK_NDOT doubles
+    double *d_scratch = nullptr;
+};
+
+MkContext &mk_ctx();
+int mk_fail(int code, const char *fmt, ...);
+
+#define MK_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return mk_fail(MK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define MK_REQUIRE_INIT()                                                              \
+    do {                                                                               \
+        if (!mk_ctx().ready) {                                                         \
+            int _r = mk_init(0);                                                       \
+            if (_r != MK_OK) return _r;                                                \
+        }                                                                              \
+    } while (0)
+
+#define MK_ARG(cond)                                                                          \
+    do {                                                                                      \
+        if (!(cond)) return mk_fail(MK_ERR_ARG, "argument check failed: %s (%s:%d)", #cond,   \
+                                    __FILE__, __LINE__);                                      \
+    } while (0)
+
+// --------------------------------------------------------------------------------------
+// exchange plan (multi-GPU); empty for a single-device matrix
+// --------------------------------------------------------------------------------------
+struct MkExchange {
+    int mode = -1;                 // -1 none, 0 halo send/recv, 1 allgather
+    int64_t n_local = 0, n_halo = 0;
+    std::vector<int64_t> send_count, recv_count, send_off, recv_off;
+    int32_t *d_send_idx = nullptr; // gather list (device)
+    double *d_send_buf = nullptr;  // packed values to send
+    int64_t send_total = 0;
+    bool contiguous_send = false;  // every rank's list is a contiguous range: send straight from x
+};
+
+struct mk_csr {
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    int32_t *d_indptr = nullptr;
+    int32_t *d_indices = nullptr;
+    double *d_data = nullptr;
+    int64_t ntiles = 0;            // ceil(nrows / MK_ROWS_PER_TILE)
+    MkExchange ex;
+    // length of the vector an SpMV reads (ncols, or n_local + n_halo with a halo plan)
+    int64_t x_len() const { return ex.mode == 0 ? ex.n_local + ex.n_halo : ncols; }
+};
+
+int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out);
+
+// grid sizes -------------------------------------------------------------------------
+static inline int mk_grid_stream(int64_t n) {          // BLAS-1 style kernels: 2 doubles per thread per step
+    int64_t g = (n + 2 * MK_BLOCK - 1) / (2 * MK_BLOCK);
+    if (g < 1) g = 1;
+    return (int)(g > MK_MAXP ? MK_MAXP : g);
+}
+static inline int mk_grid_spmv(int64_t ntiles) {
+    if (ntiles < 1) ntiles = 1;
+    return (int)(ntiles > MK_MAXP ? MK_MAXP : ntiles);
+}
+
+// --------------------------------------------------------------------------------------
+// device helpers
+// --------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// Sum over the workgroup, identical value returned to every thread.  Fixed tree:
+// shuffle-down 32,16,8,4,2,1 inside each wave64, then the four wave sums added in wave order.
+__device__ __forceinline__ double mk_block_sum(double v, double *s4) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                 // s4 may still be read from a previous call
+    if (lane == 0) s4[wave] = v;
+    __syncthreads();
+    return ((s4[0] + s4[1]) + s4[2]) + s4[3];
+}
+
+// Total of `np` partial sums written by a previous kernel (np <= MK_MAXP): thread t adds
+// slots t, t+256, ... in order, then mk_block_sum.  Every workgroup of the consumer kernel
+// does this redundantly and obtains bit-identical totals, so no extra kernel or fence is needed.
+__device__ __forceinline__ double mk_total(const double *part, int np, double *s4) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < np; i += MK_BLOCK) v += part[i];
+    return mk_block_sum(v, s4);
+}
+
+// Halting protocol.  Kernel number q of a solver reads halt[q & 1] and (one thread) writes
+// halt[(q + 1) & 1] = halt_in | new condition, so no kernel reads the word it writes and a
+// raised flag is carried forward by every later kernel, which then does no work: the solver
+// state stays frozen exactly where the reference's `while` condition failed.
+struct MkHalt {
+    int *flags;      // 2 ints
+    int parity;      // q & 1
+    __device__ __forceinline__ bool in() const { return flags[parity] != 0; }
+    __device__ __forceinline__ void out(bool v) const { flags[parity ^ 1] = v ? 1 : 0; }
+};
+
+#endif  // __HIPCC__

@@ -1,0 +1,185 @@
+// mk_solver.h -- host-side driver shared by all device-resident solver loops.
+//
+// A solver is a fixed sequence of kernels per pass of the reference's `while` body.  The
+// host only enqueues; scalars (alpha, beta, rotations, norms, stop tests) live in device
+// memory and are recomputed by every workgroup from the previous kernel's partial sums, so
+// there is no device->host round trip inside an iteration.  The driver enqueues a batch of
+// iterations, then reads back one small status record to learn whether the loop condition
+// failed (kernels after that point are no-ops thanks to MkHalt).
+#pragma once
+#include "mk_device.h"
+
+struct MkStatus {            // lives in device memory, written by one lane only
+    int64_t nMatvec;
+    int64_t itn;
+    int64_t hist_len;
+    int32_t istop;
+    int32_t definite;
+    int32_t converged;
+    int32_t pad;
+};
+
+constexpr int64_t MK_HIST_RING = 1 << 16;   // residual-history ring (drained after every batch)
+constexpr int64_t MK_BATCH_MAX = 256;
+
+// Collective hooks (implemented in mk_comm.hip; no-ops without a communicator).
+int mk_comm_active();
+int mk_comm_allreduce_sum(double *buf_dev, int64_t count, hipStream_t stream);
+
+struct mk_solver {
+    const mk_csr *A = nullptr;
+    mk_params prm{};
+    int64_t n = 0;        // local rows = length of every solver vector
+    int64_t nx = 0;       // length of vectors that feed an SpMV (n + halo)
+    hipStream_t stream = nullptr;
+
+    double *d_scal = nullptr;       // MK_NSCAL
+    double *d_part = nullptr;       // MK_NDOT * MK_MAXP
+    int *d_halt = nullptr;          // 2
+    MkStatus *d_status = nullptr;
+    double *d_hist = nullptr;       // MK_HIST_RING
+    MkStatus *h_status = nullptr;   // pinned
+    double *h_scal = nullptr;       // pinned, MK_NSCAL
+    std::vector<double *> vecs;     // owned device vectors
+    std::vector<double> hist;       // drained history (host)
+    int64_t hist_drained = 0;
+
+    int64_t q = 0;                  // kernels launched so far (halt parity)
+    int64_t it = 0;                 // loop passes enqueued so far
+    bool is_setup = false, halted = false;
+    int np_spmv = 1, np_stream = 1; // partial counts consumers must add up
+
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_iterate_ms = 0.0;
+    std::vector<hipEvent_t> spmv_ev;    // pairs
+    int64_t spmv_timed = 0;
+    double spmv_ms = 0.0;
+    int spmv_sample_stride = 0;         // 0 = no per-kernel events
+
+    virtual ~mk_solver();
+    virtual int setup(const double *rhs, const double *guess) = 0;
+    virtual int enqueue_pass() = 0;                 // one pass of the reference loop body
+    virtual int finish(mk_result *res) = 0;
+    virtual const double *x() const = 0;
+    virtual const double *vector(int) const { return nullptr; }
+
+    int init_common(const mk_csr *A_, const mk_params *p);
+    int alloc_vec(double **out, int64_t len);
+    MkHalt next_halt() { return MkHalt{d_halt, (int)(q++ & 1)}; }
+    int poll();                                     // status + scalars + history -> host
+    int iterate(int64_t max_iters, int64_t *done);
+    int allreduce(int slot0, int nslots);           // partial sums across ranks (multi-GPU only)
+    int exchange(double *x_ext);                    // halo / allgather before an SpMV
+    void fill_result(mk_result *res) const;
+    // SpMV timing helpers
+    void spmv_begin();
+    void spmv_end();
+    int collect_spmv_timing();
+};
+
+mk_solver *mk_make_cg();
+mk_solver *mk_make_bicgstab();
+mk_solver *mk_make_cgs();
+mk_solver *mk_make_tfqmr();
+mk_solver *mk_make_minres();
+mk_solver *mk_make_symmlq();
+
+#ifdef __HIPCC__
+// ------------------------------------------------------------------ small shared kernels
+struct MkOpNegCopy {            // out = -in                    (cg.py:85,104)
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *in;
+    double *out;
+    __device__ bool prologue(double *, bool) { return false; }
+    __device__ bool skip() const { return false; }
+    __device__ void pair(int64_t i, double *) {
+        double2 v = mk_ld2(in, i);
+        v.x = -v.x;
+        v.y = -v.y;
+        mk_st2(out, i, v);
+    }
+    __device__ void one(int64_t i, double *) { out[i] = -in[i]; }
+};
+
+struct MkOpCopy {               // out = in
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *in;
+    double *out;
+    __device__ bool prologue(double *, bool) { return false; }
+    __device__ bool skip() const { return false; }
+    __device__ void pair(int64_t i, double *) { mk_st2(out, i, mk_ld2(in, i)); }
+    __device__ void one(int64_t i, double *) { out[i] = in[i]; }
+};
+
+template <int SIGN>             // y = y + SIGN * x   (exact add/sub, no multiply)
+struct MkOpAddTo {
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *x;
+    double *y;
+    __device__ bool prologue(double *, bool) { return false; }
+    __device__ bool skip() const { return false; }
+    __device__ void pair(int64_t i, double *) {
+        double2 a = mk_ld2(x, i), b = mk_ld2(y, i);
+        b.x = SIGN > 0 ? b.x + a.x : b.x - a.x;
+        b.y = SIGN > 0 ? b.y + a.y : b.y - a.y;
+        mk_st2(y, i, b);
+    }
+    __device__ void one(int64_t i, double *) { y[i] = SIGN > 0 ? y[i] + x[i] : y[i] - x[i]; }
+};
+
+struct MkOpSub {                // out = a - b
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *a, *b;
+    double *out;
+    __device__ bool prologue(double *, bool) { return false; }
+    __device__ bool skip() const { return false; }
+    __device__ void pair(int64_t i, double *) {
+        double2 u = mk_ld2(a, i), v = mk_ld2(b, i);
+        u.x -= v.x;
+        u.y -= v.y;
+        mk_st2(out, i, u);
+    }
+    __device__ void one(int64_t i, double *) { out[i] = a[i] - b[i]; }
+};
+
+template <int SLOT>             // partial sums of dot(a, b) into slot SLOT
+struct MkOpDot {
+    static constexpr int NACC = 1, SLOT0 = SLOT;
+    const double *a, *b;
+    __device__ bool prologue(double *, bool) { return false; }
+    __device__ bool skip() const { return false; }
+    __device__ void pair(int64_t i, double *acc) {
+        double2 u = mk_ld2(a, i), v = mk_ld2(b, i);
+        acc[0] += u.x * v.x;
+        acc[0] += u.y * v.y;
+    }
+    __device__ void one(int64_t i, double *acc) { acc[0] += a[i] * b[i]; }
+};
+
+struct MkPlainEpi {             // y = A x, nothing fused
+    static constexpr int NACC = 0, SLOT0 = 0;
+    double *y;
+    __device__ void prologue(double *) {}
+    __device__ double xin(double v) const { return v; }
+    __device__ void row(int64_t r, double s, double *) { y[r] = s; }
+};
+
+template <class Op>
+static inline int mk_launch_stream(mk_solver *s, const Op &op, int64_t n) {
+    const int grid = mk_grid_stream(n);
+    hipLaunchKernelGGL(mk_stream_kernel<Op>, dim3(grid), dim3(MK_BLOCK), 0, s->stream, op, n, s->next_halt(),
+                       s->d_part);
+    return MK_OK;
+}
+
+template <class Epi>
+static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, bool timed = true) {
+    const int grid = mk_grid_spmv(s->A->ntiles);
+    if (timed) s->spmv_begin();
+    hipLaunchKernelGGL(mk_spmv_kernel<Epi>, dim3(grid), dim3(MK_BLOCK), 0, s->stream, mk_view(s->A), x, epi,
+                       s->next_halt(), s->d_part);
+    if (timed) s->spmv_end();
+    return MK_OK;
+}
+#endif

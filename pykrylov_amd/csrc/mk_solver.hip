@@ -1,0 +1,266 @@
+// mk_solver.hip -- generic driver of the device-resident solver loops + C ABI dispatch.
+#include "mk_solver.h"
+
+int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
+    A = A_;
+    prm = *p;
+    n = A->ex.mode >= 0 ? A->ex.n_local : A->nrows;
+    if (A->ex.mode < 0 && A->nrows != A->ncols)
+        return mk_fail(MK_ERR_ARG, "solver needs a square operator, got %lld x %lld", (long long)A->nrows,
+                       (long long)A->ncols);
+    nx = A->x_len();
+    stream = mk_ctx().stream;
+    MK_HIP(hipMalloc((void **)&d_scal, sizeof(double) * MK_NSCAL));
+    MK_HIP(hipMalloc((void **)&d_part, sizeof(double) * MK_NDOT * MK_MAXP));
+    MK_HIP(hipMalloc((void **)&d_halt, 2 * sizeof(int)));
+    MK_HIP(hipMalloc((void **)&d_status, sizeof(MkStatus)));
+    MK_HIP(hipMalloc((void **)&d_hist, sizeof(double) * MK_HIST_RING));
+    MK_HIP(hipHostMalloc((void **)&h_status, sizeof(MkStatus), hipHostMallocDefault));
+    MK_HIP(hipHostMalloc((void **)&h_scal, sizeof(double) * MK_NSCAL, hipHostMallocDefault));
+    MK_HIP(hipEventCreate(&ev0));
+    MK_HIP(hipEventCreate(&ev1));
+    // with several ranks every consumer adds all MK_MAXP slots (unused ones stay zero) so that the
+    // all-reduced partial vectors mean the same thing on every rank
+    const bool multi = mk_comm_active() != 0;
+    np_spmv = multi ? MK_MAXP : mk_grid_spmv(A->ntiles);
+    np_stream = multi ? MK_MAXP : mk_grid_stream(n);
+    const char *stride = getenv("MK_SPMV_EVENT_STRIDE");
+    spmv_sample_stride = stride ? atoi(stride) : 0;
+    return MK_OK;
+}
+
+mk_solver::~mk_solver() {
+    if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+    for (double *v : vecs) hipFree(v);
+    for (hipEvent_t e : spmv_ev) hipEventDestroy(e);
+    hipFree(d_scal);
+    hipFree(d_part);
+    hipFree(d_halt);
+    hipFree(d_status);
+    hipFree(d_hist);
+    if (h_status) hipHostFree(h_status);
+    if (h_scal) hipHostFree(h_scal);
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
+}
+
+int mk_solver::alloc_vec(double **out, int64_t len) {
+    double *p = nullptr;
+    MK_HIP(hipMalloc((void **)&p, sizeof(double) * (size_t)(len > 0 ? len : 1) + 16));
+    MK_HIP(hipMemsetAsync(p, 0, sizeof(double) * (size_t)(len > 0 ? len : 1) + 16, stream));
+    vecs.push_back(p);
+    *out = p;
+    return MK_OK;
+}
+
+int mk_solver::allreduce(int slot0, int nslots) {
+    if (!mk_comm_active()) return MK_OK;
+    return mk_comm_allreduce_sum(d_part + (size_t)slot0 * MK_MAXP, (int64_t)nslots * MK_MAXP, stream);
+}
+
+int mk_solver::exchange(double *x_ext) {
+    if (A->ex.mode < 0) return MK_OK;
+    return mk_exchange(A, x_ext);
+}
+
+void mk_solver::spmv_begin() {
+    if (spmv_sample_stride <= 0 || (it % spmv_sample_stride) != 0) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    spmv_ev.push_back(a);
+    spmv_ev.push_back(b);
+    hipEventRecord(a, stream);
+}
+
+void mk_solver::spmv_end() {
+    if (spmv_sample_stride <= 0 || (it % spmv_sample_stride) != 0 || spmv_ev.empty()) return;
+    hipEventRecord(spmv_ev.back(), stream);
+}
+
+int mk_solver::collect_spmv_timing() {
+    for (size_t i = 0; i + 1 < spmv_ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, spmv_ev[i], spmv_ev[i + 1]) == hipSuccess) {
+            spmv_ms += ms;
+            spmv_timed += 1;
+        }
+        hipEventDestroy(spmv_ev[i]);
+        hipEventDestroy(spmv_ev[i + 1]);
+    }
+    spmv_ev.clear();
+    return MK_OK;
+}
+
+int mk_solver::poll() {
+    MK_HIP(hipMemcpyAsync(h_status, d_status, sizeof(MkStatus), hipMemcpyDeviceToHost, stream));
+    MK_HIP(hipMemcpyAsync(h_scal, d_scal, sizeof(double) * MK_NSCAL, hipMemcpyDeviceToHost, stream));
+    int h[2];
+    MK_HIP(hipMemcpyAsync(h, d_halt, sizeof(h), hipMemcpyDeviceToHost, stream));
+    MK_HIP(hipStreamSynchronize(stream));
+    halted = h[q & 1] != 0;      // the word the NEXT kernel would read
+    // drain new residual-history entries from the ring
+    const int64_t have = h_status->hist_len;
+    if (have > hist_drained) {
+        if (have - hist_drained > MK_HIST_RING)
+            return mk_fail(MK_ERR_STATE, "history ring overrun (%lld new entries)", (long long)(have - hist_drained));
+        hist.resize((size_t)have);
+        int64_t pos = hist_drained;
+        while (pos < have) {
+            const int64_t off = pos % MK_HIST_RING;
+            int64_t cnt = have - pos;
+            if (cnt > MK_HIST_RING - off) cnt = MK_HIST_RING - off;
+            MK_HIP(hipMemcpyAsync(hist.data() + pos, d_hist + off, sizeof(double) * (size_t)cnt,
+                                  hipMemcpyDeviceToHost, stream));
+            pos += cnt;
+        }
+        MK_HIP(hipStreamSynchronize(stream));
+        hist_drained = have;
+    }
+    return MK_OK;
+}
+
+int mk_solver::iterate(int64_t max_iters, int64_t *done) {
+    if (!is_setup) return mk_fail(MK_ERR_STATE, "mk_solver_iterate before mk_solver_setup");
+    int64_t launched = 0;
+    int64_t batch = 16;
+    const int64_t itn0 = h_status->itn;
+    MK_HIP(hipEventRecord(ev0, stream));
+    while (!halted && launched < max_iters) {
+        int64_t todo = max_iters - launched;
+        if (todo > batch) todo = batch;
+        for (int64_t k = 0; k < todo; ++k) {
+            int rc = enqueue_pass();
+            if (rc != MK_OK) return rc;
+            ++it;
+        }
+        MK_HIP(hipGetLastError());
+        launched += todo;
+        int rc = poll();
+        if (rc != MK_OK) return rc;
+        if (batch < MK_BATCH_MAX) batch *= 2;
+    }
+    MK_HIP(hipEventRecord(ev1, stream));
+    MK_HIP(hipEventSynchronize(ev1));
+    float ms = 0.f;
+    MK_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    last_iterate_ms = ms;
+    collect_spmv_timing();
+    if (done) *done = h_status->itn - itn0;
+    return MK_OK;
+}
+
+void mk_solver::fill_result(mk_result *res) const {
+    memset(res, 0, sizeof(*res));
+    res->struct_size = (int32_t)sizeof(mk_result);
+    res->halted = halted ? 1 : 0;
+    res->nMatvec = h_status->nMatvec;
+    res->itn = h_status->itn;
+    res->hist_len = (int64_t)hist.size();
+    res->converged = h_status->converged;
+    res->definite = h_status->definite;
+    res->istop = h_status->istop;
+}
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" int mk_solver_create(const mk_csr *A, const mk_params *params, mk_solver **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A && params && out);
+    MK_ARG(params->struct_size == (int32_t)sizeof(mk_params));
+    mk_solver *s = nullptr;
+    switch (params->kind) {
+        case MK_CG: s = mk_make_cg(); break;
+        case MK_BICGSTAB: s = mk_make_bicgstab(); break;
+        case MK_CGS: s = mk_make_cgs(); break;
+        case MK_TFQMR: s = mk_make_tfqmr(); break;
+        case MK_MINRES: s = mk_make_minres(); break;
+        case MK_SYMMLQ: s = mk_make_symmlq(); break;
+        default: break;
+    }
+    if (!s) return mk_fail(MK_ERR_UNSUPPORTED, "mk_solver_create: solver kind %d is not available", params->kind);
+    int rc = s->init_common(A, params);
+    if (rc != MK_OK) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return MK_OK;
+}
+
+extern "C" int mk_solver_destroy(mk_solver *s) {
+    delete s;
+    return MK_OK;
+}
+
+extern "C" int mk_solver_setup(mk_solver *s, const double *rhs, const double *guess) {
+    MK_ARG(s && rhs);
+    s->q = 0;
+    s->it = 0;
+    s->halted = false;
+    s->hist.clear();
+    s->hist_drained = 0;
+    s->spmv_ms = 0.0;
+    s->spmv_timed = 0;
+    MK_HIP(hipMemsetAsync(s->d_halt, 0, 2 * sizeof(int), s->stream));
+    MK_HIP(hipMemsetAsync(s->d_status, 0, sizeof(MkStatus), s->stream));
+    MK_HIP(hipMemsetAsync(s->d_scal, 0, sizeof(double) * MK_NSCAL, s->stream));
+    MK_HIP(hipMemsetAsync(s->d_part, 0, sizeof(double) * MK_NDOT * MK_MAXP, s->stream));
+    int rc = s->setup(rhs, guess);
+    if (rc != MK_OK) return rc;
+    MK_HIP(hipGetLastError());
+    s->is_setup = true;
+    return s->poll();
+}
+
+extern "C" int mk_solver_iterate(mk_solver *s, int64_t max_iters, int64_t *iters_done) {
+    MK_ARG(s && max_iters >= 0);
+    return s->iterate(max_iters, iters_done);
+}
+
+extern "C" int mk_solver_finish(mk_solver *s, mk_result *res) {
+    MK_ARG(s && res);
+    if (!s->is_setup) return mk_fail(MK_ERR_STATE, "mk_solver_finish before mk_solver_setup");
+    return s->finish(res);
+}
+
+extern "C" int mk_solver_x(const mk_solver *s, const double **x_dev) {
+    MK_ARG(s && x_dev);
+    *x_dev = s->x();
+    return MK_OK;
+}
+
+extern "C" int mk_solver_history(const mk_solver *s, double *hist_host, int64_t cap) {
+    MK_ARG(s && (cap == 0 || hist_host));
+    int64_t cnt = (int64_t)s->hist.size();
+    if (cnt > cap) cnt = cap;
+    memcpy(hist_host, s->hist.data(), sizeof(double) * (size_t)cnt);
+    return MK_OK;
+}
+
+extern "C" int mk_solver_vector(const mk_solver *s, int index, const double **v_dev, int64_t *len) {
+    MK_ARG(s && v_dev);
+    const double *v = s->vector(index);
+    if (!v) return mk_fail(MK_ERR_ARG, "mk_solver_vector: index %d is not defined for this solver", index);
+    *v_dev = v;
+    if (len) *len = s->n;
+    return MK_OK;
+}
+
+extern "C" int mk_solver_timing(const mk_solver *s, double *iterate_ms, double *spmv_ms, int64_t *spmv_launches) {
+    MK_ARG(s != nullptr);
+    if (iterate_ms) *iterate_ms = s->last_iterate_ms;
+    if (spmv_ms) *spmv_ms = s->spmv_ms;
+    if (spmv_launches) *spmv_launches = s->spmv_timed;
+    return MK_OK;
+}
+
+extern "C" int mk_solver_solve(mk_solver *s, const double *rhs, const double *guess, mk_result *res) {
+    int rc = mk_solver_setup(s, rhs, guess);
+    if (rc != MK_OK) return rc;
+    while (!s->halted) {
+        rc = s->iterate((int64_t)1 << 20, nullptr);
+        if (rc != MK_OK) return rc;
+    }
+    return mk_solver_finish(s, res);
+}

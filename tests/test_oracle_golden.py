@@ -1,0 +1,220 @@
+"""Pins the CPU oracle (oracle/) against fixtures produced by the real reference.
+
+Everything here is CPU-only.  Bit-exact equality is demanded wherever the oracle
+and the reference perform the same floating-point operations in the same order
+(iteration counts, reduction traces, residual histories, iterates).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import csr_ref, krylov_ref as kr
+
+REF_EXAMPLES = "/root/reference/examples"
+
+
+def csr_from(d, prefix):
+    return csr_ref.RefCsr(d[prefix + "indptr"], d[prefix + "indices"], d[prefix + "data"], d[prefix + "shape"])
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+# ------------------------------------------------------------------ matrices
+@pytest.mark.parametrize("m", [10, 20, 100])
+def test_poisson2d_builder_bit_exact(golden, m):
+    d = golden("cg_poisson2d.npz")
+    A = csr_ref.poisson2d(m)
+    assert same(A.indptr, d["m%d_A_indptr" % m]) and A.indptr.dtype == np.int32
+    assert same(A.indices, d["m%d_A_indices" % m])
+    assert same(A.data, d["m%d_A_data" % m])
+
+
+@pytest.mark.parametrize("n", [10, 100, 1000])
+def test_poisson1d_builder_bit_exact(golden, n):
+    d = golden("cg_poisson1d.npz")
+    A = csr_ref.poisson1d(n)
+    for k in ("indptr", "indices", "data"):
+        assert same(getattr(A, k), d["n%d_A_%s" % (n, k)])
+
+
+@pytest.mark.parametrize("m", [8, 16])
+def test_poisson3d_builder_bit_exact(golden, m):
+    d = golden("large_summaries.npz")
+    A = csr_ref.poisson3d(m)
+    for k in ("indptr", "indices", "data"):
+        assert same(getattr(A, k), d["p3d%d_A_%s" % (m, k)])
+
+
+def test_random_builder_bit_exact(golden):
+    d = golden("nonsym_rand10k.npz")
+    A = csr_ref.random_diagdom(10000, seed=1)
+    for k in ("indptr", "indices", "data"):
+        assert same(getattr(A, k), d["A_" + k])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference examples not present on this box")
+@pytest.mark.parametrize("name,fix", [("1138bus.mtx", "cg_1138bus.npz"), ("jpwh_991.mtx", "nonsym_jpwh991.npz")])
+def test_matrix_market_reader_bit_exact(golden, name, fix):
+    d = golden(fix)
+    A = csr_ref.read_matrix_market(os.path.join(REF_EXAMPLES, name))
+    for k in ("indptr", "indices", "data"):
+        assert same(getattr(A, k), d["A_" + k])
+
+
+# ------------------------------------------------------------------ SpMV
+@pytest.mark.parametrize("force_numpy", [False, True])
+def test_spmv_matches_scipy_products(golden, force_numpy):
+    # rhs = A @ ones was produced by SciPy's csr_matvec in make_golden.py
+    for fix in ("cg_1138bus.npz", "nonsym_jpwh991.npz", "nonsym_rand10k.npz"):
+        d = golden(fix)
+        A = csr_from(d, "A_")
+        assert same(A.matvec(np.ones(A.shape[1]), force_numpy=force_numpy), d["rhs"])
+    d = golden("cg_poisson2d.npz")
+    A = csr_from(d, "m100_A_")
+    x = d["m100_randn_x"]
+    try:
+        import scipy.sparse as sp
+    except ImportError:
+        return
+    S = sp.csr_matrix((A.data, A.indices, A.indptr), shape=A.shape)
+    assert same(A.matvec(x, force_numpy=force_numpy), S @ x)
+    assert same(A.rmatvec(x), S.T.tocsr() @ x)
+
+
+# ------------------------------------------------------------------ CG
+def test_cg_1138bus(golden):
+    d = golden("cg_1138bus.npz")
+    A = csr_from(d, "A_")
+    out = kr.cg(A, d["rhs"])
+    assert out["nMatvec"] == int(d["nMatvec"]) == 1751
+    assert same(out["residHistory"], d["residHistory"])
+    assert same(out["x"], d["x"])
+    assert same(out["trace"], d["trace"])
+    assert out["residNorm0"] == float(d["residNorm0"])
+    assert bool(out["converged"]) == bool(d["converged"])
+
+
+@pytest.mark.parametrize("m", [10, 20, 100])
+@pytest.mark.parametrize("tag", ["ones", "randn"])
+def test_cg_poisson2d(golden, m, tag):
+    d = golden("cg_poisson2d.npz")
+    A = csr_from(d, "m%d_A_" % m)
+    k = "m%d_%s_" % (m, tag)
+    out = kr.cg(A, d[k + "rhs"])
+    assert out["nMatvec"] == int(d[k + "nMatvec"])
+    assert same(out["residHistory"], d[k + "residHistory"])
+    assert same(out["x"], d[k + "x"])
+
+
+@pytest.mark.parametrize("m", [10, 20, 100])
+def test_cg_warm_start_and_matvec_max(golden, m):
+    d = golden("cg_poisson2d.npz")
+    A = csr_from(d, "m%d_A_" % m)
+    n = m * m
+    out = kr.cg(A, A.matvec(np.ones(n)), guess=1.0 + np.arange(n), matvec_max=50)
+    k = "m%d_guess_" % m
+    assert out["nMatvec"] == int(d[k + "nMatvec"])
+    assert same(out["residHistory"], d[k + "residHistory"])
+    assert same(out["x"], d[k + "x"])
+
+
+def test_cg_poisson1d_doc_numbers(golden):
+    d = golden("cg_poisson1d.npz")
+    for n in (10, 100, 1000):
+        A = csr_from(d, "n%d_A_" % n)
+        out = kr.cg(A, A.matvec(np.ones(n)))
+        assert out["nMatvec"] == int(d["n%d_nMatvec" % n])
+        assert same(out["residHistory"], d["n%d_residHistory" % n])
+    # doc/source/introduction.rst:46-48: 50 matvecs, residual 7.39e-14
+    assert int(d["n100_nMatvec"]) == 50 and abs(float(d["n100_residNorm"]) - 7.39e-14) < 1e-16
+
+
+# ------------------------------------------------------------------ nonsymmetric solvers
+@pytest.mark.parametrize("fix", ["nonsym_jpwh991.npz", "nonsym_rand10k.npz"])
+@pytest.mark.parametrize("solver", ["bicgstab", "cgs", "tfqmr"])
+@pytest.mark.parametrize("tol", [1e-5, 1e-8])
+@pytest.mark.parametrize("gtag", ["guess", "zero"])
+def test_nonsymmetric(golden, fix, solver, tol, gtag):
+    d = golden(fix)
+    A = csr_from(d, "A_")
+    n = A.shape[0]
+    kw = dict(reltol=tol, matvec_max=2 * n)
+    if gtag == "guess":
+        kw["guess"] = 1.0 + np.arange(n)
+    with np.errstate(all="ignore"):
+        out = getattr(kr, solver)(A, d["rhs"], **kw)
+    k = "%s_%g_%s_" % (solver, tol, gtag)
+    assert out["nMatvec"] == int(d[k + "nMatvec"])
+    assert same(out["trace"], d[k + "trace"])
+    assert same(out["x"], d[k + "x"])
+    assert same(out["residNorm"], d[k + "residNorm"])
+    assert same(out["residNorm0"], d[k + "residNorm0"])
+    assert bool(out["converged"]) == bool(d[k + "converged"])
+
+
+def test_doc_numbers_jpwh991(golden):
+    # doc/source/bmark.rst:52-54 (Pysparse matvec): 82 / 84 / 84 matvecs at reltol 1e-8
+    d = golden("nonsym_jpwh991.npz")
+    got = [int(d["%s_1e-08_guess_nMatvec" % s]) for s in ("cgs", "tfqmr", "bicgstab")]
+    assert all(abs(g - w) <= 2 for g, w in zip(got, (82, 84, 84))), got
+
+
+# ------------------------------------------------------------------ MINRES
+@pytest.mark.parametrize("m", [30, 100])
+@pytest.mark.parametrize("shift", [0.0, 1.5])
+@pytest.mark.parametrize("check", [False, True])
+def test_minres(golden, m, shift, check):
+    d = golden("minres_poisson2d.npz")
+    A = csr_from(d, "m%d_A_" % m)
+    k = "m%d_s%g_c%d_" % (m, shift, check)
+    out = kr.minres(A, d[k + "rhs"], shift=shift, check=check, etol=0.0, rtol=1e-10)
+    assert (out["istop"], out["itn"]) == (int(d[k + "istop"]), int(d[k + "itn"]))
+    assert same(out["residHistory"], d[k + "residHistory"])
+    assert same(out["trace"], d[k + "trace"])
+    assert same(out["x"], d[k + "x"])
+    for name in ("rnorm", "Anorm", "Acond", "Arnorm", "ynorm", "residNorm0"):
+        assert out[name] == float(d[k + name]), name
+
+
+@pytest.mark.parametrize("m", [30, 100])
+def test_minres_default_etol_stops_on_direct_error(golden, m):
+    d = golden("minres_poisson2d.npz")
+    A = csr_from(d, "m%d_A_" % m)
+    k = "m%d_etoldef_" % m
+    out = kr.minres(A, A.matvec(np.ones(m * m)), check=False)
+    assert (out["istop"], out["itn"]) == (int(d[k + "istop"]), int(d[k + "itn"])) and out["istop"] == 10
+    assert same(out["residHistory"], d[k + "residHistory"])
+    assert same(out["dir_errors_window"], d[k + "dir_errors_window"])
+    assert same(out["x"], d[k + "x"])
+
+
+# ------------------------------------------------------------------ SYMMLQ
+@pytest.mark.parametrize("m", [30, 100])
+@pytest.mark.parametrize("shift", [0.0, 1.5])
+def test_symmlq(golden, m, shift):
+    d = golden("symmlq_poisson2d.npz")
+    A = csr_from(golden("minres_poisson2d.npz"), "m%d_A_" % m)
+    k = "m%d_s%g_" % (m, shift)
+    out = kr.symmlq(A, d[k + "rhs"], shift=(shift or None))
+    assert out["nMatvec"] == int(d[k + "nMatvec"])
+    assert same(out["trace"], d[k + "trace"])
+    assert same(out["x"], d[k + "x"])
+    for name in ("residNorm", "xNorm", "anorm", "acond"):
+        assert out[name] == float(d[k + name]), name
+
+
+# ------------------------------------------------------------------ large-n summaries
+def test_large_matrix_checksums(golden):
+    import hashlib
+    d = golden("large_summaries.npz")
+
+    def sha(a):
+        return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+    A = csr_ref.poisson2d(1000)
+    assert A.nnz == int(d["p2d1000_nnz"]) == 4996000
+    assert same(sha(A.indptr), d["p2d1000_indptr_sha"]) and same(sha(A.indices), d["p2d1000_indices_sha"])
