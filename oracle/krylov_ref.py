@@ -408,7 +408,8 @@ def minres(A, b, precon=None, shift=0.0, check=True, itnlim=None, rtol=1.0e-12, 
             x_nrg2 += phi * phi
             d_err[itn % window] = phi
             if itn > window:
-                trnc = np.linalg.norm(d_err)
+                trnc = np.linalg.norm(d_err)                 # length-`window` host array (minres.py:306)
+                red.trace.append(float(trnc))
                 x_nrg = np.sqrt(x_nrg2)
                 dir_errors.append(trnc / x_nrg)
                 if trnc < etol * x_nrg:

@@ -130,7 +130,9 @@ def test_cg_poisson1d_doc_numbers(golden):
         assert out["nMatvec"] == int(d["n%d_nMatvec" % n])
         assert same(out["residHistory"], d["n%d_residHistory" % n])
     # doc/source/introduction.rst:46-48: 50 matvecs, residual 7.39e-14
-    assert int(d["n100_nMatvec"]) == 50 and abs(float(d["n100_residNorm"]) - 7.39e-14) < 1e-16
+    # (with the matrix-free gallery operator the docs used; the CSR product rounds differently)
+    assert int(d["n100_nMatvec"]) == 50 == int(d["n100_gallery_nMatvec"])
+    assert abs(float(d["n100_gallery_residNorm"]) - 7.39e-14) < 1e-16
 
 
 # ------------------------------------------------------------------ nonsymmetric solvers
