@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- Krylov iterations/s of the device-resident CG + roofline of its SpMV kernel.
+
+    python bench.py --gpus 1 --steps K --warmup W            # BASELINE configs[1]: 2-D Poisson n=1e6
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W   # configs[4]: 512^3 on N GPUs
+
+A "step" is one pass of the CG loop body (reference pykrylov/cg/cg.py:113-158: 1 SpMV, 2 dots,
+3 vector updates) on synthetic data resident in HBM.  Tolerances are set to zero so that exactly
+K passes run inside the timed region.  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json `configs`):
+  poisson2d-1000   configs[1]  CG, 2-D 5-point Poisson, n = 1e6, one GPU         (default at N = 1)
+  poisson3d-512    configs[4]  CG, 3-D 7-point Poisson 512^3 row-partitioned over N GPUs (default at N > 1;
+                               strong scaling: the total problem is fixed)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s per GPU
+
+
+def spmv_bytes(nrows, ncols, nnz):
+    """Algorithmic bytes of one CSR SpMV launch: 12 nnz + 4 (n+1) + 8 ncols + 8 nrows."""
+    return 12 * nnz + 4 * (nrows + 1) + 8 * ncols + 8 * nrows
+
+
+def build_workload(name, world):
+    from pykrylov_amd import gallery, dist
+    if name.startswith("poisson2d-"):
+        m = int(name.split("-")[1])
+        n = m * m
+        if world.nranks == 1:
+            return gallery.poisson2d(m), n, {"grid": [m, m], "stencil": 5}
+        indptr, indices, data, _ = gallery.poisson2d_csr(m)
+        op, _ = dist.partition_host_csr(world, indptr, indices, data, n, mode=ARGS.exchange)
+        return op, n, {"grid": [m, m], "stencil": 5}
+    if name.startswith("poisson3d-"):
+        m = int(name.split("-")[1])
+        n = m ** 3
+        if world.nranks == 1:
+            return gallery.poisson3d(m), n, {"grid": [m, m, m], "stencil": 7}
+        op, _ = dist.partition_poisson3d(world, m, m, m, mode=ARGS.exchange)
+        return op, n, {"grid": [m, m, m], "stencil": 7}
+    raise SystemExit("unknown workload %r" % name)
+
+
+def cpu_baseline(name, seconds_budget=20.0):
+    """The CPU oracle (NumPy restatement of the reference loop + C CSR product, one core) timed on a
+    bounded sample of the same workload."""
+    from oracle import csr_ref, krylov_ref
+    m = int(name.split("-")[1])
+    if name.startswith("poisson2d-"):
+        A = csr_ref.poisson2d(m)
+        scale, sample = 1.0, "first %%d CG iterations of %s (n=%d), rhs=A*1" % (name, m * m)
+    else:
+        ms = min(m, 128)                 # 512^3 does not fit a host-side sample: time 128^3 and scale by rows
+        A = csr_ref.poisson3d(ms)
+        scale = float(ms ** 3) / float(m ** 3)
+        sample = ("first %%d CG iterations on %d^3 (%d rows), iterations/s scaled by rows ratio %.4g to %s"
+                  % (ms, ms ** 3, scale, name))
+    n = A.shape[0]
+    rhs = A.matvec(np.ones(n))
+    t0 = time.perf_counter()
+    krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=10)
+    per_it = (time.perf_counter() - t0) / 10.0
+    iters = int(max(20, min(2000, seconds_budget / max(per_it, 1e-6))))
+    t0 = time.perf_counter()
+    out = krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=iters)
+    dt = time.perf_counter() - t0
+    return {"value": out["nMatvec"] / dt * scale, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": sample % out["nMatvec"], "host_cpus": os.cpu_count(),
+            "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS", "default")}
+
+
+def main():
+    global ARGS
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="auto")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"])
+    ap.add_argument("--event-stride", type=int, default=4, help="bracket the SpMV of every k-th pass with HIP events")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ARGS = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != ARGS.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (ARGS.gpus, world_size, ARGS.gpus))
+    td = torch = None
+    if world_size > 1:
+        import torch
+        import torch.distributed as td
+        torch.cuda.set_device(local_rank)
+        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from pykrylov_amd import _lib, dist
+    from pykrylov_amd.generic import DeviceRun
+    lib = _lib.init(local_rank)
+    world = dist.World(rank, world_size, td)
+    if world_size > 1:
+        world.init_device_comm()
+
+    name = ARGS.workload
+    if name == "auto":
+        name = "poisson2d-1000" if world_size == 1 else "poisson3d-512"
+
+    def run_cg(workload, steps, warmup, stride):
+        op, n_global, meta = build_workload(workload, world)
+        n_local = getattr(op, "local_size", None) or op.shape[1]
+        ones = _lib.DeviceArray.from_numpy(np.ones(op.shape[1]))
+        rhs = _lib.DeviceArray(n_local)
+        op.spmv_device(ones.ptr, rhs.ptr)                     # rhs = A * 1 (test_diagdom.py:78-79 convention)
+        # tolerances 0: never converges, so exactly `steps` passes run inside the timed region
+        run = DeviceRun(op, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=1 << 60,
+                        check_curvature=1, spmv_event_stride=stride)
+        run.setup()
+        done_w = run.iterate(warmup)
+        _lib.check(lib.mk_sync())
+        if td is not None:
+            torch.cuda.synchronize()
+            td.barrier(device_ids=[local_rank])
+        t0 = time.perf_counter()
+        done = run.iterate(steps)
+        _lib.check(lib.mk_sync())
+        if td is not None:
+            torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if td is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            elapsed = float(t.item())
+            td.barrier(device_ids=[local_rank])
+        timing = run.timing()
+        res = run.finish()
+        assert done == steps and done_w == warmup, (done, steps, done_w, warmup)
+        assert np.isfinite(res.residNorm), "CG diverged"
+        hist = run.history()
+        info = dict(op_shape=op.shape, nnz=op.nnz, n_local=n_local, n_global=n_global, meta=meta, elapsed=elapsed,
+                    timing=timing, resid_first=float(hist[0]), resid_last=float(hist[-1]))
+        run.close()
+        op.free()
+        return info
+
+    info = run_cg(name, ARGS.steps, ARGS.warmup, ARGS.event_stride)
+    elapsed = info["elapsed"]
+    its = ARGS.steps / elapsed
+    n_g, n_l = info["n_global"], info["n_local"]
+    b_spmv = spmv_bytes(n_l, info["op_shape"][1], info["nnz"])
+    tm = info["timing"]
+    spmv_avg_ms = tm["spmv_ms"] / max(1, tm["spmv_launches"])
+    achieved = b_spmv / (spmv_avg_ms * 1e-3) / 1e9 if tm["spmv_launches"] else None
+    # whole-iteration roofline with the reference's op count: B_spmv + 104 n per pass
+    stencil = info["meta"]["stencil"]
+    nnz_global = stencil * n_g - 2 * sum(n_g // g for g in info["meta"]["grid"])
+    iter_bytes = spmv_bytes(n_g, n_g, nnz_global) + 104 * n_g
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("%s@%d" % (name, world_size))
+
+    line = {
+        "metric": "Krylov iters/sec + SpMV achieved HBM GB/s (% of peak), fp64",
+        "value": its, "unit": "iterations/s", "n_gpus": world_size, "steps": ARGS.steps, "warmup": ARGS.warmup,
+        "ms_per_step": 1e3 * elapsed / ARGS.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "CG %s (%d rows, %d nnz), rhs=A*1, x0=0, tolerances 0" % (name, n_g, nnz_global),
+                   "solver": "cg", "rows": n_g, "nnz": nnz_global,
+                   "parallelism": "1 GPU" if world_size == 1 else "row-partition x%d, %s exchange + allreduce(dots), RCCL"
+                                  % (world_size, ARGS.exchange)},
+        "roofline": {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpi> (CSR-stream SpMV + fused <p,Ap>)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "bytes_per_launch": b_spmv, "avg_launch_us": 1e3 * spmv_avg_ms,
+                     "launches_timed": tm["spmv_launches"]},
+        "iteration_roofline": {"algorithmic_bytes_per_iter": iter_bytes,
+                               "achieved_GBs": iter_bytes * its / 1e9,
+                               "frac_of_aggregate_hbm": iter_bytes * its / 1e9 / (HBM_PEAK_GBS * world_size)},
+        "device_loop_ms": tm["iterate_ms"],
+        "residual": {"first": info["resid_first"], "last": info["resid_last"]},
+    }
+    if rank == 0 and world_size == 1 and not ARGS.no_cpu:
+        line["cpu_baseline"] = cpu_baseline(name)
+    if world_size == 1 and name == "poisson2d-1000" and not ARGS.no_extra:
+        # N=1 reference point of the strong-scaling series the N>1 runs belong to (configs[4])
+        ex = run_cg("poisson3d-512", 100, 10, 0)
+        line["extra"] = {"poisson3d-512@1": {"value": 100 / ex["elapsed"], "unit": "iterations/s",
+                                             "ms_per_step": 1e3 * ex["elapsed"] / 100}}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if td is not None:
+        lib.mk_comm_destroy()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,7 +105,15 @@ int mk_comm_info(int *nranks, int *rank);
  * last rank possibly fewer). */
 int mk_csr_set_exchange(mk_csr *A, int mode, int64_t n_local, int64_t n_halo, const int64_t *send_count,
                         const int64_t *recv_count, const int32_t *send_idx_host);
-/* x_ext_dev has n_local + n_halo entries (mode 0) or the global length (mode 1). */
+/* Rewrite the global column ids of a row block [col_begin, col_end) of a square matrix into the
+ * local numbering, in place, on the device.
+ * mode 0 (halo): columns outside the owned range must lie in two contiguous windows next to it
+ *   (banded / stencil matrices); their widths are returned in halo_lo / halo_hi and the new
+ *   numbering is [owned | lower window | upper window], ncols becomes n_local + lo + hi.
+ * mode 1 (allgather): col' = n_local + col, ncols becomes n_local + gathered_len. */
+int mk_csr_localize(mk_csr *A, int mode, int64_t col_begin, int64_t col_end, int64_t gathered_len,
+                    int64_t *halo_lo, int64_t *halo_hi);
+/* x_ext_dev has n_local + n_halo entries: the rank's own slice first, received entries after. */
 int mk_exchange(const mk_csr *A, double *x_ext_dev);
 
 /* ------------------------------------------------------------------ solvers ---- */
@@ -131,7 +139,7 @@ typedef struct {
     double etol;              /* minres.py:127 */
     int64_t itnlim;           /* minres.py:125 */
     int32_t window;           /* minres.py:130 */
-    int32_t reserved;
+    int32_t spmv_event_stride; /* >0: bracket the SpMV kernel of every k-th pass with HIP events */
 } mk_params;
 
 typedef struct {

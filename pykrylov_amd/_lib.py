@@ -21,7 +21,7 @@ MK_CG, MK_BICGSTAB, MK_CGS, MK_TFQMR, MK_MINRES, MK_SYMMLQ = 1, 2, 3, 4, 5, 6
 class MkParams(ctypes.Structure):
     _fields_ = [("struct_size", c_i32), ("kind", c_i32), ("abstol", c_f64), ("reltol", c_f64),
                 ("matvec_max", c_i64), ("check_curvature", c_i32), ("has_shift", c_i32), ("shift", c_f64),
-                ("rtol", c_f64), ("etol", c_f64), ("itnlim", c_i64), ("window", c_i32), ("reserved", c_i32)]
+                ("rtol", c_f64), ("etol", c_f64), ("itnlim", c_i64), ("window", c_i32), ("spmv_event_stride", c_i32)]
 
 
 class MkResult(ctypes.Structure):
@@ -64,6 +64,7 @@ PROTOTYPES = {
     "mk_comm_destroy": (ctypes.c_int, []),
     "mk_comm_info": (ctypes.c_int, [P(ctypes.c_int), P(ctypes.c_int)]),
     "mk_csr_set_exchange": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "mk_csr_localize": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_i64, P(c_i64), P(c_i64)]),
     "mk_exchange": (ctypes.c_int, [c_vp, c_vp]),
     "mk_solver_create": (ctypes.c_int, [c_vp, P(MkParams), P(c_vp)]),
     "mk_solver_destroy": (ctypes.c_int, [c_vp]),

@@ -165,6 +165,70 @@ extern "C" int mk_csr_set_exchange(mk_csr *A, int mode, int64_t n_local, int64_t
     return MK_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(MK_BLOCK) void col_extent_kernel(int64_t nnz, const int32_t *__restrict__ idx,
+                                                              int *__restrict__ minmax) {
+    int lo = 2147483647, hi = -1;
+    for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * MK_BLOCK) {
+        const int c = idx[j];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+    atomicMin(&minmax[0], lo);
+    atomicMax(&minmax[1], hi);
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void col_remap_kernel(int64_t nnz, int32_t *__restrict__ idx, int64_t c0,
+                                                             int64_t c1, int64_t lo_begin, int64_t n_local,
+                                                             int64_t halo_lo, int mode) {
+    for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * MK_BLOCK) {
+        const int64_t c = idx[j];
+        int64_t v;
+        if (mode == 1) v = n_local + c;
+        else if (c < c0) v = n_local + (c - lo_begin);
+        else if (c >= c1) v = n_local + halo_lo + (c - c1);
+        else v = c - c0;
+        idx[j] = (int32_t)v;
+    }
+}
+}  // namespace
+
+extern "C" int mk_csr_localize(mk_csr *A, int mode, int64_t col_begin, int64_t col_end, int64_t gathered_len,
+                               int64_t *halo_lo, int64_t *halo_hi) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A && (mode == 0 || mode == 1) && col_begin >= 0 && col_begin <= col_end && col_end <= A->ncols);
+    MK_ARG(col_end - col_begin == A->nrows);
+    hipStream_t st = mk_ctx().stream;
+    const int64_t n_local = A->nrows;
+    int64_t lo = 0, hi = 0, lo_begin = col_begin;
+    int grid = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
+    grid = grid < 1 ? 1 : (grid > 8192 ? 8192 : grid);
+    if (mode == 0 && A->nnz > 0) {
+        int *d_mm = nullptr;
+        int h_mm[2] = {2147483647, -1};
+        MK_HIP(hipMalloc((void **)&d_mm, sizeof(h_mm)));
+        MK_HIP(hipMemcpyAsync(d_mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(col_extent_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_indices, d_mm);
+        MK_HIP(hipMemcpyAsync(h_mm, d_mm, sizeof(h_mm), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        MK_HIP(hipFree(d_mm));
+        if (h_mm[0] < col_begin) lo = col_begin - h_mm[0];
+        if (h_mm[1] >= col_end) hi = h_mm[1] - col_end + 1;
+        lo_begin = col_begin - lo;
+    }
+    const int64_t new_cols = (mode == 1) ? n_local + gathered_len : n_local + lo + hi;
+    if (new_cols > 2147483647LL) return mk_fail(MK_ERR_UNSUPPORTED, "localized column count exceeds int32");
+    if (A->nnz > 0)
+        hipLaunchKernelGGL(col_remap_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_indices, col_begin,
+                           col_end, lo_begin, n_local, lo, mode);
+    MK_HIP(hipGetLastError());
+    MK_HIP(hipStreamSynchronize(st));
+    A->ncols = new_cols;
+    if (halo_lo) *halo_lo = lo;
+    if (halo_hi) *halo_hi = hi;
+    return MK_OK;
+}
+
 extern "C" int mk_exchange(const mk_csr *A, double *x_ext) {
     MK_ARG(A && x_ext);
     const MkExchange &ex = A->ex;

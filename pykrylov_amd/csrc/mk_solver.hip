@@ -24,8 +24,7 @@ int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
     const bool multi = mk_comm_active() != 0;
     np_spmv = multi ? MK_MAXP : mk_grid_spmv(A->ntiles);
     np_stream = multi ? MK_MAXP : mk_grid_stream(n);
-    const char *stride = getenv("MK_SPMV_EVENT_STRIDE");
-    spmv_sample_stride = stride ? atoi(stride) : 0;
+    spmv_sample_stride = prm.spmv_event_stride;
     return MK_OK;
 }
 

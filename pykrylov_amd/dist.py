@@ -1,0 +1,202 @@
+"""Row-partitioned multi-GPU execution: one process per GPU, RCCL over xGMI.
+
+The reference is single-process; this module is new design.  The matrix is
+split into contiguous row blocks, every solver vector likewise.  Before each SpMV a rank needs
+the entries of the input vector owned by other ranks that its rows reference:
+
+* ``halo``      -- neighbour send/recv of exactly those entries (2 planes of 512^2 doubles for
+                   the slab-partitioned 512^3 Poisson problem); the path that fits the xGMI budget;
+* ``allgather`` -- RCCL all-gather of the whole iterate, the general path north_star names.
+
+Dot products are all-reduced as vectors of per-workgroup partial sums (``csrc/mk_solver.hip``).
+The integer planning below is plain NumPy so that it can be tested on CPU (world_size 2, gloo);
+the exchange itself runs in ``libmikrylov.so`` (``mk_exchange``), enqueued on the solver's stream.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+# ======================================================================================
+# pure planning (no GPU, no communication)
+# ======================================================================================
+def row_ranges(n, nranks, align=1):
+    """Contiguous, balanced row blocks; block starts are multiples of `align` (e.g. a grid plane)."""
+    units = n // align
+    assert units * align == n, "n must be a multiple of align"
+    base, extra = divmod(units, nranks)
+    starts = [0]
+    for r in range(nranks):
+        starts.append(starts[-1] + (base + (1 if r < extra else 0)) * align)
+    return [(starts[r], starts[r + 1]) for r in range(nranks)]
+
+
+def equal_ranges(n, nranks):
+    """Blocks of ceil(n / nranks) rows (the layout an all-gather needs); trailing blocks may be short."""
+    cnt = -(-n // nranks)
+    if cnt * nranks != n:
+        raise NotImplementedError("all-gather exchange needs n divisible by the number of ranks "
+                                  "(got n=%d, ranks=%d); use mode='halo'" % (n, nranks))
+    return [(min(n, r * cnt), min(n, (r + 1) * cnt)) for r in range(nranks)], cnt
+
+
+def owner_of(cols, ranges):
+    starts = np.array([r[0] for r in ranges] + [ranges[-1][1]], dtype=np.int64)
+    return np.searchsorted(starts, cols, side="right") - 1
+
+
+def needed_columns(indices, c0, c1):
+    """Sorted unique global columns outside the owned range [c0, c1)."""
+    idx = np.asarray(indices, dtype=np.int64)
+    off = idx[(idx < c0) | (idx >= c1)]
+    return np.unique(off)
+
+
+def localize_columns(indices, c0, c1, halo_cols):
+    """Global -> local column ids: owned columns first, then `halo_cols` in ascending order."""
+    idx = np.asarray(indices, dtype=np.int64)
+    out = idx - c0
+    off = (idx < c0) | (idx >= c1)
+    out[off] = (c1 - c0) + np.searchsorted(halo_cols, idx[off])
+    return out.astype(np.int32)
+
+
+def halo_plan(rank, ranges, needs_by_rank):
+    """Exchange plan of `rank` from every rank's sorted needed-column list.
+
+    Returns ``(send_count[nranks], recv_count[nranks], send_idx)`` where `send_idx` holds local
+    row indices grouped by destination rank and the halo region of this rank is the
+    concatenation, in rank order, of what it receives (= its own needs in ascending order).
+    """
+    nranks = len(ranges)
+    c0, c1 = ranges[rank]
+    recv_count = np.zeros(nranks, dtype=np.int64)
+    mine = np.asarray(needs_by_rank[rank], dtype=np.int64)
+    if mine.size:
+        own = owner_of(mine, ranges)
+        assert not np.any(own == rank)
+        recv_count = np.bincount(own, minlength=nranks).astype(np.int64)
+    send_count = np.zeros(nranks, dtype=np.int64)
+    send_idx = []
+    for r in range(nranks):
+        if r == rank:
+            continue
+        want = np.asarray(needs_by_rank[r], dtype=np.int64)
+        sel = want[(want >= c0) & (want < c1)]
+        send_count[r] = sel.size
+        send_idx.append((sel - c0).astype(np.int32))
+    send_idx = np.concatenate(send_idx) if send_idx else np.zeros(0, dtype=np.int32)
+    return send_count, recv_count, send_idx
+
+
+def banded_needs(c0, c1, halo_lo, halo_hi):
+    """Needed columns of a banded row block: the two contiguous windows next to the owned range."""
+    return np.concatenate([np.arange(c0 - halo_lo, c0, dtype=np.int64),
+                           np.arange(c1, c1 + halo_hi, dtype=np.int64)])
+
+
+# ======================================================================================
+# process group / communicator bootstrap
+# ======================================================================================
+class World(object):
+    """Rank bookkeeping + a tiny object all-gather used only while planning.
+
+    `torch.distributed` (already initialised by the launcher contract of bench.py, backend nccl
+    on GPUs, gloo in CPU tests) carries the planning metadata and the 128-byte RCCL id; the
+    per-iteration collectives never go through torch."""
+
+    def __init__(self, rank=0, nranks=1, torch_dist=None):
+        self.rank, self.nranks, self.td = rank, nranks, torch_dist
+
+    @classmethod
+    def from_env(cls):
+        nranks = int(os.environ.get("WORLD_SIZE", "1"))
+        if nranks == 1:
+            return cls()
+        import torch.distributed as td
+        assert td.is_initialized(), "initialise torch.distributed before pykrylov_amd.dist.World.from_env()"
+        return cls(td.get_rank(), td.get_world_size(), td)
+
+    def allgather_object(self, obj):
+        if self.nranks == 1:
+            return [obj]
+        out = [None] * self.nranks
+        self.td.all_gather_object(out, obj)
+        return out
+
+    def init_device_comm(self):
+        """Create the RCCL communicator inside libmikrylov (one per process)."""
+        lib = _lib.init()
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.mk_comm_unique_id(buf))
+        uid = self.allgather_object(bytes(buf.raw))[0]
+        _lib.check(lib.mk_comm_init(self.nranks, self.rank, ctypes.c_char_p(uid)))
+
+
+def attach_exchange(op, mode, n_local, n_halo, send_count=None, recv_count=None, send_idx=None):
+    lib = _lib.init()
+    sc = None if send_count is None else np.ascontiguousarray(send_count, dtype=np.int64)
+    rc = None if recv_count is None else np.ascontiguousarray(recv_count, dtype=np.int64)
+    si = None if send_idx is None else np.ascontiguousarray(send_idx, dtype=np.int32)
+    _lib.check(lib.mk_csr_set_exchange(op.handle, mode, n_local, n_halo,
+                                       None if sc is None else sc.ctypes.data,
+                                       None if rc is None else rc.ctypes.data,
+                                       None if si is None or si.size == 0 else si.ctypes.data))
+    op.local_size = int(n_local)
+    op.halo_size = int(n_halo)
+    return op
+
+
+def partition_host_csr(world, indptr, indices, data, n, mode="halo"):
+    """Distribute a (replicated) host CSR matrix: every rank keeps its row block on its GPU."""
+    from .linop import CsrOperator
+    from .sparse import csr_row_slice
+    if mode == "allgather":
+        ranges, cnt = equal_ranges(n, world.nranks)
+    else:
+        ranges = row_ranges(n, world.nranks)
+    c0, c1 = ranges[world.rank]
+    lp, li, ld = csr_row_slice(indptr, indices, data, c0, c1)
+    n_local = c1 - c0
+    if mode == "allgather":
+        n_halo = cnt * world.nranks
+        op = CsrOperator(lp, li.astype(np.int64) + n_local, ld, (n_local, n_local + n_halo))
+        return attach_exchange(op, 1, n_local, n_halo), ranges
+    need = needed_columns(li, c0, c1)
+    needs = world.allgather_object(need)
+    send_count, recv_count, send_idx = halo_plan(world.rank, ranges, needs)
+    lcols = localize_columns(li, c0, c1, need)
+    op = CsrOperator(lp, lcols, ld, (n_local, n_local + need.size))
+    return attach_exchange(op, 0, n_local, need.size, send_count, recv_count, send_idx), ranges
+
+
+def partition_poisson3d(world, nx, ny, nz, mode="halo"):
+    """7-point Poisson matrix on an nx x ny x nz grid, slab-partitioned in z, generated per rank in
+    HBM (BASELINE config 5: 512^3 never exists on the host)."""
+    from .linop import CsrOperator
+    lib = _lib.init()
+    n = nx * ny * nz
+    if mode == "allgather":
+        ranges, cnt = equal_ranges(n, world.nranks)
+    else:
+        ranges = row_ranges(n, world.nranks, align=nx * ny)
+    c0, c1 = ranges[world.rank]
+    h = ctypes.c_void_p()
+    _lib.check(lib.mk_csr_poisson3d(nx, ny, nz, c0, c1, ctypes.byref(h)))
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    n_local = c1 - c0
+    if mode == "allgather":
+        n_halo = cnt * world.nranks
+        _lib.check(lib.mk_csr_localize(h, 1, c0, c1, n_halo, ctypes.byref(lo), ctypes.byref(hi)))
+        op = CsrOperator.from_handle(h.value)
+        return attach_exchange(op, 1, n_local, n_halo), ranges
+    _lib.check(lib.mk_csr_localize(h, 0, c0, c1, 0, ctypes.byref(lo), ctypes.byref(hi)))
+    op = CsrOperator.from_handle(h.value)
+    windows = world.allgather_object((c0, c1, lo.value, hi.value))
+    needs = [banded_needs(*w) for w in windows]
+    send_count, recv_count, send_idx = halo_plan(world.rank, ranges, needs)
+    return attach_exchange(op, 0, n_local, lo.value + hi.value, send_count, recv_count, send_idx), ranges

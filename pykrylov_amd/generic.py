@@ -90,10 +90,17 @@ class DeviceRun(object):
     def __init__(self, op, kind, rhs, guess=None, **params):
         self.lib = _lib.init()
         self.op = op
-        n = op.shape[1]
+        n = getattr(op, 'local_size', None) or op.shape[1]     # row-partitioned operator: local rows
         self.n = n
-        self.d_rhs = _lib.DeviceArray.from_numpy(as_f64_vector(rhs, n, 'rhs'))
-        self.d_guess = None if guess is None else _lib.DeviceArray.from_numpy(as_f64_vector(guess, n, 'guess'))
+        # rhs / guess: host arrays (copied to HBM) or DeviceArray objects already resident there
+        self._borrowed = [b for b in (rhs, guess) if isinstance(b, _lib.DeviceArray)]
+        self.d_rhs = rhs if isinstance(rhs, _lib.DeviceArray) else \
+            _lib.DeviceArray.from_numpy(as_f64_vector(rhs, n, 'rhs'))
+        self.d_guess = None if guess is None else (
+            guess if isinstance(guess, _lib.DeviceArray) else
+            _lib.DeviceArray.from_numpy(as_f64_vector(guess, n, 'guess')))
+        if self.d_rhs.n != n or (self.d_guess is not None and self.d_guess.n != n):
+            raise ValueError('rhs / guess must have %d entries' % n)
         p = _lib.MkParams()
         p.struct_size = ctypes.sizeof(_lib.MkParams)
         p.kind = kind
@@ -154,7 +161,7 @@ class DeviceRun(object):
             self.lib.mk_solver_destroy(self.handle)
             self.handle = ctypes.c_void_p()
         for b in (self.d_rhs, self.d_guess):
-            if b is not None:
+            if b is not None and not any(b is x for x in getattr(self, '_borrowed', [])):
                 b.free()
 
     def __enter__(self):

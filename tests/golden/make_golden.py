@@ -134,15 +134,20 @@ class _LinalgProxy:
         return getattr(np.linalg, k)
 
 
+def _exact_dot(a, b):
+    return np.float64(np.dot(a.astype(np.longdouble), b.astype(np.longdouble)))
+
+
 class _NumpyProxy:
     """Stands in for the module-level name ``np`` inside one solver module."""
 
-    def __init__(self, log):
+    def __init__(self, log, exact=False):
         self._log = log
+        self._exact = exact
         self.linalg = _LinalgProxy(log)
 
     def dot(self, a, b):
-        v = np.dot(a, b)
+        v = _exact_dot(a, b) if self._exact else np.dot(a, b)
         self._log.append(float(v))
         return v
 
@@ -151,13 +156,13 @@ class _NumpyProxy:
 
 
 @contextlib.contextmanager
-def traced(module):
+def traced(module, exact=False):
     """Record dots/norms made through ``np.*`` or bare ``dot``/``norm`` names of *module*."""
     log = []
     saved = {}
     if hasattr(module, "np"):
         saved["np"] = module.np
-        module.np = _NumpyProxy(log)
+        module.np = _NumpyProxy(log, exact)
     if hasattr(module, "dot"):
         saved["dot"] = module.dot
 
@@ -381,6 +386,13 @@ def main():
     s.solve(rhs)
     out.update({"p2d1000_cg_nMatvec": s.nMatvec, "p2d1000_cg_residHistory": np.array(s.residHistory),
                 "p2d1000_cg_x_sample": s.x[::997].copy(), "p2d1000_cg_residNorm": s.residNorm})
+    # the same reference code with np.dot replaced by an exactly rounded inner product (80-bit
+    # accumulation): separates the reference's own summation noise from the algorithm
+    with traced(m_cg, exact=True):
+        s = m_cg.CG(csr_op(A, True))
+        s.solve(rhs)
+    out.update({"p2d1000_cg_residHistory_exactdot": np.array(s.residHistory),
+                "p2d1000_cg_nMatvec_exactdot": s.nMatvec})
     A = random_diagdom(1000000, seed=1)
     n = A.shape[0]
     out.update({"rand1m_nnz": A.nnz, "rand1m_indptr_sha": sha(A.indptr), "rand1m_indices_sha": sha(A.indices),

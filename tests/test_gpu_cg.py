@@ -46,18 +46,22 @@ def test_cg_poisson2d_vs_golden(golden, m, tag):
 
 
 def test_cg_1138bus_config1(golden):
-    """BASELINE config 1.  The iteration count on this ill-conditioned matrix depends on the dot
-    summation order (1751 with np.dot, 1759 in the docs with Pysparse), so the
-    count is bracketed and the trajectory compared over its well-conditioned head."""
+    """BASELINE config 1.  On this ill-conditioned matrix CG is chaotic with respect to the dot
+    summation order: the reference's own history moves by O(1) relative after ~50 iterations when
+    np.dot is replaced by an exactly rounded dot (1751 matvecs with np.dot, 1757 with exact dots,
+    1759 in doc/source/cg.rst:59 with Pysparse).  What is comparable: the first iterations, the
+    iteration count to within that spread, convergence and the solution; bit-level agreement with the
+    oracle run in the device's summation order is checked in test_cg_bit_exact_with_emulated_dot_order."""
     from pykrylov_amd import CG
     d = golden("cg_1138bus.npz")
     A = golden_csr(d, "A_")
     s = CG(op_from(A, symmetric=True))
     s.solve(d["rhs"])
     assert abs(s.nMatvec - int(d["nMatvec"])) <= 40
-    assert s.converged and s.residNorm0 == float(d["residNorm0"])
-    assert rel_hist_err(s.residHistory[:200], d["residHistory"][:200]) <= 1e-9
+    assert s.converged and abs(s.residNorm0 - float(d["residNorm0"])) <= 1e-14 * float(d["residNorm0"])
+    assert rel_hist_err(s.residHistory[:8], d["residHistory"][:8]) <= 1e-10
     assert np.linalg.norm(s.x - 1.0) / np.sqrt(A.shape[0]) < 1e-4        # doc/source/cg.rst:59: error 1.30e-05
+    assert np.linalg.norm(s.x - d["x"]) / np.linalg.norm(d["x"]) < 1e-4
 
 
 @pytest.mark.parametrize("n", [10, 100, 1000])
@@ -68,7 +72,9 @@ def test_cg_poisson1d(golden, n):
     s = CG(op_from(A, symmetric=True))
     s.solve(A.matvec(np.ones(n)))
     assert s.nMatvec == int(d["n%d_nMatvec" % n])
-    assert rel_hist_err(s.residHistory, d["n%d_residHistory" % n]) <= TOL
+    href = d["n%d_residHistory" % n]
+    # finite termination: the last entry is pure rounding noise (exact arithmetic gives 0) -> excluded
+    assert rel_hist_err(s.residHistory[:-1], href[:-1]) <= TOL and s.residHistory[-1] <= 1e-10
     cond = 4.0 * (n + 1) ** 2 / np.pi ** 2
     assert np.allclose(1.0, s.x, rtol=cond * np.finfo(float).eps * 10)   # test_diagdom.py:33-47 criterion
 
@@ -91,24 +97,29 @@ def test_cg_warm_start_matvec_max(golden, m):
     assert np.array_equal(rhs, rhs0) and np.array_equal(guess, guess0)   # inputs are never modified
 
 
-def test_cg_bit_exact_with_emulated_dot_order(golden):
-    """With the oracle's dots replaced by the device's summation tree every other operation must
-    round identically: history and iterate are compared for BIT equality."""
-    from pykrylov_amd import CG
+def emulated_dots(n):
     from oracle import gpu_order
-    d = golden("cg_poisson2d.npz")
-    A = golden_csr(d, "m100_A_")
-    rhs = d["m100_randn_rhs"]
-    s = CG(op_from(A, symmetric=True))
-    s.solve(rhs)
-
-    ntiles = (A.shape[0] + 255) // 256
+    ntiles = (n + 255) // 256
 
     def dots(a, b, site):
         if site == "cg.pAp":                 # fused into the SpMV kernel: lane t of tile k owns row 256k+t
             return gpu_order.total(gpu_order.spmv_partials(a, b, ntiles))
         return gpu_order.stream_dot(a, b)
-    out = kr.cg(A, rhs, red=kr.Reductions(dots))
+    return dots
+
+
+@pytest.mark.parametrize("fix,prefix,rhs_key", [("cg_poisson2d.npz", "m100_A_", "m100_randn_rhs"),
+                                                ("cg_1138bus.npz", "A_", "rhs")])
+def test_cg_bit_exact_with_emulated_dot_order(golden, fix, prefix, rhs_key):
+    """With the oracle's dots replaced by the device's summation tree every other operation must
+    round identically: iteration count, history and iterate are compared for BIT equality."""
+    from pykrylov_amd import CG
+    d = golden(fix)
+    A = golden_csr(d, prefix)
+    rhs = d[rhs_key]
+    s = CG(op_from(A, symmetric=True))
+    s.solve(rhs)
+    out = kr.cg(A, rhs, red=kr.Reductions(emulated_dots(A.shape[0])))
     assert out["nMatvec"] == s.nMatvec
     assert np.array_equal(out["residHistory"], np.array(s.residHistory))
     assert np.array_equal(out["x"], s.x)
@@ -132,7 +143,8 @@ def test_cg_negative_curvature():
     s2 = CG(op)
     s2.solve(rhs, check_curvature=False, matvec_max=5)       # keeps iterating like the reference
     ref2 = kr.cg(A, rhs, check_curvature=False, matvec_max=5)
-    assert s2.nMatvec == ref2["nMatvec"] == 5 and s2.definite
+    assert s2.nMatvec == ref2["nMatvec"] == 2 and s2.definite and s2.converged   # 2 eigenvalues: done in 2
+    assert rel_hist_err(s2.residHistory[:-1], ref2["residHistory"][:-1]) <= TOL
 
 
 def test_cg_zero_rhs_and_history_accumulates(golden):
@@ -188,6 +200,10 @@ def test_cg_config2_n1e6_head_of_trajectory(golden):
     s.solve(rhs)
     href = d["p2d1000_cg_residHistory"]
     assert s.nMatvec == int(d["p2d1000_cg_nMatvec"]) == 1474
-    assert rel_hist_err(s.residHistory, href) <= TOL
+    # The reference's own np.dot (OpenBLAS) is 1.1e-12 away from the trajectory obtained with exactly
+    # rounded inner products; the device's fixed-tree dots stay within 3e-14 of it (parity).
+    assert rel_hist_err(s.residHistory, href) <= 2e-12
+    assert rel_hist_err(s.residHistory[:300], href[:300]) <= TOL
+    assert rel_hist_err(s.residHistory, d["p2d1000_cg_residHistory_exactdot"]) <= 1e-13
     assert np.max(np.abs(s.x[::997] - d["p2d1000_cg_x_sample"]) / np.abs(d["p2d1000_cg_x_sample"])) <= 1e-11
     assert np.allclose(s.x, 1.0, rtol=0, atol=1e-3)
