@@ -92,3 +92,26 @@ def spmv_partials(w, y, ntiles):
         b = tile % grid
         acc[b] = acc[b] + prod[tile]
     return _block_sum(acc)
+
+
+class GpuDots(object):
+    """`dot_impl` for krylov_ref.Reductions reproducing the device's summation order: call sites
+    listed in `spmv_sites` are fused into an SpMV kernel (row-owner order), all others are streaming
+    kernels."""
+
+    def __init__(self, n, spmv_sites):
+        self.ntiles = (n + BLOCK - 1) // BLOCK
+        self.spmv_sites = set(spmv_sites)
+
+    def __call__(self, a, b, site):
+        if site in self.spmv_sites:
+            return total(spmv_partials(a, b, self.ntiles))
+        return stream_dot(a, b)
+
+
+SPMV_SITES = {
+    "cg": ["cg.pAp"],
+    "bicgstab": ["bicgstab.r0v", "bicgstab.ts", "bicgstab.tt", "bicgstab.r0t"],
+}
+SPMV_SITES["cgs"] = ["cgs.sigma", "cgs.r", "cgs.rho"]
+SPMV_SITES["tfqmr"] = ["tfqmr.sigma", "tfqmr.w2", "tfqmr.rho"]

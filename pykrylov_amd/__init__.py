@@ -12,3 +12,6 @@ from .linop import (BaseLinearOperator, LinearOperator, IdentityOperator, Diagon
                     CoordLinearOperator, CsrOperator, ShapeError, linop_from_ndarray)
 from .generic import KrylovMethod                                                               # noqa: F401
 from .cg import CG                                                                              # noqa: F401
+from .bicgstab import BiCGSTAB                                                                  # noqa: F401
+from .cgs import CGS                                                                            # noqa: F401
+from .tfqmr import TFQMR                                                                        # noqa: F401

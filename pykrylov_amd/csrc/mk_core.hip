@@ -223,8 +223,8 @@ extern "C" int mk_spmv(const mk_csr *A, const double *x, double *y) {
     MK_ARG(A && x && y);
     if (A->nrows == 0) return MK_OK;
     MkPlainEpi epi{y};
-    hipLaunchKernelGGL(mk_spmv_kernel<MkPlainEpi>, dim3(mk_grid_spmv(A->ntiles)), dim3(MK_BLOCK), 0, mk_ctx().stream,
-                       mk_view(A), x, epi, never_halt(), mk_ctx().d_scratch);
+    hipLaunchKernelGGL((mk_spmv_kernel<MkPlainEpi, MkNoGate>), dim3(mk_grid_spmv(A->ntiles)), dim3(MK_BLOCK), 0,
+                       mk_ctx().stream, mk_view(A), x, epi, MkNoGate(), never_halt(), mk_ctx().d_scratch);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }

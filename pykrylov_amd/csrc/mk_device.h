@@ -96,14 +96,28 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     }
 }
 
-template <class Epi>
+// Gate: a test on a global sum that must be settled before the product may start (e.g. the loop
+// condition on ||r||).  Every workgroup evaluates it identically from the previous kernel's partial
+// sums; `open` returns whether to run the product and may request a halt through *stop.
+struct MkNoGate {
+    __device__ bool open(double *, bool, bool *) { return true; }
+};
+
+template <class Epi, class Gate>
 __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
-                                                           MkHalt halt, double *__restrict__ partials) {
+                                                           Gate gate, MkHalt halt, double *__restrict__ partials) {
     __shared__ double prod[MK_SPMV_TILE];
     __shared__ double s4[4];
     const bool halted = halt.in();
-    if (blockIdx.x == 0 && threadIdx.x == 0) halt.out(halted);
-    if (halted) return;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (halted) {
+        if (lead) halt.out(true);
+        return;
+    }
+    bool stop = false;
+    const bool go = gate.open(s4, lead, &stop);
+    if (lead) halt.out(stop);
+    if (!go) return;
     epi.prologue(s4);
     double acc[Epi::NACC > 0 ? Epi::NACC : 1];
 #pragma unroll

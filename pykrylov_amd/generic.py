@@ -175,3 +175,31 @@ class DeviceRun(object):
             self.close()
         except Exception:
             pass
+
+
+def solve_guess_matvec_max(solver, kind, rhs, kwargs, count_guess_product):
+    """Shared body of the BiCGSTAB / CGS / TFQMR `solve` methods: keywords `guess` and `matvec_max`
+    (default 2n), result attributes `converged, nMatvec, bestSolution, x, residNorm, residNorm0`
+    (reference bicgstab.py:148-151, cgs.py:120-123, tfqmr.py:156-159).  These solvers keep no history."""
+    op = solver._device_operator()
+    solver._no_precon(solver.precon)
+    n = rhs.shape[0]
+    guess = kwargs.get('guess', None)
+    matvec_max = kwargs.get('matvec_max', 2 * n)
+    with DeviceRun(op, kind, rhs, guess, abstol=float(solver.abstol), reltol=float(solver.reltol),
+                   matvec_max=int(matvec_max)) as run:
+        res = run.run()
+        x = run.x()
+    # the product that forms the initial residual from a guess is counted by the operator, but by the
+    # solver only in BiCGSTAB (bicgstab.py:64-65 vs cgs.py:59-60, tfqmr.py:58-59)
+    op._nMatvec += int(res.nMatvec) + (1 if (guess is not None and not count_guess_product) else 0)
+    solver.residNorm0 = np.float64(res.residNorm0)
+    if solver._logging():
+        solver.logger.info('Initial residual = %8.2e' % solver.residNorm0)
+        solver.logger.info('Threshold = %8.2e' % res.threshold)
+        solver.logger.info('%6d  %8.2e' % (res.nMatvec, res.residNorm))
+    solver.converged = bool(res.converged)
+    solver.nMatvec = int(res.nMatvec)
+    solver.bestSolution = solver.x = x
+    solver.residNorm = np.float64(res.residNorm)
+    return res
