@@ -174,6 +174,9 @@ int mk_solver_iterate(mk_solver *s, int64_t max_iters, int64_t *iters_done);
 int mk_solver_finish(mk_solver *s, mk_result *res);
 int mk_solver_x(const mk_solver *s, const double **x_dev);
 int mk_solver_history(const mk_solver *s, double *hist_host, int64_t cap);
+/* Second per-iteration channel, same length as the history (MINRES: truncated direct-error
+ * estimate / energy norm, `dir_errors_window` of minres.py:307-308; NaN while itn <= window). */
+int mk_solver_history2(const mk_solver *s, double *hist_host, int64_t cap);
 /* Other device vectors of the loop by solver-specific index (CG: 0 = r, 1 = p, the
  * direction stored as `infiniteDescent`, cg.py:122).  len may be NULL. */
 int mk_solver_vector(const mk_solver *s, int index, const double **v_dev, int64_t *len);

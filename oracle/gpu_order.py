@@ -115,3 +115,5 @@ SPMV_SITES = {
 }
 SPMV_SITES["cgs"] = ["cgs.sigma", "cgs.r", "cgs.rho"]
 SPMV_SITES["tfqmr"] = ["tfqmr.sigma", "tfqmr.w2", "tfqmr.rho"]
+SPMV_SITES["minres"] = ["minres.alfa"]
+SPMV_SITES["symmlq"] = ["symmlq.alfa"]

@@ -15,3 +15,4 @@ from .cg import CG                                                              
 from .bicgstab import BiCGSTAB                                                                  # noqa: F401
 from .cgs import CGS                                                                            # noqa: F401
 from .tfqmr import TFQMR                                                                        # noqa: F401
+from .minres import Minres                                                                      # noqa: F401

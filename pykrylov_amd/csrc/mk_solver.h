@@ -37,11 +37,13 @@ struct mk_solver {
     double *d_part = nullptr;       // MK_NDOT * MK_MAXP
     int *d_halt = nullptr;          // 2
     MkStatus *d_status = nullptr;
-    double *d_hist = nullptr;       // MK_HIST_RING
+    double *d_hist = nullptr;       // 2 * MK_HIST_RING: channel 0 = residual history, channel 1 = solver specific
     MkStatus *h_status = nullptr;   // pinned
     double *h_scal = nullptr;       // pinned, MK_NSCAL
     std::vector<double *> vecs;     // owned device vectors
     std::vector<double> hist;       // drained history (host)
+    std::vector<double> hist2;      // second channel (MINRES: direct-error estimates)
+    bool use_hist2 = false;
     int64_t hist_drained = 0;
 
     int64_t q = 0;                  // kernels launched so far (halt parity)

@@ -14,7 +14,7 @@ int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
     MK_HIP(hipMalloc((void **)&d_part, sizeof(double) * MK_NDOT * MK_MAXP));
     MK_HIP(hipMalloc((void **)&d_halt, 2 * sizeof(int)));
     MK_HIP(hipMalloc((void **)&d_status, sizeof(MkStatus)));
-    MK_HIP(hipMalloc((void **)&d_hist, sizeof(double) * MK_HIST_RING));
+    MK_HIP(hipMalloc((void **)&d_hist, sizeof(double) * 2 * MK_HIST_RING));
     MK_HIP(hipHostMalloc((void **)&h_status, sizeof(MkStatus), hipHostMallocDefault));
     MK_HIP(hipHostMalloc((void **)&h_scal, sizeof(double) * MK_NSCAL, hipHostMallocDefault));
     MK_HIP(hipEventCreate(&ev0));
@@ -103,6 +103,7 @@ int mk_solver::poll() {
         if (have - hist_drained > MK_HIST_RING)
             return mk_fail(MK_ERR_STATE, "history ring overrun (%lld new entries)", (long long)(have - hist_drained));
         hist.resize((size_t)have);
+        if (use_hist2) hist2.resize((size_t)have);
         int64_t pos = hist_drained;
         while (pos < have) {
             const int64_t off = pos % MK_HIST_RING;
@@ -110,6 +111,9 @@ int mk_solver::poll() {
             if (cnt > MK_HIST_RING - off) cnt = MK_HIST_RING - off;
             MK_HIP(hipMemcpyAsync(hist.data() + pos, d_hist + off, sizeof(double) * (size_t)cnt,
                                   hipMemcpyDeviceToHost, stream));
+            if (use_hist2)
+                MK_HIP(hipMemcpyAsync(hist2.data() + pos, d_hist + MK_HIST_RING + off, sizeof(double) * (size_t)cnt,
+                                      hipMemcpyDeviceToHost, stream));
             pos += cnt;
         }
         MK_HIP(hipStreamSynchronize(stream));
@@ -198,6 +202,7 @@ extern "C" int mk_solver_setup(mk_solver *s, const double *rhs, const double *gu
     s->it = 0;
     s->halted = false;
     s->hist.clear();
+    s->hist2.clear();
     s->hist_drained = 0;
     s->spmv_ms = 0.0;
     s->spmv_timed = 0;
@@ -234,6 +239,14 @@ extern "C" int mk_solver_history(const mk_solver *s, double *hist_host, int64_t 
     int64_t cnt = (int64_t)s->hist.size();
     if (cnt > cap) cnt = cap;
     memcpy(hist_host, s->hist.data(), sizeof(double) * (size_t)cnt);
+    return MK_OK;
+}
+
+extern "C" int mk_solver_history2(const mk_solver *s, double *hist_host, int64_t cap) {
+    MK_ARG(s && (cap == 0 || hist_host));
+    int64_t cnt = (int64_t)s->hist2.size();
+    if (cnt > cap) cnt = cap;
+    memcpy(hist_host, s->hist2.data(), sizeof(double) * (size_t)cnt);
     return MK_OK;
 }
 

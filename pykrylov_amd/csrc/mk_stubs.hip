@@ -1,4 +1,3 @@
 // temporary: solvers not yet implemented
 #include "mk_solver.h"
-mk_solver *mk_make_minres() { return nullptr; }
 mk_solver *mk_make_symmlq() { return nullptr; }
