@@ -117,3 +117,4 @@ SPMV_SITES["cgs"] = ["cgs.sigma", "cgs.r", "cgs.rho"]
 SPMV_SITES["tfqmr"] = ["tfqmr.sigma", "tfqmr.w2", "tfqmr.rho"]
 SPMV_SITES["minres"] = ["minres.alfa"]
 SPMV_SITES["symmlq"] = ["symmlq.alfa"]
+SPMV_SITES["symmlq"] = ["symmlq.alfa1", "symmlq.alfa", "symmlq.rnorm"]

@@ -16,3 +16,4 @@ from .bicgstab import BiCGSTAB                                                  
 from .cgs import CGS                                                                            # noqa: F401
 from .tfqmr import TFQMR                                                                        # noqa: F401
 from .minres import Minres                                                                      # noqa: F401
+from .symmlq import Symmlq                                                                      # noqa: F401

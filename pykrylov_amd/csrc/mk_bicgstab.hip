@@ -12,7 +12,9 @@
 namespace {
 
 enum { S_RHO0 = 0, S_RHO1 = 1, S_THRESH = 2, S_RESID = 3, S_RESID0 = 4, S_ALPHA = 5, S_EXIT = 6 };
-enum { SLOT_R0V = 0, SLOT_SS = 1, SLOT_TS = 0, SLOT_TT = 1, SLOT_R0T = 2, SLOT_RR = 3 };
+// a kernel never writes a slot it reads: a workgroup that finishes early would otherwise overwrite partial
+// sums that a later-starting workgroup is still adding up in its prologue / gate
+enum { SLOT_R0V = 0, SLOT_SS = 1, SLOT_TS = 2, SLOT_TT = 3, SLOT_R0T = 4, SLOT_RR = 5 };
 
 struct BEpi {    // v = A p, fused <r0, v>
     static constexpr int NACC = 1, SLOT0 = SLOT_R0V;

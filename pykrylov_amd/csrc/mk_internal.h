@@ -20,7 +20,7 @@ constexpr int MK_MAXP = 1024;         // partial-sum slots per reduction (= max 
 constexpr int MK_ROWS_PER_TILE = 256; // SpMV: one row per thread in the row-sum phase
 constexpr int MK_SPMV_TILE = 2048;    // SpMV: products staged in LDS per pass (16 KiB)
 constexpr int MK_NSCAL = 160;         // device scalar file per solver
-constexpr int MK_NDOT = 4;            // reduction slots per solver (MK_MAXP doubles each)
+constexpr int MK_NDOT = 6;           // reduction slots per solver (MK_MAXP doubles each)
 
 // --------------------------------------------------------------------------------------
 // host context
