@@ -53,6 +53,10 @@ int mk_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int mk_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
 int mk_memset(void *dst_dev, int byte, size_t bytes);
 
+/* Profiling aid: stream `bytes` of device memory with `width` (4, 8 or 16) bytes per lane, reading
+ * (write = 0) or writing (write = 1).  Known byte counts to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE. */
+int mk_calib_stream(void *dev, int64_t bytes, int width, int write);
+
 /* ------------------------------------------------------------------ CSR -------- */
 /* The device-resident operator behind `linop.LinearOperator`: replaces the user
  * `matvec` callable of pykrylov/linop/linop.py:114,:289 (Pysparse in
@@ -183,6 +187,11 @@ int mk_solver_vector(const mk_solver *s, int index, const double **v_dev, int64_
 /* Device time of the last mk_solver_iterate call (HIP events on the solver's stream)
  * and the accumulated time/launch count of its SpMV kernel. */
 int mk_solver_timing(const mk_solver *s, double *iterate_ms, double *spmv_ms, int64_t *spmv_launches);
+/* Average duration of the solver's fused SpMV kernel: `launches` back-to-back launches of exactly the
+ * kernel a loop pass uses, bracketed by ONE pair of HIP events on the solver's stream (a pair around
+ * each single launch would add ~3-6 us of marker overhead to a ~20 us kernel).  Destroys the product
+ * vector of the current pass: call it after the timed iterations. */
+int mk_solver_time_spmv(mk_solver *s, int64_t launches, double *avg_us);
 /* One-shot convenience: setup + iterate(until halted) + finish. */
 int mk_solver_solve(mk_solver *s, const double *rhs_dev, const double *guess_dev, mk_result *res);
 

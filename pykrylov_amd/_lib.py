@@ -46,6 +46,7 @@ PROTOTYPES = {
     "mk_memcpy_d2h": (ctypes.c_int, [c_vp, c_vp, c_sz]),
     "mk_memcpy_d2d": (ctypes.c_int, [c_vp, c_vp, c_sz]),
     "mk_memset": (ctypes.c_int, [c_vp, ctypes.c_int, c_sz]),
+    "mk_calib_stream": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int]),
     "mk_csr_create": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),
     "mk_csr_destroy": (ctypes.c_int, [c_vp]),
     "mk_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),
@@ -76,6 +77,7 @@ PROTOTYPES = {
     "mk_solver_history2": (ctypes.c_int, [c_vp, c_vp, c_i64]),
     "mk_solver_vector": (ctypes.c_int, [c_vp, ctypes.c_int, P(c_vp), P(c_i64)]),
     "mk_solver_timing": (ctypes.c_int, [c_vp, P(c_f64), P(c_f64), P(c_i64)]),
+    "mk_solver_time_spmv": (ctypes.c_int, [c_vp, c_i64, P(c_f64)]),
     "mk_solver_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, P(MkResult)]),
 }
 

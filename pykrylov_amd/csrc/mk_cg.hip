@@ -160,6 +160,11 @@ struct CgSolver : mk_solver {
         return MK_OK;
     }
 
+    int enqueue_spmv_only() override {
+        mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap}, false);
+        return MK_OK;
+    }
+
     int enqueue_pass() override {
         const int par = (int)(it & 1);
         int rc = exchange(d_p);

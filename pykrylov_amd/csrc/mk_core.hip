@@ -477,3 +477,47 @@ extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
     *out = B;
     return MK_OK;
 }
+
+// ======================================================================================
+// counter calibration helpers (profiles/: known byte counts at the access widths the solver
+// kernels use, to scale rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 -- MI355X_MICROARCH.md, HBM)
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(MK_BLOCK) void calib_read_kernel(const T *__restrict__ p, int64_t count, double *sink) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; i < count; i += (int64_t)gridDim.x * MK_BLOCK) {
+        const T v = p[i];
+        if constexpr (sizeof(T) == 16) acc += v.x + v.y;
+        else acc += (double)v;
+    }
+    if (acc == 1.2345e300) sink[0] = acc;       // never true: keeps the loads alive
+}
+
+template <typename T>
+__global__ __launch_bounds__(MK_BLOCK) void calib_write_kernel(T *__restrict__ p, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; i < count; i += (int64_t)gridDim.x * MK_BLOCK) {
+        if constexpr (sizeof(T) == 16) p[i] = T{1.0, 2.0};
+        else p[i] = (T)1;
+    }
+}
+
+extern "C" int mk_calib_stream(void *dev, int64_t bytes, int width, int write) {
+    MK_REQUIRE_INIT();
+    MK_ARG(dev && bytes > 0 && (width == 4 || width == 8 || width == 16));
+    hipStream_t st = mk_ctx().stream;
+    const int grid = MK_MAXP * 2;
+    const int64_t count = bytes / width;
+    if (write) {
+        if (width == 4) hipLaunchKernelGGL(calib_write_kernel<int32_t>, dim3(grid), dim3(MK_BLOCK), 0, st, (int32_t *)dev, count);
+        if (width == 8) hipLaunchKernelGGL(calib_write_kernel<double>, dim3(grid), dim3(MK_BLOCK), 0, st, (double *)dev, count);
+        if (width == 16) hipLaunchKernelGGL(calib_write_kernel<double2>, dim3(grid), dim3(MK_BLOCK), 0, st, (double2 *)dev, count);
+    } else {
+        double *sink = mk_ctx().d_scratch;
+        if (width == 4) hipLaunchKernelGGL(calib_read_kernel<int32_t>, dim3(grid), dim3(MK_BLOCK), 0, st, (const int32_t *)dev, count, sink);
+        if (width == 8) hipLaunchKernelGGL(calib_read_kernel<double>, dim3(grid), dim3(MK_BLOCK), 0, st, (const double *)dev, count, sink);
+        if (width == 16) hipLaunchKernelGGL(calib_read_kernel<double2>, dim3(grid), dim3(MK_BLOCK), 0, st, (const double2 *)dev, count, sink);
+    }
+    MK_HIP(hipGetLastError());
+    MK_HIP(hipStreamSynchronize(st));
+    return MK_OK;
+}

@@ -65,6 +65,9 @@ struct mk_solver {
     virtual int finish(mk_result *res) = 0;
     virtual const double *x() const = 0;
     virtual const double *vector(int) const { return nullptr; }
+    // enqueue only the solver's (fused) SpMV kernel, exactly as a loop pass launches it; used to time
+    // that kernel back to back.  Overwrites the product vector and its partial sums.
+    virtual int enqueue_spmv_only() { return mk_fail(MK_ERR_UNSUPPORTED, "SpMV timing is not wired for this solver"); }
 
     int init_common(const mk_csr *A_, const mk_params *p);
     int alloc_vec(double **out, int64_t len);

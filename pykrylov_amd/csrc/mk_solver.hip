@@ -259,6 +259,23 @@ extern "C" int mk_solver_vector(const mk_solver *s, int index, const double **v_
     return MK_OK;
 }
 
+extern "C" int mk_solver_time_spmv(mk_solver *s, int64_t launches, double *avg_us) {
+    MK_ARG(s && launches > 0 && avg_us);
+    if (!s->is_setup) return mk_fail(MK_ERR_STATE, "mk_solver_time_spmv before mk_solver_setup");
+    int rc = s->enqueue_spmv_only();                       // one untimed launch first
+    if (rc != MK_OK) return rc;
+    MK_HIP(hipEventRecord(s->ev0, s->stream));
+    for (int64_t k = 0; k < launches; ++k)
+        if ((rc = s->enqueue_spmv_only()) != MK_OK) return rc;
+    MK_HIP(hipEventRecord(s->ev1, s->stream));
+    MK_HIP(hipEventSynchronize(s->ev1));
+    MK_HIP(hipGetLastError());
+    float ms = 0.f;
+    MK_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    *avg_us = 1e3 * (double)ms / (double)launches;
+    return MK_OK;
+}
+
 extern "C" int mk_solver_timing(const mk_solver *s, double *iterate_ms, double *spmv_ms, int64_t *spmv_launches) {
     MK_ARG(s != nullptr);
     if (iterate_ms) *iterate_ms = s->last_iterate_ms;

@@ -151,9 +151,9 @@ def attach_exchange(op, mode, n_local, n_halo, send_count=None, recv_count=None,
     return op
 
 
-def partition_host_csr(world, indptr, indices, data, n, mode="halo"):
-    """Distribute a (replicated) host CSR matrix: every rank keeps its row block on its GPU."""
-    from .linop import CsrOperator
+def plan_host_csr(world, indptr, indices, data, n, mode="halo"):
+    """Pure planning step of :func:`partition_host_csr` (NumPy + one object all-gather; no GPU):
+    the local CSR triple with localized columns, the exchange plan and the row ranges."""
     from .sparse import csr_row_slice
     if mode == "allgather":
         ranges, cnt = equal_ranges(n, world.nranks)
@@ -164,14 +164,24 @@ def partition_host_csr(world, indptr, indices, data, n, mode="halo"):
     n_local = c1 - c0
     if mode == "allgather":
         n_halo = cnt * world.nranks
-        op = CsrOperator(lp, li.astype(np.int64) + n_local, ld, (n_local, n_local + n_halo))
-        return attach_exchange(op, 1, n_local, n_halo), ranges
+        return dict(mode=1, indptr=lp, indices=(li.astype(np.int64) + n_local).astype(np.int32), data=ld,
+                    n_local=n_local, n_halo=n_halo, ranges=ranges, send_count=None, recv_count=None,
+                    send_idx=None)
     need = needed_columns(li, c0, c1)
     needs = world.allgather_object(need)
     send_count, recv_count, send_idx = halo_plan(world.rank, ranges, needs)
-    lcols = localize_columns(li, c0, c1, need)
-    op = CsrOperator(lp, lcols, ld, (n_local, n_local + need.size))
-    return attach_exchange(op, 0, n_local, need.size, send_count, recv_count, send_idx), ranges
+    return dict(mode=0, indptr=lp, indices=localize_columns(li, c0, c1, need), data=ld, n_local=n_local,
+                n_halo=int(need.size), ranges=ranges, send_count=send_count, recv_count=recv_count,
+                send_idx=send_idx, halo_cols=need)
+
+
+def partition_host_csr(world, indptr, indices, data, n, mode="halo"):
+    """Distribute a (replicated) host CSR matrix: every rank keeps its row block on its GPU."""
+    from .linop import CsrOperator
+    p = plan_host_csr(world, indptr, indices, data, n, mode)
+    op = CsrOperator(p["indptr"], p["indices"], p["data"], (p["n_local"], p["n_local"] + p["n_halo"]))
+    return attach_exchange(op, p["mode"], p["n_local"], p["n_halo"], p["send_count"], p["recv_count"],
+                           p["send_idx"]), p["ranges"]
 
 
 def partition_poisson3d(world, nx, ny, nz, mode="halo"):
