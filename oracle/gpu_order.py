@@ -13,7 +13,9 @@ stream kernels (csrc/mk_device.h `mk_stream_kernel`):
 import numpy as np
 
 BLOCK = 256
-MAXP = 1024
+MAXP = 512          # default grid cap of the streaming kernels (MK_GRID_STREAM)
+SPMV_CAP = 2048     # SpMV grid cap for cache-resident matrices (2 x MK_GRID_SPMV; XCD-chunked tile order);
+                    # matrices beyond ~200 MB use 1024 workgroups and a plain round-robin (csrc/mk_device.h)
 
 
 def _wave_tree(v):
@@ -76,21 +78,39 @@ def stream_dot(a, b):
 
 
 def grid_spmv(ntiles):
-    return min(max(1, ntiles), MAXP)
+    g = min(max(1, ntiles), SPMV_CAP)
+    if g >= 8:
+        g -= g % 8
+    return g
+
+
+def spmv_tile_order(ntiles):
+    """For every workgroup the list of tiles it processes, in order (XCD-aware mapping of
+    csrc/mk_device.h: XCD b % 8 owns a contiguous eighth of the tiles, dealt round-robin to its workgroups)."""
+    grid = grid_spmv(ntiles)
+    nxcd = 8 if grid % 8 == 0 else 1
+    per = grid // nxcd
+    chunk = (ntiles + nxcd - 1) // nxcd
+    order = []
+    for b in range(grid):
+        c0 = (b % nxcd) * chunk
+        cend = min(c0 + chunk, ntiles)
+        order.append(range(c0 + b // nxcd, cend, per))
+    return order
 
 
 def spmv_partials(w, y, ntiles):
-    """Per-workgroup partial sums of sum(w*y) when the dot is fused into the SpMV kernel: lane t of
-    workgroup b owns rows 256*tile + t for tile = b, b+grid, ... and adds w[r]*y[r] in that order."""
+    """Per-workgroup partial sums of sum(w*y) when the dot is fused into the SpMV kernel: lane t of a
+    workgroup owns row 256*tile + t of each of its tiles and adds w[r]*y[r] in tile order."""
     n = len(w)
-    grid = grid_spmv(ntiles)
     prod = np.zeros(ntiles * BLOCK)
     prod[:n] = np.asarray(w, dtype=np.float64) * np.asarray(y, dtype=np.float64)
     prod = prod.reshape(ntiles, BLOCK)
-    acc = np.zeros((grid, BLOCK))
-    for tile in range(ntiles):
-        b = tile % grid
-        acc[b] = acc[b] + prod[tile]
+    order = spmv_tile_order(ntiles)
+    acc = np.zeros((len(order), BLOCK))
+    for b, tiles in enumerate(order):
+        for tile in tiles:
+            acc[b] = acc[b] + prod[tile]
     return _block_sum(acc)
 
 

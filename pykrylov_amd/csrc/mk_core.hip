@@ -24,6 +24,21 @@ int mk_fail(int code, const char *fmt, ...) {
 
 static int *g_halt0 = nullptr;   // two zero ints: "never halted" flags for standalone kernels
 
+static int env_cap(const char *name, int dflt) {
+    const char *v = getenv(name);
+    int c = v ? atoi(v) : dflt;
+    if (c < 1) c = 1;
+    return c > MK_MAXP ? MK_MAXP : c;
+}
+int mk_cap_stream() {
+    static int c = env_cap("MK_GRID_STREAM", 512);
+    return c;
+}
+int mk_cap_spmv() {
+    static int c = env_cap("MK_GRID_SPMV", 1024);
+    return c;
+}
+
 extern "C" int mk_version(void) { return MK_VERSION; }
 
 extern "C" const char *mk_last_error(void) { return mk_ctx().last_error.c_str(); }
@@ -149,8 +164,12 @@ int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out) {
     A->nnz = nnz;
     A->ntiles = (nrows + MK_ROWS_PER_TILE - 1) / MK_ROWS_PER_TILE;
     hipError_t e1 = hipMalloc((void **)&A->d_indptr, sizeof(int32_t) * (size_t)(nrows + 1));
-    hipError_t e2 = hipMalloc((void **)&A->d_indices, sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
-    hipError_t e3 = hipMalloc((void **)&A->d_data, sizeof(double) * (size_t)(nnz ? nnz : 1));
+    // +2 entries: the SpMV kernel reads nonzeros in aligned pairs and may touch one slot past the end
+    hipError_t e2 = hipMalloc((void **)&A->d_indices, sizeof(int32_t) * (size_t)(nnz + 2));
+    hipError_t e3 = hipMalloc((void **)&A->d_data, sizeof(double) * (size_t)(nnz + 2));
+    // (on the library's stream: the legacy default stream is not ordered with a non-blocking stream)
+    if (e2 == hipSuccess) e2 = hipMemsetAsync(A->d_indices + nnz, 0, 2 * sizeof(int32_t), mk_ctx().stream);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(A->d_data + nnz, 0, 2 * sizeof(double), mk_ctx().stream);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         mk_csr_destroy(A);
         return mk_fail(MK_ERR_HIP, "mk_csr: hipMalloc failed for nrows=%lld nnz=%lld", (long long)nrows,
@@ -223,7 +242,7 @@ extern "C" int mk_spmv(const mk_csr *A, const double *x, double *y) {
     MK_ARG(A && x && y);
     if (A->nrows == 0) return MK_OK;
     MkPlainEpi epi{y};
-    hipLaunchKernelGGL((mk_spmv_kernel<MkPlainEpi, MkNoGate>), dim3(mk_grid_spmv(A->ntiles)), dim3(MK_BLOCK), 0,
+    hipLaunchKernelGGL((mk_spmv_kernel<MkPlainEpi, MkNoGate>), dim3(mk_grid_spmv_for(A)), dim3(MK_BLOCK), 0,
                        mk_ctx().stream, mk_view(A), x, epi, MkNoGate(), never_halt(), mk_ctx().d_scratch);
     MK_HIP(hipGetLastError());
     return MK_OK;

@@ -22,21 +22,46 @@ struct MkCsrView {
     const double *data;
     int64_t nrows;
     int64_t ntiles;
+    int xcd_chunks;          // 1: each XCD sweeps its own contiguous eighth of the tiles (cache-resident problems)
 };
 
+// Working sets that fit the 256 MiB Infinity Cache profit from XCD-local tile ranges (every x line is then
+// fetched by one L2 instead of by up to five); beyond that size eight distant sweeps cost more in DRAM
+// locality than they save (measured: 2-D n=1e6 +5 %, 3-D 512^3 -8 %), so large problems sweep in one front.
+static inline int mk_xcd_chunks(const mk_csr *A) {
+    const int64_t bytes = 12 * A->nnz + 4 * (A->nrows + 1) + 8 * (A->x_len() + A->nrows) * 3;
+    return bytes <= (int64_t)200 * 1024 * 1024 ? 1 : 0;
+}
+
+// SpMV grid: twice as many (smaller-share) workgroups pay off only while the problem is cache resident
+static inline int mk_grid_spmv_for(const mk_csr *A) {
+    int g = mk_grid_spmv(A->ntiles);
+    if (!getenv("MK_GRID_SPMV") && mk_xcd_chunks(A)) {
+        const int64_t cap = 2 * (int64_t)mk_cap_spmv() > MK_MAXP ? MK_MAXP : 2 * mk_cap_spmv();
+        g = (int)(A->ntiles > cap ? cap : (A->ntiles < 1 ? 1 : A->ntiles));
+        if (g >= 8) g -= g % 8;
+    }
+    return g;
+}
+
 static inline MkCsrView mk_view(const mk_csr *A) {
-    return MkCsrView{A->d_indptr, A->d_indices, A->d_data, A->nrows, A->ntiles};
+    return MkCsrView{A->d_indptr, A->d_indices, A->d_data, A->nrows, A->ntiles, mk_xcd_chunks(A)};
 }
 
 #ifdef __HIPCC__
 
+typedef double mk_d2 __attribute__((ext_vector_type(2)));
+typedef int mk_i2 __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------------------
 // CSR-stream SpMV.  A workgroup owns 256 consecutive rows per tile.  Pass 1: all lanes walk
-// the tile's nonzeros in storage order -- `data`/`indices` are read fully coalesced, x is
-// gathered through L1/L2, the PRODUCTS go to LDS.  Pass 2: lane t owns row t and adds its
-// LDS segment left to right, so the per-row rounding sequence is that of a scalar CSR loop
-// (bit-identical to the oracle).  Rows longer than the LDS tile are handled by looping
-// over chunks with the running sum kept in a register.
+// the tile's nonzeros in storage order, two per lane -- `data` is read 16 bytes and `indices`
+// 8 bytes per lane, fully coalesced (the chunk starts at an even nonzero so that the accesses
+// are naturally aligned; at most one entry of the previous tile is read and ignored); x is
+// gathered through L1/L2; the PRODUCTS go to LDS.  Pass 2: lane t owns row t and adds its LDS
+// segment left to right, so the per-row rounding sequence is that of a scalar CSR loop
+// (bit-identical to the oracle).  Rows longer than the LDS tile are handled by looping over
+// chunks with the running sum kept in a register.
 //
 // Epi interface:   double xin(double xj)            value actually multiplied (e.g. s*y[j])
 //                  void   row(int64_t r, double s, double *acc)   consume the row result
@@ -44,9 +69,17 @@ static inline MkCsrView mk_view(const mk_csr *A) {
 template <class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
                                               double *prod, double (&acc)[NACC]) {
-    constexpr int PER = MK_SPMV_TILE / MK_BLOCK;   // 8 nonzeros per lane per chunk
+    constexpr int PAIRS = MK_SPMV_TILE / (2 * MK_BLOCK);   // 4 pairs of nonzeros per lane per chunk
     const int tid = threadIdx.x;
-    for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    // XCD-aware tile order (optional).  Workgroup b is dispatched to XCD b % 8 (observed,
+    // MI355X_MICROARCH.md) and each XCD has its own 4 MiB L2.  Placement only affects speed.
+    const int G = gridDim.x;
+    const int nxcd = (A.xcd_chunks && G % 8 == 0) ? 8 : 1;
+    const int per_xcd = G / nxcd;
+    const int64_t chunk = (A.ntiles + nxcd - 1) / nxcd;
+    const int64_t chunk0 = (int64_t)(blockIdx.x % nxcd) * chunk;
+    const int64_t chunk_end = (chunk0 + chunk < A.ntiles) ? chunk0 + chunk : A.ntiles;
+    for (int64_t tile = chunk0 + blockIdx.x / nxcd; tile < chunk_end; tile += per_xcd) {
         const int64_t r0 = tile * MK_ROWS_PER_TILE;
         const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
         const int64_t r = r0 + tid;
@@ -58,25 +91,36 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             my_hi = A.indptr[r + 1];
         }
         double sum = 0.0;
-        for (int base = p_lo; base < p_hi; base += MK_SPMV_TILE) {
+        for (int base = p_lo & ~1; base < p_hi; base += MK_SPMV_TILE) {
             const int cnt = (p_hi - base < MK_SPMV_TILE) ? p_hi - base : MK_SPMV_TILE;
             // ---- pass 1: coalesced stream of the chunk, products into LDS
-            int col[PER];
-            double val[PER];
+            mk_i2 col[PAIRS];
+            mk_d2 val[PAIRS];
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                int j = k * MK_BLOCK + tid;
-                j = (j < cnt) ? j : cnt - 1;            // clamp: loads stay unconditional
-                col[k] = A.indices[base + j];
-                val[k] = A.data[base + j];
+            for (int k = 0; k < PAIRS; ++k) {
+                int j = 2 * (k * MK_BLOCK + tid);
+                j = (j < cnt) ? j : ((cnt - 1) & ~1);    // clamp: loads stay unconditional and aligned
+                col[k] = *reinterpret_cast<const mk_i2 *>(A.indices + base + j);
+                val[k] = *reinterpret_cast<const mk_d2 *>(A.data + base + j);
+                if (j + 1 >= cnt) col[k].y = col[k].x;   // the odd slot past the chunk: keep the gather in range
             }
-            double xv[PER];
+            mk_d2 xv[PAIRS];
 #pragma unroll
-            for (int k = 0; k < PER; ++k) xv[k] = x[col[k]];
+            for (int k = 0; k < PAIRS; ++k) {
+                xv[k].x = x[col[k].x];
+                xv[k].y = x[col[k].y];
+            }
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int j = k * MK_BLOCK + tid;
-                if (j < cnt) prod[j] = val[k] * epi.xin(xv[k]);
+            for (int k = 0; k < PAIRS; ++k) {
+                const int j = 2 * (k * MK_BLOCK + tid);
+                if (j + 1 < cnt) {
+                    mk_d2 pr;
+                    pr.x = val[k].x * epi.xin(xv[k].x);
+                    pr.y = val[k].y * epi.xin(xv[k].y);
+                    *reinterpret_cast<mk_d2 *>(prod + j) = pr;
+                } else if (j < cnt) {
+                    prod[j] = val[k].x * epi.xin(xv[k].x);
+                }
             }
             __syncthreads();
             // ---- pass 2: one lane per row, left-to-right sum of its segment

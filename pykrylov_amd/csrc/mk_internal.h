@@ -16,7 +16,7 @@
 // --------------------------------------------------------------------------------------
 constexpr int MK_BLOCK = 256;         // 4 wave64 per workgroup
 constexpr int MK_WAVE = 64;
-constexpr int MK_MAXP = 1024;         // partial-sum slots per reduction (= max grid of a producer)
+constexpr int MK_MAXP = 2048;         // partial-sum slots per reduction (= max grid of a producer)
 constexpr int MK_ROWS_PER_TILE = 256; // SpMV: one row per thread in the row-sum phase
 constexpr int MK_SPMV_TILE = 2048;    // SpMV: products staged in LDS per pass (16 KiB)
 constexpr int MK_NSCAL = 160;         // device scalar file per solver
@@ -88,14 +88,22 @@ struct mk_csr {
 int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out);
 
 // grid sizes -------------------------------------------------------------------------
+// Persistent-style grids: at most `cap` workgroups which stride over the work.  The caps are tuning
+// knobs (MK_GRID_STREAM / MK_GRID_SPMV in the environment override them, <= MK_MAXP).
+int mk_cap_stream();
+int mk_cap_spmv();
 static inline int mk_grid_stream(int64_t n) {          // BLAS-1 style kernels: 2 doubles per thread per step
     int64_t g = (n + 2 * MK_BLOCK - 1) / (2 * MK_BLOCK);
     if (g < 1) g = 1;
-    return (int)(g > MK_MAXP ? MK_MAXP : g);
+    const int cap = mk_cap_stream();
+    return (int)(g > cap ? cap : g);
 }
 static inline int mk_grid_spmv(int64_t ntiles) {
     if (ntiles < 1) ntiles = 1;
-    return (int)(ntiles > MK_MAXP ? MK_MAXP : ntiles);
+    const int cap = mk_cap_spmv();
+    int g = (int)(ntiles > cap ? cap : ntiles);
+    if (g >= 8) g -= g % 8;             // multiples of 8: one equal share of workgroups per XCD
+    return g;
 }
 
 // --------------------------------------------------------------------------------------

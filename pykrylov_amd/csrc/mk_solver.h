@@ -181,7 +181,7 @@ static inline int mk_launch_stream(mk_solver *s, const Op &op, int64_t n) {
 template <class Epi, class Gate = MkNoGate>
 static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, bool timed = true,
                                  const Gate &gate = Gate()) {
-    const int grid = mk_grid_spmv(s->A->ntiles);
+    const int grid = mk_grid_spmv_for(s->A);
     if (timed) s->spmv_begin();
     hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate>), dim3(grid), dim3(MK_BLOCK), 0, s->stream, mk_view(s->A), x, epi,
                        gate, s->next_halt(), s->d_part);

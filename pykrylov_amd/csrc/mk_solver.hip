@@ -22,7 +22,7 @@ int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
     // with several ranks every consumer adds all MK_MAXP slots (unused ones stay zero) so that the
     // all-reduced partial vectors mean the same thing on every rank
     const bool multi = mk_comm_active() != 0;
-    np_spmv = multi ? MK_MAXP : mk_grid_spmv(A->ntiles);
+    np_spmv = multi ? MK_MAXP : mk_grid_spmv_for(A);
     np_stream = multi ? MK_MAXP : mk_grid_stream(n);
     spmv_sample_stride = prm.spmv_event_stride;
     return MK_OK;

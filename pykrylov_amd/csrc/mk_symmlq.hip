@@ -542,7 +542,7 @@ struct SymmlqSolver : mk_solver {
                                OpFinX{d_w, d_b, d_x, zbar, bstep, cg_point}, n, nh, d_part);
             if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
             if ((rc = exchange(d_x)) != MK_OK) return rc;
-            hipLaunchKernelGGL((mk_spmv_kernel<EpiFinR, MkNoGate>), dim3(mk_grid_spmv(A->ntiles)), dim3(MK_BLOCK), 0,
+            hipLaunchKernelGGL((mk_spmv_kernel<EpiFinR, MkNoGate>), dim3(mk_grid_spmv_for(A)), dim3(MK_BLOCK), 0,
                                stream, mk_view(A), d_x, EpiFinR{d_x, d_b, prm.shift, prm.has_shift}, MkNoGate(), nh,
                                d_part);
             if ((rc = allreduce(SLOT_B, 1)) != MK_OK) return rc;
