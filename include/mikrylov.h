@@ -127,7 +127,11 @@ typedef enum {
     MK_CGS = 3,       /* pykrylov/cgs/cgs.py:40-123           */
     MK_TFQMR = 4,     /* pykrylov/tfqmr/tfqmr.py:39-159       */
     MK_MINRES = 5,    /* pykrylov/minres/minres.py:115-410    */
-    MK_SYMMLQ = 6     /* pykrylov/symmlq/symmlq.py:65-400     */
+    MK_SYMMLQ = 6,    /* pykrylov/symmlq/symmlq.py:65-400     */
+    MK_LSQR = 7,      /* pykrylov/lls/lsqr.py:86-453          */
+    MK_LSMR = 8,      /* pykrylov/lls/lsmr.py:64-492          */
+    MK_CRAIG = 9,     /* pykrylov/lls/craig.py:104-520        */
+    MK_CRAIGMR = 10   /* pykrylov/lls/craigmr.py:51-241       */
 } mk_solver_kind;
 
 typedef struct {
@@ -144,6 +148,10 @@ typedef struct {
     int64_t itnlim;           /* minres.py:125 */
     int32_t window;           /* minres.py:130 */
     int32_t spmv_event_stride; /* >0: bracket the SpMV kernel of every k-th pass with HIP events */
+    double damp;              /* lsqr.py:86, lsmr.py:64 */
+    double atol;              /* lsqr.py:86 */
+    double btol;              /* lsqr.py:86 */
+    double conlim;            /* lsqr.py:87 */
 } mk_params;
 
 typedef struct {
@@ -167,6 +175,10 @@ typedef struct mk_solver mk_solver;
 
 int mk_solver_create(const mk_csr *A, const mk_params *params, mk_solver **out);
 int mk_solver_destroy(mk_solver *s);
+/* The least-squares solvers (MK_LSQR ... MK_CRAIGMR) need `A.T * u` (lls/lsqr.py:200,264): hand them the
+ * transposed matrix (mk_csr_transpose) before mk_solver_setup.  rhs then has nrows(A) entries and x
+ * ncols(A) (CRAIG-MR: nrows(A), craigmr.py:112). */
+int mk_solver_set_transpose(mk_solver *s, const mk_csr *At);
 /* Everything before the `while` loop of the reference's solve().  rhs_dev has n_local
  * entries; guess_dev may be NULL (x0 = 0).  Neither is modified. */
 int mk_solver_setup(mk_solver *s, const double *rhs_dev, const double *guess_dev);

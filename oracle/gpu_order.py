@@ -138,3 +138,5 @@ SPMV_SITES["tfqmr"] = ["tfqmr.sigma", "tfqmr.w2", "tfqmr.rho"]
 SPMV_SITES["minres"] = ["minres.alfa"]
 SPMV_SITES["symmlq"] = ["symmlq.alfa"]
 SPMV_SITES["symmlq"] = ["symmlq.alfa1", "symmlq.alfa", "symmlq.rnorm"]
+for _s in ("lsqr", "lsmr", "craig", "craigmr"):
+    SPMV_SITES[_s] = [_s + ".beta", _s + ".alpha", _s + ".alpha0"]

@@ -17,3 +17,4 @@ from .cgs import CGS                                                            
 from .tfqmr import TFQMR                                                                        # noqa: F401
 from .minres import Minres                                                                      # noqa: F401
 from .symmlq import Symmlq                                                                      # noqa: F401
+from . import lls                                                                               # noqa: F401

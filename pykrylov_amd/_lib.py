@@ -16,12 +16,14 @@ c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
 P = ctypes.POINTER
 
 MK_CG, MK_BICGSTAB, MK_CGS, MK_TFQMR, MK_MINRES, MK_SYMMLQ = 1, 2, 3, 4, 5, 6
+MK_LSQR, MK_LSMR, MK_CRAIG, MK_CRAIGMR = 7, 8, 9, 10
 
 
 class MkParams(ctypes.Structure):
     _fields_ = [("struct_size", c_i32), ("kind", c_i32), ("abstol", c_f64), ("reltol", c_f64),
                 ("matvec_max", c_i64), ("check_curvature", c_i32), ("has_shift", c_i32), ("shift", c_f64),
-                ("rtol", c_f64), ("etol", c_f64), ("itnlim", c_i64), ("window", c_i32), ("spmv_event_stride", c_i32)]
+                ("rtol", c_f64), ("etol", c_f64), ("itnlim", c_i64), ("window", c_i32), ("spmv_event_stride", c_i32),
+                ("damp", c_f64), ("atol", c_f64), ("btol", c_f64), ("conlim", c_f64)]
 
 
 class MkResult(ctypes.Structure):
@@ -69,6 +71,7 @@ PROTOTYPES = {
     "mk_exchange": (ctypes.c_int, [c_vp, c_vp]),
     "mk_solver_create": (ctypes.c_int, [c_vp, P(MkParams), P(c_vp)]),
     "mk_solver_destroy": (ctypes.c_int, [c_vp]),
+    "mk_solver_set_transpose": (ctypes.c_int, [c_vp, c_vp]),
     "mk_solver_setup": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mk_solver_iterate": (ctypes.c_int, [c_vp, c_i64, P(c_i64)]),
     "mk_solver_finish": (ctypes.c_int, [c_vp, P(MkResult)]),

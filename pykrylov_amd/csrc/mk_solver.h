@@ -28,6 +28,7 @@ int mk_comm_allreduce_sum(double *buf_dev, int64_t count, hipStream_t stream);
 
 struct mk_solver {
     const mk_csr *A = nullptr;
+    const mk_csr *At = nullptr;     // transposed matrix (least-squares solvers only)
     mk_params prm{};
     int64_t n = 0;        // local rows = length of every solver vector
     int64_t nx = 0;       // length of vectors that feed an SpMV (n + halo)
@@ -89,6 +90,7 @@ mk_solver *mk_make_cgs();
 mk_solver *mk_make_tfqmr();
 mk_solver *mk_make_minres();
 mk_solver *mk_make_symmlq();
+mk_solver *mk_make_lls(int kind);
 
 #ifdef __HIPCC__
 // ------------------------------------------------------------------ small shared kernels
@@ -175,6 +177,14 @@ static inline int mk_launch_stream(mk_solver *s, const Op &op, int64_t n) {
     const int grid = mk_grid_stream(n);
     hipLaunchKernelGGL(mk_stream_kernel<Op>, dim3(grid), dim3(MK_BLOCK), 0, s->stream, op, n, s->next_halt(),
                        s->d_part);
+    return MK_OK;
+}
+
+template <class Epi, class Gate = MkNoGate>
+static inline int mk_launch_spmv_on(mk_solver *s, const mk_csr *M, const double *x, const Epi &epi,
+                                    const Gate &gate = Gate()) {
+    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate>), dim3(mk_grid_spmv_for(M)), dim3(MK_BLOCK), 0, s->stream,
+                       mk_view(M), x, epi, gate, s->next_halt(), s->d_part);
     return MK_OK;
 }
 

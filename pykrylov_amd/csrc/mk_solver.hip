@@ -5,7 +5,10 @@ int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
     A = A_;
     prm = *p;
     n = A->ex.mode >= 0 ? A->ex.n_local : A->nrows;
-    if (A->ex.mode < 0 && A->nrows != A->ncols)
+    const bool rectangular_ok = prm.kind >= MK_LSQR;
+    if (rectangular_ok && A->ex.mode >= 0)
+        return mk_fail(MK_ERR_UNSUPPORTED, "the least-squares solvers are single-GPU in this version");
+    if (!rectangular_ok && A->ex.mode < 0 && A->nrows != A->ncols)
         return mk_fail(MK_ERR_ARG, "solver needs a square operator, got %lld x %lld", (long long)A->nrows,
                        (long long)A->ncols);
     nx = A->x_len();
@@ -179,6 +182,10 @@ extern "C" int mk_solver_create(const mk_csr *A, const mk_params *params, mk_sol
         case MK_TFQMR: s = mk_make_tfqmr(); break;
         case MK_MINRES: s = mk_make_minres(); break;
         case MK_SYMMLQ: s = mk_make_symmlq(); break;
+        case MK_LSQR:
+        case MK_LSMR:
+        case MK_CRAIG:
+        case MK_CRAIGMR: s = mk_make_lls(params->kind); break;
         default: break;
     }
     if (!s) return mk_fail(MK_ERR_UNSUPPORTED, "mk_solver_create: solver kind %d is not available", params->kind);
@@ -188,6 +195,13 @@ extern "C" int mk_solver_create(const mk_csr *A, const mk_params *params, mk_sol
         return rc;
     }
     *out = s;
+    return MK_OK;
+}
+
+extern "C" int mk_solver_set_transpose(mk_solver *s, const mk_csr *At) {
+    MK_ARG(s && At);
+    MK_ARG(At->nrows == s->A->ncols && At->ncols == s->A->nrows && At->nnz == s->A->nnz);
+    s->At = At;
     return MK_OK;
 }
 

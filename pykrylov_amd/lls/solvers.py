@@ -1,0 +1,224 @@
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from ..generic import KrylovMethod, DeviceRun, as_f64_vector
+
+__docformat__ = 'restructuredtext'
+
+_STATUS = {0: 'solution is zero', 1: 'residual small', 2: 'residual small', 4: 'residual small',
+           5: 'residual small', 3: 'ill-conditioned operator', 6: 'ill-conditioned operator',
+           7: 'max iterations', 8: 'direct error small'}
+
+
+class _LlsBase(KrylovMethod):
+    """Shared device glue of the four least-squares solvers."""
+
+    kind = None
+
+    def __init__(self, A, **kwargs):
+        KrylovMethod.__init__(self, A, **kwargs)
+        self.A = A
+        self.x = None
+        self.var = None
+        self.itn = 0
+        self.istop = 0
+        self.optimal = False
+        self.resids = []
+        self.normal_eqns_resids = []
+        self.dir_errors_window = []
+        self.iterates = []
+        self.msg = ['The exact solution is  x = 0                              ',
+                    'Ax - b is small enough, given atol, btol                  ',
+                    'The least-squares solution is good enough, given atol     ',
+                    'The estimate of cond(Abar) has exceeded conlim            ',
+                    'Ax - b is small enough for this machine                   ',
+                    'The least-squares solution is good enough for this machine',
+                    'Cond(Abar) seems to be too large for this machine         ',
+                    'The iteration limit has been reached                      ',
+                    'The truncated direct error is small enough, given etol    ']
+
+    def _run(self, rhs, itnlim, damp, atol, btol, conlim, M, N, kwargs, x_rows=False):
+        A = self._device_operator()
+        if M is not None or N is not None:
+            raise NotImplementedError('%s: preconditioners M, N are not available on the device path yet'
+                                      % self.__class__.__name__)
+        if kwargs.get('wantvar', False):
+            raise NotImplementedError('wantvar is broken in the reference as well (lsqr.py:155)')
+        m, n = A.shape
+        etol = kwargs.get('etol', 1.0e-6)
+        window = kwargs.get('window', 5)
+        store_iterates = kwargs.get('store_iterates', False)
+        b = as_f64_vector(np.asarray(rhs).squeeze()[:m], m, 'rhs')
+        At = A.T
+        lib = _lib.init()
+        self.iterates = []
+        # DeviceRun sizes its rhs buffer from the operator's input size: build the run by hand for m x n
+        d_rhs = _lib.DeviceArray.from_numpy(b)
+        p = _lib.MkParams()
+        p.struct_size = ctypes.sizeof(_lib.MkParams)
+        p.kind = self.kind
+        p.itnlim = int(itnlim)
+        p.damp, p.atol, p.btol, p.conlim, p.etol = float(damp), float(atol), float(btol), float(conlim), float(etol)
+        p.window = int(window)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.mk_solver_create(A.handle, ctypes.byref(p), ctypes.byref(handle)))
+        try:
+            _lib.check(lib.mk_solver_set_transpose(handle, At.handle))
+            _lib.check(lib.mk_solver_setup(handle, d_rhs.ptr, None))
+            res = _lib.MkResult()
+            _lib.check(lib.mk_solver_finish(handle, ctypes.byref(res)))
+            nx = m if x_rows else n
+
+            def get_x():
+                px = ctypes.c_void_p()
+                _lib.check(lib.mk_solver_x(handle, ctypes.byref(px)))
+                return _lib.download(px.value, nx)
+            if store_iterates:
+                self.iterates.append(get_x())
+            while not res.halted:
+                done = ctypes.c_int64()
+                _lib.check(lib.mk_solver_iterate(handle, 1 if store_iterates else (1 << 20), ctypes.byref(done)))
+                last_itn = int(res.itn)
+                _lib.check(lib.mk_solver_finish(handle, ctypes.byref(res)))
+                if store_iterates and int(res.itn) > last_itn:
+                    self.iterates.append(get_x())
+            x = get_x()
+            hist = np.empty(int(res.hist_len))
+            derr = np.empty(int(res.hist_len))
+            _lib.check(lib.mk_solver_history(handle, hist.ctypes.data, len(hist)))
+            _lib.check(lib.mk_solver_history2(handle, derr.ctypes.data, len(derr)))
+            r = None
+            if self.kind == _lib.MK_CRAIG:
+                pr = ctypes.c_void_p()
+                _lib.check(lib.mk_solver_vector(handle, 0, ctypes.byref(pr), None))
+                r = _lib.download(pr.value, m)
+        finally:
+            lib.mk_solver_destroy(handle)
+            d_rhs.free()
+        itn = int(res.itn)
+        A._nMatvec += itn
+        At._nMatvec += itn + (1 if res.residNorm0 > 0 else 0)
+        self._hist = hist
+        self.dir_errors_window = [np.float64(e) for e in derr[window:]]
+        return res, x, r, itn
+
+
+class LSQRFramework(_LlsBase):
+    """LSQR for ``A x = b`` / ``min |b - A x|`` / damped least squares (lsqr.py:26-453).
+
+    Result attributes: `x, bestSolution, istop, itn, nMatvec (= 2 itn), r1norm, r2norm, residNorm, Anorm,
+    Acond, Arnorm, xnorm, var (None), optimal, status`.
+    """
+    kind = _lib.MK_LSQR
+
+    def solve(self, rhs, itnlim=0, damp=0.0, M=None, N=None, atol=1.0e-9, btol=1.0e-9, conlim=1.0e+8,
+              show=False, wantvar=False, **kwargs):
+        m, n = self.A.shape
+        if itnlim == 0:
+            itnlim = 3 * n
+        kwargs['wantvar'] = wantvar
+        res, x, _, itn = self._run(rhs, itnlim, damp, atol, btol, conlim, M, N, kwargs)
+        if kwargs.get('store_resids', False):
+            self.resids = [np.float64(res.residNorm0)] + [np.float64(h) for h in self._hist]
+        istop = int(res.istop)
+        if show:
+            print(' ')
+            print('LSQR finished')
+            print(self.msg[istop])
+            print('istop =%8g   r1norm =%8.1e   Anorm =%8.1e   Arnorm =%8.1e' % (istop, res.aux[0], res.Anorm, res.Arnorm))
+            print('itn   =%8g   r2norm =%8.1e   Acond =%8.1e   xnorm  =%8.1e' % (itn, res.residNorm, res.Acond, res.xnorm))
+        self.status = _STATUS[istop]
+        self.optimal = istop in [1, 2, 4, 5, 8]
+        self.x = self.bestSolution = x
+        self.istop = istop
+        self.itn = itn
+        self.nMatvec = 2 * itn
+        self.r1norm = np.float64(res.aux[0])
+        self.r2norm = np.float64(res.residNorm)
+        self.residNorm = self.r2norm
+        self.Anorm = np.float64(res.Anorm)
+        self.Acond = np.float64(res.Acond)
+        self.Arnorm = np.float64(res.Arnorm)
+        self.xnorm = np.float64(res.xnorm)
+        self.var = None
+        return
+
+
+class LSMRFramework(_LlsBase):
+    """LSMR (lsmr.py:28-492).  Like the reference, `solve` RETURNS
+    ``(x, istop, itn, normr, normar, normA, condA, normx)`` and only sets `self.x`."""
+    kind = _lib.MK_LSMR
+
+    def solve(self, b, damp=0.0, atol=1e-9, btol=1e-9, conlim=1e8, M=None, N=None, itnlim=None, show=False,
+              **kwargs):
+        m, n = self.A.shape
+        if itnlim is None:
+            itnlim = min([m, n])
+        res, x, _, itn = self._run(b, itnlim, damp, atol, btol, conlim, M, N, kwargs)
+        istop = int(res.istop)
+        if kwargs.get('store_resids', False):
+            self.resids = [np.float64(res.residNorm0)] + [np.float64(h) for h in self._hist]
+        if show:
+            print(' ')
+            print('LSMR finished')
+            print(self.msg[istop])
+            print('istop =%8g    normr =%8.1e    normA =%8.1e    normAr =%8.1e' % (istop, res.aux[1], res.Anorm, res.aux[2]))
+            print('itn   =%8g    condA =%8.1e    normx =%8.1e' % (itn, res.Acond, res.xnorm))
+        self.x = x
+        return (x, istop, itn, np.float64(res.aux[1]), np.float64(res.aux[2]), np.float64(res.Anorm),
+                np.float64(res.Acond), np.float64(res.xnorm))
+
+
+class CRAIGFramework(_LlsBase):
+    """CRAIG (craig.py:30-520).  Result attributes: `x, bestSolution, r, istop, itn, nMatvec, r1norm, r2norm,
+    Arnorm, xnorm, optimal, status`."""
+    kind = _lib.MK_CRAIG
+
+    def solve(self, rhs, itnlim=0, damp=0.0, M=None, N=None, atol=1.0e-9, btol=1.0e-9, conlim=1.0e+8,
+              show=False, wantvar=False, **kwargs):
+        m, n = self.A.shape
+        if itnlim == 0:
+            itnlim = 3 * n
+        kwargs['wantvar'] = wantvar
+        res, x, r, itn = self._run(rhs, itnlim, damp, atol, btol, conlim, M, N, kwargs)
+        istop = int(res.istop)
+        self.dir_errors_d_window = self.dir_errors_window
+        self.status = _STATUS[istop]
+        self.optimal = istop in [1, 2, 4, 5, 8]
+        self.x = self.bestSolution = x
+        self.r = r
+        self.istop = istop
+        self.itn = itn
+        self.nMatvec = 2 * itn
+        self.r1norm = np.float64(res.aux[0])
+        self.r2norm = np.float64(res.residNorm)
+        self.Arnorm = np.float64(res.Arnorm)
+        self.xnorm = np.float64(res.xnorm)
+        return
+
+
+class CRAIGMRFramework(_LlsBase):
+    """CRAIG-MR (craigmr.py:12-241; its per-iteration debugging print at :190 is dropped).  `x` has
+    ``nargout`` entries as in the reference (craigmr.py:112)."""
+    kind = _lib.MK_CRAIGMR
+
+    def solve(self, b, damp=0.0, atol=1e-9, btol=1e-9, conlim=1e8, M=None, N=None, itnlim=None, show=False,
+              **kwargs):
+        m, n = self.A.shape
+        if itnlim is None:
+            itnlim = min([m, n])
+        res, x, _, itn = self._run(b, itnlim, damp, atol, btol, conlim, M, N, kwargs, x_rows=True)
+        istop = int(res.istop)
+        if show:
+            print(' ')
+            print('CRAIG-MR finished')
+            print(self.msg[istop])
+        self.status = _STATUS[istop]
+        self.optimal = istop in [1, 2, 4, 5, 8]
+        self.x = self.bestSolution = x
+        self.istop = istop
+        self.itn = itn
+        self.nMatvec = 2 * itn
+        return

@@ -220,3 +220,42 @@ def test_large_matrix_checksums(golden):
     A = csr_ref.poisson2d(1000)
     assert A.nnz == int(d["p2d1000_nnz"]) == 4996000
     assert same(sha(A.indptr), d["p2d1000_indptr_sha"]) and same(sha(A.indices), d["p2d1000_indices_sha"])
+
+
+# ------------------------------------------------------------------ least-squares family
+def _lls_cases():
+    for tag in ("s", "l"):
+        for solver in ("lsqr", "lsmr", "craig", "craigmr"):
+            for btag in ("cons", "ls"):
+                if solver.startswith("craig") and btag == "ls":
+                    continue
+                for damp, etol in ((0.0, 1e-6), (0.1, 1e-6), (0.0, 0.0)):
+                    if solver.startswith("craig") and damp != 0.0:
+                        continue
+                    yield tag, solver, btag, damp, etol
+
+
+@pytest.mark.parametrize("tag,solver,btag,damp,etol", list(_lls_cases()))
+def test_lls(golden, tag, solver, btag, damp, etol):
+    from oracle import lls_ref
+    d = golden("lls_random.npz")
+    A = csr_from(d, tag + "_A_")
+    At = A.transpose()
+    b = d[tag + "_b_" + btag]
+    k = "%s_%s_%s_d%g_e%g_" % (tag, solver, btag, damp, etol)
+    if solver == "lsqr":
+        out = lls_ref.lsqr(A.matvec, At.matvec, A.shape, b.copy(), damp=damp, etol=etol)
+        names = ("istop", "itn", "nMatvec", "r1norm", "r2norm", "Anorm", "Acond", "Arnorm", "xnorm")
+    elif solver == "lsmr":
+        out = lls_ref.lsmr(A.matvec, At.matvec, A.shape, b.copy(), damp=damp, etol=etol)
+        names = ("istop", "itn", "normr", "normar", "normA", "condA", "normx")
+    elif solver == "craig":
+        out = lls_ref.craig(A.matvec, At.matvec, A.shape, b.copy(), etol=etol)
+        names = ("istop", "itn", "nMatvec", "r1norm", "r2norm", "Arnorm", "xnorm")
+    else:
+        out = lls_ref.craigmr(A.matvec, At.matvec, A.shape, b.copy(), etol=etol)
+        names = ("istop", "itn", "nMatvec")
+    for name in names:
+        assert out[name] == d[k + name].item(), name
+    assert same(out["trace"], d[k + "trace"])
+    assert same(out["x"], d[k + "x"])
