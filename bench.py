@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Krylov iterations/s of the device-resident CG + roofline of its SpMV kernel.
 
-    python bench.py --gpus 1 --steps K --warmup W            # BASELINE configs[1]: 2-D Poisson n=1e6
+    python bench.py --gpus 1 --steps K --warmup W            # configs[4] on one GPU (+ configs[1] as "extra")
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W   # configs[4]: 512^3 on N GPUs
 
@@ -10,9 +10,12 @@ A "step" is one pass of the CG loop body (reference pykrylov/cg/cg.py:113-158: 1
 K passes run inside the timed region.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json `configs`):
-  poisson2d-1000   configs[1]  CG, 2-D 5-point Poisson, n = 1e6, one GPU         (default at N = 1)
-  poisson3d-512    configs[4]  CG, 3-D 7-point Poisson 512^3 row-partitioned over N GPUs (default at N > 1;
-                               strong scaling: the total problem is fixed)
+  poisson3d-512    configs[4]  CG, 3-D 7-point Poisson 512^3 (1.34e8 rows, 9.4e8 nnz) row-partitioned over N GPUs --
+                               the configuration BASELINE.json's target is quoted on.  It fits one GPU (14 GB of
+                               288 GB), so it is the default at EVERY N: the 1/2/4/8 series is one strong-scaling
+                               series over a fixed problem.
+  poisson2d-1000   configs[1]  CG, 2-D 5-point Poisson, n = 1e6, one GPU; also run at N = 1 and reported under
+                               "extra" (value, ms_per_step and its own SpMV roofline), or alone with --workload.
 """
 import argparse
 import ctypes
@@ -86,14 +89,14 @@ def main():
     global ARGS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"])
     ap.add_argument("--event-stride", type=int, default=0,
                     help="additionally bracket the SpMV of every k-th pass with its own HIP event pair "
                          "(intrusive: each pair costs ~3-6 us; 0 = off)")
-    ap.add_argument("--spmv-launches", type=int, default=500,
+    ap.add_argument("--spmv-launches", type=int, default=200,
                     help="back-to-back launches of the fused SpMV kernel timed by one HIP event pair")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -121,7 +124,7 @@ def main():
 
     name = ARGS.workload
     if name == "auto":
-        name = "poisson2d-1000" if world_size == 1 else "poisson3d-512"
+        name = "poisson3d-512"
 
     def run_cg(workload, steps, warmup, stride):
         op, n_global, meta = build_workload(workload, world)
@@ -167,23 +170,37 @@ def main():
         op.free()
         return info
 
+    def roofline_of(info, workload, steps):
+        n_g, n_l = info["n_global"], info["n_local"]
+        b_spmv = spmv_bytes(n_l, info["op_shape"][1], info["nnz"])
+        tm = info["timing"]
+        spmv_us = tm["spmv_b2b_us"]
+        achieved = b_spmv / (spmv_us * 1e-6) / 1e9 if spmv_us else None
+        inloop_us = 1e3 * tm["spmv_ms"] / tm["spmv_launches"] if tm["spmv_launches"] else None
+        # whole-iteration roofline with the reference's op count: B_spmv + 104 n per pass
+        stencil = info["meta"]["stencil"]
+        nnz_global = stencil * n_g - 2 * sum(n_g // g for g in info["meta"]["grid"])
+        iter_bytes = spmv_bytes(n_g, n_g, nnz_global) + 104 * n_g
+        its = steps / info["elapsed"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("%s@%d" % (workload, world_size))
+        roof = {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpi> (CSR-stream SpMV + fused <p,Ap>)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "bytes_per_launch": b_spmv, "avg_launch_us": spmv_us, "launches_timed": ARGS.spmv_launches,
+                "method": "one hipEvent pair around back-to-back launches on the solver stream",
+                "inloop_event_pair_us": inloop_us}
+        it_roof = {"algorithmic_bytes_per_iter": iter_bytes, "achieved_GBs": iter_bytes * its / 1e9,
+                   "frac_of_aggregate_hbm": iter_bytes * its / 1e9 / (HBM_PEAK_GBS * world_size)}
+        return its, nnz_global, roof, it_roof
+
     info = run_cg(name, ARGS.steps, ARGS.warmup, ARGS.event_stride)
     elapsed = info["elapsed"]
-    its = ARGS.steps / elapsed
-    n_g, n_l = info["n_global"], info["n_local"]
-    b_spmv = spmv_bytes(n_l, info["op_shape"][1], info["nnz"])
     tm = info["timing"]
-    spmv_us = tm["spmv_b2b_us"]
-    achieved = b_spmv / (spmv_us * 1e-6) / 1e9 if spmv_us else None
-    inloop_us = 1e3 * tm["spmv_ms"] / tm["spmv_launches"] if tm["spmv_launches"] else None
-    # whole-iteration roofline with the reference's op count: B_spmv + 104 n per pass
-    stencil = info["meta"]["stencil"]
-    nnz_global = stencil * n_g - 2 * sum(n_g // g for g in info["meta"]["grid"])
-    iter_bytes = spmv_bytes(n_g, n_g, nnz_global) + 104 * n_g
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("%s@%d" % (name, world_size))
+    n_g = info["n_global"]
+    its, nnz_global, roof, it_roof = roofline_of(info, name, ARGS.steps)
 
     line = {
         "metric": "Krylov iters/sec + SpMV achieved HBM GB/s (% of peak), fp64",
@@ -194,25 +211,20 @@ def main():
                    "solver": "cg", "rows": n_g, "nnz": nnz_global,
                    "parallelism": "1 GPU" if world_size == 1 else "row-partition x%d, %s exchange + allreduce(dots), RCCL"
                                   % (world_size, ARGS.exchange)},
-        "roofline": {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpi> (CSR-stream SpMV + fused <p,Ap>)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "bytes_per_launch": b_spmv, "avg_launch_us": spmv_us, "launches_timed": ARGS.spmv_launches,
-                     "method": "one hipEvent pair around back-to-back launches on the solver stream",
-                     "inloop_event_pair_us": inloop_us},
-        "iteration_roofline": {"algorithmic_bytes_per_iter": iter_bytes,
-                               "achieved_GBs": iter_bytes * its / 1e9,
-                               "frac_of_aggregate_hbm": iter_bytes * its / 1e9 / (HBM_PEAK_GBS * world_size)},
+        "roofline": roof,
+        "iteration_roofline": it_roof,
         "device_loop_ms": tm["iterate_ms"],
         "residual": {"first": info["resid_first"], "last": info["resid_last"]},
     }
     if rank == 0 and world_size == 1 and not ARGS.no_cpu:
         line["cpu_baseline"] = cpu_baseline(name)
-    if world_size == 1 and name == "poisson2d-1000" and not ARGS.no_extra:
-        # N=1 reference point of the strong-scaling series the N>1 runs belong to (configs[4])
-        ex = run_cg("poisson3d-512", 100, 10, -1)
-        line["extra"] = {"poisson3d-512@1": {"value": 100 / ex["elapsed"], "unit": "iterations/s",
-                                             "ms_per_step": 1e3 * ex["elapsed"] / 100}}
+    if world_size == 1 and name == "poisson3d-512" and not ARGS.no_extra:
+        # BASELINE configs[1] (CG, 2-D Poisson n = 1e6, one GPU): same measurement, reported beside the headline
+        ex = run_cg("poisson2d-1000", 2000, 200, 0)
+        e_its, e_nnz, e_roof, e_it = roofline_of(ex, "poisson2d-1000", 2000)
+        line["extra"] = {"poisson2d-1000@1": {"value": e_its, "unit": "iterations/s", "steps": 2000, "warmup": 200,
+                                              "ms_per_step": 1e3 * ex["elapsed"] / 2000, "roofline": e_roof,
+                                              "iteration_roofline": e_it}}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if td is not None:

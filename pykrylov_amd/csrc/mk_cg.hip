@@ -16,11 +16,13 @@ struct CgSpmvEpi {
     static constexpr int NACC = 1, SLOT0 = 0;
     const double *p;
     double *Ap;
+    double pr;
     __device__ void prologue(double *) {}
     __device__ double xin(double v) const { return v; }
+    __device__ void pre(int64_t r) { pr = p[r]; }          // issued at the top of the tile
     __device__ void row(int64_t r, double s, double *acc) {
         Ap[r] = s;
-        acc[0] += p[r] * s;
+        acc[0] += pr * s;
     }
 };
 
@@ -48,17 +50,26 @@ struct CgUpdateXR {
         return bad;
     }
     __device__ bool skip() const { return bad; }
-    __device__ void pair(int64_t i, double *acc) {
-        const double2 pv = mk_ld2(p, i), av = mk_ld2(Ap, i);
-        double2 xv = mk_ld2(x, i), rv = mk_ld2(r, i);
-        xv.x = xv.x + alpha * pv.x;                       // cg.py:130
-        xv.y = xv.y + alpha * pv.y;
-        rv.x = rv.x + alpha * av.x;                       // cg.py:131
-        rv.y = rv.y + alpha * av.y;
-        mk_st2(x, i, xv);
-        mk_st2(r, i, rv);
-        acc[0] += rv.x * rv.x;                            // cg.py:146
-        acc[0] += rv.y * rv.y;
+    struct Regs {
+        double2 pv, av, xv, rv;
+    };
+    __device__ void load2(int64_t i, Regs &g) const {
+        g.pv = mk_ld2(p, i);
+        g.av = mk_ld2(Ap, i);
+        g.xv = mk_ld2(x, i);
+        g.rv = mk_ld2(r, i);
+    }
+    __device__ void apply2(Regs &g, double *acc) const {
+        g.xv.x = g.xv.x + alpha * g.pv.x;                 // cg.py:130
+        g.xv.y = g.xv.y + alpha * g.pv.y;
+        g.rv.x = g.rv.x + alpha * g.av.x;                 // cg.py:131
+        g.rv.y = g.rv.y + alpha * g.av.y;
+        acc[0] += g.rv.x * g.rv.x;                        // cg.py:146
+        acc[0] += g.rv.y * g.rv.y;
+    }
+    __device__ void store2(int64_t i, const Regs &g) const {
+        mk_st2(x, i, g.xv);
+        mk_st2(r, i, g.rv);
     }
     __device__ void one(int64_t i, double *acc) {
         x[i] = x[i] + alpha * p[i];
@@ -96,13 +107,18 @@ struct CgUpdateP {
         return !go;
     }
     __device__ bool skip() const { return false; }
-    __device__ void pair(int64_t i, double *) {
-        const double2 rv = mk_ld2(r, i);
-        double2 pv = mk_ld2(p, i);
-        pv.x = beta * pv.x - rv.x;                        // cg.py:150-151 (p *= beta; p -= r)
-        pv.y = beta * pv.y - rv.y;
-        mk_st2(p, i, pv);
+    struct Regs {
+        double2 rv, pv;
+    };
+    __device__ void load2(int64_t i, Regs &g) const {
+        g.rv = mk_ld2(r, i);
+        g.pv = mk_ld2(p, i);
     }
+    __device__ void apply2(Regs &g, double *) const {
+        g.pv.x = beta * g.pv.x - g.rv.x;                  // cg.py:150-151 (p *= beta; p -= r)
+        g.pv.y = beta * g.pv.y - g.rv.y;
+    }
+    __device__ void store2(int64_t i, const Regs &g) const { mk_st2(p, i, g.pv); }
     __device__ void one(int64_t i, double *) { p[i] = beta * p[i] - r[i]; }
 };
 
@@ -161,7 +177,7 @@ struct CgSolver : mk_solver {
     }
 
     int enqueue_spmv_only() override {
-        mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap}, false);
+        mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0}, false);
         return MK_OK;
     }
 
@@ -169,7 +185,7 @@ struct CgSolver : mk_solver {
         const int par = (int)(it & 1);
         int rc = exchange(d_p);
         if (rc != MK_OK) return rc;
-        mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap});
+        mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0});
         if ((rc = allreduce(0, 1)) != MK_OK) return rc;
         mk_launch_stream(this, CgUpdateXR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_p, d_Ap, d_x,
                                           d_r, 0.0, false}, n);

@@ -14,6 +14,9 @@
 // and obey the MkHalt protocol.  Everything is compiled with -ffp-contract=off: each
 // multiply and add rounds separately, exactly like the NumPy expressions being replaced.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "mk_internal.h"
 
 struct MkCsrView {
@@ -66,6 +69,13 @@ typedef int mk_i2 __attribute__((ext_vector_type(2)));
 // Epi interface:   double xin(double xj)            value actually multiplied (e.g. s*y[j])
 //                  void   row(int64_t r, double s, double *acc)   consume the row result
 // ---------------------------------------------------------------------------------------
+// optional epilogue hook `void pre(int64_t r)`: loads that do not depend on the row sum (e.g. p[r] for <p, Ap>)
+// are issued at the top of the tile instead of after the last barrier
+template <class Epi, class = void>
+struct MkHasPre : std::false_type {};
+template <class Epi>
+struct MkHasPre<Epi, std::void_t<decltype(std::declval<Epi &>().pre((int64_t)0))>> : std::true_type {};
+
 template <class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
                                               double *prod, double (&acc)[NACC]) {
@@ -79,30 +89,57 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     const int64_t chunk = (A.ntiles + nxcd - 1) / nxcd;
     const int64_t chunk0 = (int64_t)(blockIdx.x % nxcd) * chunk;
     const int64_t chunk_end = (chunk0 + chunk < A.ntiles) ? chunk0 + chunk : A.ntiles;
-    for (int64_t tile = chunk0 + blockIdx.x / nxcd; tile < chunk_end; tile += per_xcd) {
+
+    // Row pointers of a tile; fetched one tile ahead so that their latency is not on the critical path.
+    struct Meta {
+        int p_lo, p_hi, my_lo, my_hi;
+    };
+    auto load_meta = [&](int64_t tile, Meta &m) {
+        m.p_lo = m.p_hi = m.my_lo = m.my_hi = 0;
+        if (tile < chunk_end) {
+            const int64_t r0 = tile * MK_ROWS_PER_TILE;
+            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
+            const int64_t r = r0 + tid;
+            m.p_lo = A.indptr[r0];
+            m.p_hi = A.indptr[rend];
+            m.my_lo = m.my_hi = m.p_hi;
+            if (r < rend) {
+                m.my_lo = A.indptr[r];
+                m.my_hi = A.indptr[r + 1];
+            }
+        }
+    };
+    int64_t tile = chunk0 + blockIdx.x / nxcd;
+    Meta cur, nxt;
+    load_meta(tile, cur);
+    for (; tile < chunk_end; tile += per_xcd) {
         const int64_t r0 = tile * MK_ROWS_PER_TILE;
         const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
         const int64_t r = r0 + tid;
-        const int p_lo = A.indptr[r0];
-        const int p_hi = A.indptr[rend];
-        int my_lo = p_hi, my_hi = p_hi;
-        if (r < rend) {
-            my_lo = A.indptr[r];
-            my_hi = A.indptr[r + 1];
+        if constexpr (MkHasPre<Epi>::value) {
+            if (r < rend) epi.pre(r);
         }
+        const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo, my_hi = cur.my_hi;
         double sum = 0.0;
+        bool first = true;
         for (int base = p_lo & ~1; base < p_hi; base += MK_SPMV_TILE) {
             const int cnt = (p_hi - base < MK_SPMV_TILE) ? p_hi - base : MK_SPMV_TILE;
-            // ---- pass 1: coalesced stream of the chunk, products into LDS
+            // ---- pass 1: coalesced stream of the chunk, products into LDS.  Straight-line code: loads are
+            // clamped instead of predicated and every lane stores its (possibly unused) products, so that the
+            // compiler keeps all loads of the chunk in flight together.
             mk_i2 col[PAIRS];
             mk_d2 val[PAIRS];
 #pragma unroll
             for (int k = 0; k < PAIRS; ++k) {
                 int j = 2 * (k * MK_BLOCK + tid);
-                j = (j < cnt) ? j : ((cnt - 1) & ~1);    // clamp: loads stay unconditional and aligned
+                j = (j < cnt) ? j : ((cnt - 1) & ~1);
                 col[k] = *reinterpret_cast<const mk_i2 *>(A.indices + base + j);
                 val[k] = *reinterpret_cast<const mk_d2 *>(A.data + base + j);
-                if (j + 1 >= cnt) col[k].y = col[k].x;   // the odd slot past the chunk: keep the gather in range
+                col[k].y = (j + 1 < cnt) ? col[k].y : col[k].x;   // the odd slot past the chunk: keep the gather in range
+            }
+            if (first) {
+                load_meta(tile + per_xcd, nxt);              // next tile's row pointers go in flight now
+                first = false;
             }
             mk_d2 xv[PAIRS];
 #pragma unroll
@@ -112,31 +149,33 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             }
 #pragma unroll
             for (int k = 0; k < PAIRS; ++k) {
-                const int j = 2 * (k * MK_BLOCK + tid);
-                if (j + 1 < cnt) {
-                    mk_d2 pr;
-                    pr.x = val[k].x * epi.xin(xv[k].x);
-                    pr.y = val[k].y * epi.xin(xv[k].y);
-                    *reinterpret_cast<mk_d2 *>(prod + j) = pr;
-                } else if (j < cnt) {
-                    prod[j] = val[k].x * epi.xin(xv[k].x);
-                }
+                mk_d2 pr;
+                pr.x = val[k].x * epi.xin(xv[k].x);
+                pr.y = val[k].y * epi.xin(xv[k].y);
+                *reinterpret_cast<mk_d2 *>(prod + 2 * (k * MK_BLOCK + tid)) = pr;
             }
             __syncthreads();
-            // ---- pass 2: one lane per row, left-to-right sum of its segment
+            // ---- pass 2: one lane per row, left-to-right sum of its segment (clamped reads + selects)
             const int lo = ((my_lo > base) ? my_lo : base) - base;
             const int hi = ((my_hi < base + cnt) ? my_hi : base + cnt) - base;
             const int len = hi - lo;
             double t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = (k < len) ? prod[lo + k] : 0.0;
+            for (int k = 0; k < 8; ++k) {
+                const int idx = lo + k;
+                t[k] = prod[(idx < MK_SPMV_TILE && idx >= 0) ? idx : 0];
+            }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < len) sum += t[k];
+            for (int k = 0; k < 8; ++k) {
+                const double s2 = sum + t[k];
+                sum = (k < len) ? s2 : sum;
+            }
             for (int k = 8; k < len; ++k) sum += prod[lo + k];
             __syncthreads();
         }
+        if (first) load_meta(tile + per_xcd, nxt);           // empty tile: still advance the prefetch
         if (r < rend) epi.row(r, sum, acc);
+        cur = nxt;
     }
 }
 
@@ -185,10 +224,36 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const do
 // Lane g of the grid handles pairs g, g+S, g+2S, ...  (S = total lanes): every wave
 // instruction touches 1 KiB of consecutive memory.
 // ---------------------------------------------------------------------------------------
+// Ops may additionally provide the split form  struct Regs; load2(i, Regs&); apply2(Regs&, acc); store2(i, Regs&):
+// the kernel then issues the loads of each lane's FIRST pair before it waits for anything else (halt word, partial
+// sums, the prologue's barriers), which takes about one memory latency off every launch -- what matters for the
+// cache-resident sizes where a whole kernel lasts 5-10 us.
+template <class Op, class = void>
+struct MkIsSplit : std::false_type {};
+template <class Op>
+struct MkIsSplit<Op, std::void_t<typename Op::Regs>> : std::true_type {};
+template <class Op, bool = MkIsSplit<Op>::value>
+struct MkRegsOf {
+    struct type {};
+};
+template <class Op>
+struct MkRegsOf<Op, true> {
+    using type = typename Op::Regs;
+};
+
 template <class Op>
 __global__ __launch_bounds__(MK_BLOCK) void mk_stream_kernel(Op op, int64_t n, MkHalt halt,
                                                              double *__restrict__ partials) {
     __shared__ double s4[4];
+    constexpr bool split = MkIsSplit<Op>::value;
+    const int64_t S = (int64_t)gridDim.x * MK_BLOCK;
+    const int64_t g = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x;
+    const int64_t npair = n >> 1;
+    [[maybe_unused]] typename MkRegsOf<Op>::type first;
+    [[maybe_unused]] const bool has_first = g < npair;
+    if constexpr (split) {
+        if (has_first) op.load2(2 * g, first);       // in flight while the prologue runs (barriers pin it here)
+    }
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (halted) {
@@ -201,10 +266,20 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_stream_kernel(Op op, int64_t n, M
     double acc[Op::NACC > 0 ? Op::NACC : 1];
 #pragma unroll
     for (int d = 0; d < (Op::NACC > 0 ? Op::NACC : 1); ++d) acc[d] = 0.0;
-    const int64_t S = (int64_t)gridDim.x * MK_BLOCK;
-    const int64_t g = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x;
-    const int64_t npair = n >> 1;
-    for (int64_t q = g; q < npair; q += S) op.pair(2 * q, acc);
+    if constexpr (split) {
+        if (has_first) {
+            op.apply2(first, acc);
+            op.store2(2 * g, first);
+        }
+        for (int64_t q = g + S; q < npair; q += S) {
+            typename Op::Regs r;
+            op.load2(2 * q, r);
+            op.apply2(r, acc);
+            op.store2(2 * q, r);
+        }
+    } else {
+        for (int64_t q = g; q < npair; q += S) op.pair(2 * q, acc);
+    }
     if ((n & 1) && g == (npair % S)) op.one(n - 1, acc);
 #pragma unroll
     for (int d = 0; d < Op::NACC; ++d) {

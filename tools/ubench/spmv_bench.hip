@@ -192,7 +192,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_pipe(const int* __restrict__ ip, c
 
 // VAR 7: x window [r0 - H, r0 + 256 + H) staged in LDS by coalesced loads; gathers inside the window come from
 // LDS, the rest from global memory.
-template <int XCD, int H>
+template <int XCD, int H, int BF = 0>
 __global__ __launch_bounds__(BLOCK) void spmv_win(const int* __restrict__ ip, const int* __restrict__ ix, const double* __restrict__ dv,
                                                   const double* __restrict__ x, double* __restrict__ y, long nrows, long ncols, long ntiles, double* part) {
     constexpr int WIN = ROWS + 2 * H;
@@ -220,8 +220,20 @@ __global__ __launch_bounds__(BLOCK) void spmv_win(const int* __restrict__ ip, co
                 __syncthreads();
             }
             double xv[8];
+            if (BF) {
+                // branch-free: every lane issues one LDS read (clamped index) and one global load (out-of-window
+                // lanes their real column, in-window lanes one shared dummy address), then selects
+                double xl[8], xg[8]; bool inw[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const long rel = (long)col[k] - w0; inw[k] = (rel >= 0 && rel < WIN); xl[k] = xw[inw[k] ? rel : 0]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xg[k] = x[inw[k] ? r0 : (long)col[k]];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] = inw[k] ? xl[k] : xg[k];
+            } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const long rel = (long)col[k] - w0; xv[k] = (rel >= 0 && rel < WIN) ? xw[rel] : x[col[k]]; }
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const int j = k * BLOCK + tid; if (j < cnt) prod[j] = val[k] * xv[k]; }
             __syncthreads();
@@ -331,6 +343,10 @@ int main(int argc, char** argv) {
 #define RUNR(XCD) for (int g : {1024, 1280, 2048}) { float ms = timeit([&] { hipLaunchKernelGGL((spmv_rowgather<XCD>), dim3(g), dim3(BLOCK), 0, 0, ip, ix, dv, x, y, n, ntiles, part); }, reps); \
         CK(hipMemcpy(h0.data(), y0, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), y, n * 8, hipMemcpyDeviceToHost)); const char* ok = "bit-exact"; for (long i = 0; i < n; ++i) if (h0[i] != h1[i]) { ok = "MISMATCH"; break; } \
         printf("rowg  xcd=%d grid=%4d : %9.1f us  %.2f TB/s  %s\n", XCD, g, ms * 1e3, bytes / ms / 1e9, ok); }
-    RUNR(0) RUNR(1)
+    RUNR(0)
+#define RUNWB(XCD, H) for (int g : {1024, 2048}) { float ms = timeit([&] { hipLaunchKernelGGL((spmv_win<XCD, H, 1>), dim3(g), dim3(BLOCK), 0, 0, ip, ix, dv, x, y, n, n, ntiles, part); }, reps); \
+        CK(hipMemcpy(h0.data(), y0, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), y, n * 8, hipMemcpyDeviceToHost)); const char* ok = "bit-exact"; for (long i = 0; i < n; ++i) if (h0[i] != h1[i]) { ok = "MISMATCH"; break; } \
+        printf("winBF xcd=%d H=%4d grid=%4d : %9.1f us  %.2f TB/s  %s\n", XCD, H, g, ms * 1e3, bytes / ms / 1e9, ok); }
+    RUNWB(0, 512) RUNWB(1, 512) RUNWB(0, 1024) RUNWB(1, 1024) RUNWB(1, 64)
     return 0;
 }
