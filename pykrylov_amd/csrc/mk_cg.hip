@@ -2,15 +2,18 @@
 //
 // One pass of the reference loop (cg.py:113-158) = three kernels:
 //   K1  Ap = A p ; partial sums of <p, Ap>                          (cg.py:115-117)
-//   K2  alpha = ry / pAp ; x += alpha p ; r += alpha Ap ; partial sums of <r, r>   (cg.py:119-146)
-//   K3  beta = ry' / ry ; p = beta p - r ; residNorm, history, loop test           (cg.py:149-158, :113)
-// Algorithmic traffic per pass: B_spmv + (32n read + 16n write) + (16n read + 8n write)
-//   = B_spmv + 72n bytes (the reference's op count gives B_spmv + 104n).
+//   K2  alpha = ry / pAp ; r += alpha Ap ; partial sums of <r, r>                  (cg.py:119-127,131,146)
+//   K3  x += alpha p ; beta = ry' / ry ; p = beta p - r ; residNorm, history, loop test
+//                                                                                  (cg.py:130,149-158, :113)
+// The x update rides in K3 because K3 streams p anyway (x is not read by anything in between and K3 always
+// runs when K2 did), which saves one pass over p.  Same operations on the same values: results are unchanged.
+// Algorithmic traffic per pass: B_spmv + (16n read + 8n write) + (24n read + 16n write)
+//   = B_spmv + 64n bytes (the reference's op count gives B_spmv + 104n).
 #include "mk_solver.h"
 
 namespace {
 
-enum { S_RY0 = 0, S_RY1 = 1, S_THRESH = 2, S_RESID = 3, S_RESID0 = 4, S_PAP = 5 };
+enum { S_RY0 = 0, S_RY1 = 1, S_THRESH = 2, S_RESID = 3, S_RESID0 = 4, S_PAP = 5, S_ALPHA = 6 };
 
 struct CgSpmvEpi {
     static constexpr int NACC = 1, SLOT0 = 0;
@@ -26,15 +29,15 @@ struct CgSpmvEpi {
     }
 };
 
-struct CgUpdateXR {
+struct CgUpdateR {
     static constexpr int NACC = 1, SLOT0 = 1;
     const double *part;
     int np;
     double *scal;
     MkStatus *st;
     int par, check_curv;
-    const double *p, *Ap;
-    double *x, *r;
+    const double *Ap;
+    double *r;
     double alpha;
     bool bad;
     __device__ bool prologue(double *s4, bool lead) {
@@ -45,41 +48,34 @@ struct CgUpdateXR {
         if (lead) {
             st->nMatvec += 1;                             // cg.py:116
             scal[S_PAP] = pAp;
+            scal[S_ALPHA] = alpha;
             if (bad) st->definite = 0;
         }
         return bad;
     }
     __device__ bool skip() const { return bad; }
     struct Regs {
-        double2 pv, av, xv, rv;
+        double2 av, rv;
     };
     __device__ void load2(int64_t i, Regs &g) const {
-        g.pv = mk_ld2(p, i);
         g.av = mk_ld2(Ap, i);
-        g.xv = mk_ld2(x, i);
         g.rv = mk_ld2(r, i);
     }
     __device__ void apply2(Regs &g, double *acc) const {
-        g.xv.x = g.xv.x + alpha * g.pv.x;                 // cg.py:130
-        g.xv.y = g.xv.y + alpha * g.pv.y;
         g.rv.x = g.rv.x + alpha * g.av.x;                 // cg.py:131
         g.rv.y = g.rv.y + alpha * g.av.y;
         acc[0] += g.rv.x * g.rv.x;                        // cg.py:146
         acc[0] += g.rv.y * g.rv.y;
     }
-    __device__ void store2(int64_t i, const Regs &g) const {
-        mk_st2(x, i, g.xv);
-        mk_st2(r, i, g.rv);
-    }
+    __device__ void store2(int64_t i, const Regs &g) const { mk_st2(r, i, g.rv); }
     __device__ void one(int64_t i, double *acc) {
-        x[i] = x[i] + alpha * p[i];
         const double rv = r[i] + alpha * Ap[i];
         r[i] = rv;
         acc[0] += rv * rv;
     }
 };
 
-struct CgUpdateP {
+struct CgUpdateXP {
     static constexpr int NACC = 0, SLOT0 = 0;
     const double *part;
     int np;
@@ -89,11 +85,12 @@ struct CgUpdateP {
     int par;
     int64_t matvec_max;
     const double *r;
-    double *p;
-    double beta;
+    double *p, *x;
+    double alpha, beta;
     __device__ bool prologue(double *s4, bool lead) {
         const double ry_next = mk_total(part + MK_MAXP, np, s4);
         const double ry = scal[S_RY0 + par];
+        alpha = scal[S_ALPHA];                            // written by K2 of this pass
         beta = ry_next / ry;                              // cg.py:149
         const double resid = fabs(__dsqrt_rn(ry_next));   // cg.py:154
         const bool go = (resid > scal[S_THRESH]) && (st->nMatvec < matvec_max);   // cg.py:113
@@ -108,18 +105,28 @@ struct CgUpdateP {
     }
     __device__ bool skip() const { return false; }
     struct Regs {
-        double2 rv, pv;
+        double2 rv, pv, xv;
     };
     __device__ void load2(int64_t i, Regs &g) const {
         g.rv = mk_ld2(r, i);
         g.pv = mk_ld2(p, i);
+        g.xv = mk_ld2(x, i);
     }
     __device__ void apply2(Regs &g, double *) const {
+        g.xv.x = g.xv.x + alpha * g.pv.x;                 // cg.py:130 (with the p of this pass)
+        g.xv.y = g.xv.y + alpha * g.pv.y;
         g.pv.x = beta * g.pv.x - g.rv.x;                  // cg.py:150-151 (p *= beta; p -= r)
         g.pv.y = beta * g.pv.y - g.rv.y;
     }
-    __device__ void store2(int64_t i, const Regs &g) const { mk_st2(p, i, g.pv); }
-    __device__ void one(int64_t i, double *) { p[i] = beta * p[i] - r[i]; }
+    __device__ void store2(int64_t i, const Regs &g) const {
+        mk_st2(x, i, g.xv);
+        mk_st2(p, i, g.pv);
+    }
+    __device__ void one(int64_t i, double *) {
+        const double pv = p[i];
+        x[i] = x[i] + alpha * pv;
+        p[i] = beta * pv - r[i];
+    }
 };
 
 // everything between the initial <r, y> and the loop header (cg.py:99-113)
@@ -187,11 +194,11 @@ struct CgSolver : mk_solver {
         if (rc != MK_OK) return rc;
         mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0});
         if ((rc = allreduce(0, 1)) != MK_OK) return rc;
-        mk_launch_stream(this, CgUpdateXR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_p, d_Ap, d_x,
-                                          d_r, 0.0, false}, n);
+        mk_launch_stream(this, CgUpdateR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_Ap, d_r, 0.0,
+                                         false}, n);
         if ((rc = allreduce(1, 1)) != MK_OK) return rc;
-        mk_launch_stream(this, CgUpdateP{d_part, np_stream, d_scal, d_status, d_hist, par, prm.matvec_max, d_r, d_p,
-                                         0.0}, n);
+        mk_launch_stream(this, CgUpdateXP{d_part, np_stream, d_scal, d_status, d_hist, par, prm.matvec_max, d_r, d_p,
+                                          d_x, 0.0, 0.0}, n);
         return MK_OK;
     }
 

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1000 --warmup 100 --no-cpu --no-extra $*"
+ARGS="--steps ${STEPS:-300} --warmup 20 --no-cpu --no-extra $*"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o bench -- python $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o bench -- python $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -o bench -- python $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/bench_write.err
