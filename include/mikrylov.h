@@ -179,6 +179,12 @@ int mk_solver_destroy(mk_solver *s);
  * transposed matrix (mk_csr_transpose) before mk_solver_setup.  rhs then has nrows(A) entries and x
  * ncols(A) (CRAIG-MR: nrows(A), craigmr.py:112). */
 int mk_solver_set_transpose(mk_solver *s, const mk_csr *At);
+/* Diagonal (Jacobi-type) preconditioner: `diag` is a device array with nrows(A) entries holding the diagonal of
+ * the operator the reference applies as `precon * r` (cg.py:91-92,137-138; bicgstab.py:96-99,120-123;
+ * cgs.py:79-82,88-91; tfqmr.py:77-80; minres.py:162-163,249; symmlq.py:134,228), i.e. what a
+ * linop.DiagonalOperator(diag) (linop.py:473-516) multiplies by.  Borrowed: it must stay alive until the solver
+ * is destroyed.  NULL removes it.  Call before mk_solver_setup.  MK_ERR_UNSUPPORTED for the lls kinds. */
+int mk_solver_set_precon_diag(mk_solver *s, const double *diag);
 /* Everything before the `while` loop of the reference's solve().  rhs_dev has n_local
  * entries; guess_dev may be NULL (x0 = 0).  Neither is modified. */
 int mk_solver_setup(mk_solver *s, const double *rhs_dev, const double *guess_dev);

@@ -40,7 +40,7 @@ class CG(KrylovMethod):
             :store_iterates:  keep every iterate in `self.iterates` (default False)
         """
         op = self._device_operator()
-        self._no_precon(self.precon)
+        pdiag = self._device_precon(self.precon)
         n = rhs.shape[0]
         store_resids = kwargs.get('store_resids', False)
         store_iterates = kwargs.get('store_iterates', False)
@@ -53,7 +53,8 @@ class CG(KrylovMethod):
         guess = kwargs.get('guess', None)
         matvec_max = kwargs.get('matvec_max', 2 * n)
 
-        with DeviceRun(op, _lib.MK_CG, rhs, guess, abstol=float(self.abstol), reltol=float(self.reltol),
+        with DeviceRun(op, _lib.MK_CG, rhs, guess, precon_diag=pdiag, abstol=float(self.abstol),
+                       reltol=float(self.reltol),
                        matvec_max=int(matvec_max),
                        check_curvature=int(bool(kwargs.get('check_curvature', True)))) as run:
             if store_resids or store_iterates:
@@ -63,7 +64,7 @@ class CG(KrylovMethod):
                 if store_iterates:
                     self.iterates.append(run.x())
                 if store_resids:
-                    self.resids.append(run.vector(0))
+                    self.resids.append(run.vector(0) if pdiag is None else pdiag * run.vector(0))
                 while not res.halted:
                     run.iterate(1)
                     res = run.finish()
@@ -71,7 +72,7 @@ class CG(KrylovMethod):
                         if store_iterates:
                             self.iterates.append(run.x())
                         if store_resids:
-                            self.resids.append(run.vector(0))
+                            self.resids.append(run.vector(0) if pdiag is None else pdiag * run.vector(0))
             else:
                 res = run.run()
             x = run.x()

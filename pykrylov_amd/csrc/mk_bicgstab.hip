@@ -7,6 +7,8 @@
 //   F  omega, rho' ; r = s - omega t ; s *= omega ; x += s ; x += alpha p ; partial <r,r> ;
 //      and, already here, next pass's  p = beta p - beta omega v + r                     (:130-139, :87-93)
 // Algorithmic traffic per pass: 2 B_spmv + 8n (r0 in B) + 32n (C) + 16n (r0, s in D) + 80n (F).
+// With a diagonal preconditioner (q = precon*p, z = precon*s; :96-99,:120-123) the products read q and z, which
+// the kernels that produce p and s write alongside (C: z = d*s; F: z *= omega, x += z + alpha q, q' = d*p').
 #include "mk_solver.h"
 
 namespace {
@@ -60,6 +62,8 @@ struct OpC {     // alpha, s = r - alpha v, <s,s>
     int par;
     const double *r, *v;
     double *s;
+    const double *dg;                                       // preconditioner diagonal or null
+    double *z;                                              // z = precon * s (only with dg)
     double alpha;
     __device__ bool prologue(double *s4, bool lead) {
         const double r0v = mk_total(part + SLOT_R0V * MK_MAXP, np, s4);
@@ -74,12 +78,20 @@ struct OpC {     // alpha, s = r - alpha v, <s,s>
         sv.x = rv.x - alpha * vv.x;                         // bicgstab.py:104
         sv.y = rv.y - alpha * vv.y;
         mk_st2(s, i, sv);
+        if (dg) {                                           // bicgstab.py:120-121
+            const double2 dv = mk_ld2(dg, i);
+            double2 zv;
+            zv.x = dv.x * sv.x;
+            zv.y = dv.y * sv.y;
+            mk_st2(z, i, zv);
+        }
         acc[0] += sv.x * sv.x;
         acc[0] += sv.y * sv.y;
     }
     __device__ void one(int64_t i, double *acc) {
         const double sv = r[i] - alpha * v[i];
         s[i] = sv;
+        if (dg) z[i] = dg[i] * sv;
         acc[0] += sv * sv;
     }
 };
@@ -128,6 +140,8 @@ struct OpF {
     int par;
     const double *t, *v;
     double *s, *r, *x, *p;
+    const double *dg;                                       // preconditioner diagonal or null
+    double *q, *z;                                          // q = precon * p, z = precon * s (only with dg)
     double alpha, omega, beta, bo;
     int ex;
     __device__ bool prologue(double *s4, bool lead) {
@@ -149,50 +163,74 @@ struct OpF {
         return ex != 0;
     }
     __device__ bool skip() const { return ex == 2; }
-    __device__ void elem(double tv, double vv, double &sv, double &rv, double &xv, double &pv, double *acc) {
+    // zv: the vector that is scaled by omega and added to x (s itself without a preconditioner);
+    // qv: the vector x advances along (p itself without a preconditioner)
+    __device__ void elem(double tv, double vv, double sv, double &zv, double qv, double dv, double &rv, double &xv,
+                         double &pv, double &qn, double *acc) {
         if (ex == 1) {
-            xv = xv + alpha * pv;                           // bicgstab.py:112
+            xv = xv + alpha * qv;                           // bicgstab.py:112
             return;
         }
         rv = sv - omega * tv;                               // bicgstab.py:130
-        sv = sv * omega;                                    // bicgstab.py:135 (z is s)
-        xv = xv + sv;                                       // bicgstab.py:136
-        xv = xv + alpha * pv;                               // bicgstab.py:137
+        zv = zv * omega;                                    // bicgstab.py:135
+        xv = xv + zv;                                       // bicgstab.py:136
+        xv = xv + alpha * qv;                               // bicgstab.py:137
         acc[0] += rv * rv;                                  // bicgstab.py:139
         pv = pv * beta;                                     // bicgstab.py:91
         pv = pv - bo * vv;                                  // bicgstab.py:92
         pv = pv + rv;                                       // bicgstab.py:93
+        qn = dv * pv;                                       // bicgstab.py:96-97 (next pass; unused without dg)
     }
     __device__ void pair(int64_t i, double *acc) {
-        double2 tv{0, 0}, vv{0, 0}, sv{0, 0}, rv{0, 0};
+        double2 tv{0, 0}, vv{0, 0}, sv{0, 0}, rv{0, 0}, zv{0, 0}, dv{0, 0}, qn{0, 0};
         if (ex == 0) {
             tv = mk_ld2(t, i);
             vv = mk_ld2(v, i);
             sv = mk_ld2(s, i);
         }
-        double2 xv = mk_ld2(x, i), pv = mk_ld2(p, i);
-        elem(tv.x, vv.x, sv.x, rv.x, xv.x, pv.x, acc);
-        elem(tv.y, vv.y, sv.y, rv.y, xv.y, pv.y, acc);
+        double2 xv = mk_ld2(x, i), pv = mk_ld2(p, i), qv = pv;
+        if (dg) {
+            qv = mk_ld2(q, i);
+            if (ex == 0) {
+                zv = mk_ld2(z, i);
+                dv = mk_ld2(dg, i);
+            }
+        } else {
+            zv = sv;
+        }
+        elem(tv.x, vv.x, sv.x, zv.x, qv.x, dv.x, rv.x, xv.x, pv.x, qn.x, acc);
+        elem(tv.y, vv.y, sv.y, zv.y, qv.y, dv.y, rv.y, xv.y, pv.y, qn.y, acc);
         mk_st2(x, i, xv);
         if (ex == 0) {
-            mk_st2(s, i, sv);
+            mk_st2(dg ? z : s, i, zv);
             mk_st2(r, i, rv);
             mk_st2(p, i, pv);
+            if (dg) mk_st2(q, i, qn);
         }
     }
     __device__ void one(int64_t i, double *acc) {
-        double tv = 0, vv = 0, sv = 0, rv = 0, xv = x[i], pv = p[i];
+        double tv = 0, vv = 0, sv = 0, rv = 0, zv = 0, dv = 0, qn = 0, xv = x[i], pv = p[i], qv = pv;
         if (ex == 0) {
             tv = t[i];
             vv = v[i];
             sv = s[i];
         }
-        elem(tv, vv, sv, rv, xv, pv, acc);
+        if (dg) {
+            qv = q[i];
+            if (ex == 0) {
+                zv = z[i];
+                dv = dg[i];
+            }
+        } else {
+            zv = sv;
+        }
+        elem(tv, vv, sv, zv, qv, dv, rv, xv, pv, qn, acc);
         x[i] = xv;
         if (ex == 0) {
-            s[i] = sv;
+            (dg ? z : s)[i] = zv;
             r[i] = rv;
             p[i] = pv;
+            if (dg) q[i] = qn;
         }
     }
 };
@@ -218,8 +256,9 @@ __global__ __launch_bounds__(MK_BLOCK) void bicgstab_init_kernel(const double *p
 
 struct BicgstabSolver : mk_solver {
     double *d_x = nullptr, *d_r0 = nullptr, *d_r = nullptr, *d_p = nullptr, *d_v = nullptr, *d_s = nullptr,
-           *d_t = nullptr;
+           *d_t = nullptr, *d_q = nullptr, *d_z = nullptr;
     int64_t nmv0 = 0;
+    bool takes_precon() const override { return true; }
 
     int setup(const double *rhs, const double *guess) override {
         if (!d_x) {
@@ -228,6 +267,10 @@ struct BicgstabSolver : mk_solver {
                 (rc = alloc_vec(&d_p, nx)) || (rc = alloc_vec(&d_v, n)) || (rc = alloc_vec(&d_s, nx)) ||
                 (rc = alloc_vec(&d_t, n)))
                 return rc;
+        }
+        if (d_prec && !d_q) {
+            int rc;
+            if ((rc = alloc_vec(&d_q, nx)) || (rc = alloc_vec(&d_z, nx))) return rc;
         }
         nmv0 = 0;
         if (guess) {
@@ -249,25 +292,27 @@ struct BicgstabSolver : mk_solver {
         // r = r0.copy(); p = v = 0; the first pass's p update (beta p - beta omega v + r) gives exactly r
         mk_launch_stream(this, MkOpCopy{d_r0, d_r}, n);
         mk_launch_stream(this, MkOpCopy{d_r0, d_p}, n);
+        if (d_prec) mk_launch_stream(this, MkOpMul{d_prec, d_r0, d_q}, n);     // q = precon * p   bicgstab.py:96-97
         MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)n, stream));
         return MK_OK;
     }
 
     int enqueue_pass() override {
         const int par = (int)(it & 1);
-        int rc = exchange(d_p);
+        double *qin = d_prec ? d_q : d_p, *zin = d_prec ? d_z : d_s;           // what the two products read
+        int rc = exchange(qin);
         if (rc != MK_OK) return rc;
-        mk_launch_spmv(this, d_p, BEpi{d_r0, d_v}, true,
+        mk_launch_spmv(this, qin, BEpi{d_r0, d_v}, true,
                        GateB{d_part, np_stream, d_scal, d_status, it == 0 ? 1 : 0, prm.matvec_max, nmv0 + 2 * it});
         if ((rc = allreduce(SLOT_R0V, 1)) != MK_OK) return rc;
-        mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_r, d_v, d_s, 0.0}, n);
+        mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_r, d_v, d_s, d_prec, d_z, 0.0}, n);
         if ((rc = allreduce(SLOT_SS, 1)) != MK_OK) return rc;
-        if ((rc = exchange(d_s)) != MK_OK) return rc;
-        mk_launch_spmv(this, d_s, DEpi{d_s, d_r0, d_t}, true,
+        if ((rc = exchange(zin)) != MK_OK) return rc;
+        mk_launch_spmv(this, zin, DEpi{d_s, d_r0, d_t}, true,
                        GateD{d_part, np_stream, d_scal, d_status, prm.matvec_max, nmv0 + 2 * it + 1});
         if ((rc = allreduce(SLOT_TS, 3)) != MK_OK) return rc;
-        mk_launch_stream(this, OpF{d_part, np_spmv, d_scal, d_status, par, d_t, d_v, d_s, d_r, d_x, d_p, 0, 0, 0, 0, 0},
-                         n);
+        mk_launch_stream(this, OpF{d_part, np_spmv, d_scal, d_status, par, d_t, d_v, d_s, d_r, d_x, d_p, d_prec, d_q,
+                                   d_z, 0, 0, 0, 0, 0}, n);
         if ((rc = allreduce(SLOT_RR, 1)) != MK_OK) return rc;
         return MK_OK;
     }

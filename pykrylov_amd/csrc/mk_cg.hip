@@ -38,6 +38,7 @@ struct CgUpdateR {
     int par, check_curv;
     const double *Ap;
     double *r;
+    const double *dg;                                     // preconditioner diagonal or null
     double alpha;
     bool bad;
     __device__ bool prologue(double *s4, bool lead) {
@@ -55,23 +56,29 @@ struct CgUpdateR {
     }
     __device__ bool skip() const { return bad; }
     struct Regs {
-        double2 av, rv;
+        double2 av, rv, dv;
     };
     __device__ void load2(int64_t i, Regs &g) const {
         g.av = mk_ld2(Ap, i);
         g.rv = mk_ld2(r, i);
+        if (dg) g.dv = mk_ld2(dg, i);
     }
     __device__ void apply2(Regs &g, double *acc) const {
         g.rv.x = g.rv.x + alpha * g.av.x;                 // cg.py:131
         g.rv.y = g.rv.y + alpha * g.av.y;
-        acc[0] += g.rv.x * g.rv.x;                        // cg.py:146
-        acc[0] += g.rv.y * g.rv.y;
+        if (dg) {                                         // y = precon * r ; <r, y>   cg.py:137-138,146
+            acc[0] += g.rv.x * (g.dv.x * g.rv.x);
+            acc[0] += g.rv.y * (g.dv.y * g.rv.y);
+        } else {
+            acc[0] += g.rv.x * g.rv.x;                    // cg.py:146
+            acc[0] += g.rv.y * g.rv.y;
+        }
     }
     __device__ void store2(int64_t i, const Regs &g) const { mk_st2(r, i, g.rv); }
     __device__ void one(int64_t i, double *acc) {
         const double rv = r[i] + alpha * Ap[i];
         r[i] = rv;
-        acc[0] += rv * rv;
+        acc[0] += dg ? rv * (dg[i] * rv) : rv * rv;
     }
 };
 
@@ -174,7 +181,12 @@ struct CgSolver : mk_solver {
         } else {
             MK_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)nx, stream));
         }
-        mk_launch_stream(this, MkOpDot<1>{d_r, d_r}, n);                    // ry = <r, r>       cg.py:99
+        if (d_prec) {
+            mk_launch_stream(this, MkOpMul{d_prec, d_r, d_Ap}, n);          // y = precon * r    cg.py:91-92
+            mk_launch_stream(this, MkOpDot<1>{d_r, d_Ap}, n);               // ry = <r, y>       cg.py:99
+        } else {
+            mk_launch_stream(this, MkOpDot<1>{d_r, d_r}, n);                // ry = <r, r>       cg.py:99
+        }
         int rc = allreduce(1, 1);
         if (rc != MK_OK) return rc;
         hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_stream, d_scal, d_status,
@@ -194,8 +206,8 @@ struct CgSolver : mk_solver {
         if (rc != MK_OK) return rc;
         mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0});
         if ((rc = allreduce(0, 1)) != MK_OK) return rc;
-        mk_launch_stream(this, CgUpdateR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_Ap, d_r, 0.0,
-                                         false}, n);
+        mk_launch_stream(this, CgUpdateR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_Ap, d_r,
+                                         d_prec, 0.0, false}, n);
         if ((rc = allreduce(1, 1)) != MK_OK) return rc;
         mk_launch_stream(this, CgUpdateXP{d_part, np_stream, d_scal, d_status, d_hist, par, prm.matvec_max, d_r, d_p,
                                           d_x, 0.0, 0.0}, n);
@@ -216,6 +228,8 @@ struct CgSolver : mk_solver {
 
     const double *x() const override { return d_x; }
     const double *vector(int i) const override { return i == 0 ? d_r : (i == 1 ? d_p : nullptr); }
+    // The search direction is built from r, not from y = precon*r, exactly as cg.py:104,150-151 do.
+    bool takes_precon() const override { return true; }
 };
 
 }  // namespace

@@ -29,6 +29,7 @@ int mk_comm_allreduce_sum(double *buf_dev, int64_t count, hipStream_t stream);
 struct mk_solver {
     const mk_csr *A = nullptr;
     const mk_csr *At = nullptr;     // transposed matrix (least-squares solvers only)
+    const double *d_prec = nullptr; // diagonal of a Jacobi-type preconditioner M^-1 (borrowed, n entries) or null
     mk_params prm{};
     int64_t n = 0;        // local rows = length of every solver vector
     int64_t nx = 0;       // length of vectors that feed an SpMV (n + halo)
@@ -66,6 +67,7 @@ struct mk_solver {
     virtual int finish(mk_result *res) = 0;
     virtual const double *x() const = 0;
     virtual const double *vector(int) const { return nullptr; }
+    virtual bool takes_precon() const { return false; }
     // enqueue only the solver's (fused) SpMV kernel, exactly as a loop pass launches it; used to time
     // that kernel back to back.  Overwrites the product vector and its partial sums.
     virtual int enqueue_spmv_only() { return mk_fail(MK_ERR_UNSUPPORTED, "SpMV timing is not wired for this solver"); }
@@ -148,6 +150,21 @@ struct MkOpSub {                // out = a - b
         mk_st2(out, i, u);
     }
     __device__ void one(int64_t i, double *) { out[i] = a[i] - b[i]; }
+};
+
+struct MkOpMul {                // out = a * b elementwise  (DiagonalOperator matvec `diag*x`, linop.py:503)
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *a, *b;
+    double *out;
+    __device__ bool prologue(double *, bool) { return false; }
+    __device__ bool skip() const { return false; }
+    __device__ void pair(int64_t i, double *) {
+        double2 u = mk_ld2(a, i), v = mk_ld2(b, i);
+        u.x *= v.x;
+        u.y *= v.y;
+        mk_st2(out, i, u);
+    }
+    __device__ void one(int64_t i, double *) { out[i] = a[i] * b[i]; }
 };
 
 template <int SLOT>             // partial sums of dot(a, b) into slot SLOT

@@ -205,6 +205,14 @@ extern "C" int mk_solver_set_transpose(mk_solver *s, const mk_csr *At) {
     return MK_OK;
 }
 
+extern "C" int mk_solver_set_precon_diag(mk_solver *s, const double *diag) {
+    MK_ARG(s);
+    if (diag && !s->takes_precon())
+        return mk_fail(MK_ERR_UNSUPPORTED, "this solver kind has no device preconditioner hook");
+    s->d_prec = diag;
+    return MK_OK;
+}
+
 extern "C" int mk_solver_destroy(mk_solver *s) {
     delete s;
     return MK_OK;

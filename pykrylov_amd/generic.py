@@ -71,6 +71,22 @@ class KrylovMethod(object):
             raise NotImplementedError('%s: preconditioners are not available on the device path yet'
                                       % self.__class__.__name__)
 
+    def _device_precon(self, precon):
+        """The diagonal of a preconditioner the device loop can apply (``precon * r`` with a DiagonalOperator,
+        reference linop.py:473-516; the docs' `DiagonalPrec`, examples/bmark.py:14-23), or None.
+
+        Anything else -- an arbitrary callable / operator -- cannot run inside the device-resident loop and is
+        refused loudly: there is no host fallback."""
+        if precon is None:
+            return None
+        diag = getattr(precon, 'diag', None)
+        if diag is None or callable(diag):
+            raise NotImplementedError('%s: only diagonal preconditioners (an operator with a `.diag` array, e.g. '
+                                      'pykrylov_amd.linop.DiagonalOperator) run on the device path; got %r'
+                                      % (self.__class__.__name__, type(precon).__name__))
+        n = self.op.shape[0]
+        return as_f64_vector(diag, getattr(self.op, 'local_size', None) or n, 'precon.diag')
+
     def _logging(self):
         return self.logger is not null_log and self.logger.isEnabledFor(logging.INFO)
 
@@ -87,9 +103,10 @@ def as_f64_vector(v, n, what):
 class DeviceRun(object):
     """One solve on the device: owns the ``mk_solver`` handle and the rhs / guess buffers."""
 
-    def __init__(self, op, kind, rhs, guess=None, **params):
+    def __init__(self, op, kind, rhs, guess=None, precon_diag=None, **params):
         self.lib = _lib.init()
         self.op = op
+        self.d_prec = None
         n = getattr(op, 'local_size', None) or op.shape[1]     # row-partitioned operator: local rows
         self.n = n
         # rhs / guess: host arrays (copied to HBM) or DeviceArray objects already resident there
@@ -108,6 +125,12 @@ class DeviceRun(object):
             setattr(p, k, v)
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.mk_solver_create(op.handle, ctypes.byref(p), ctypes.byref(self.handle)))
+        if precon_diag is not None:
+            self.d_prec = precon_diag if isinstance(precon_diag, _lib.DeviceArray) else \
+                _lib.DeviceArray.from_numpy(as_f64_vector(precon_diag, n, 'precon.diag'))
+            if isinstance(precon_diag, _lib.DeviceArray):
+                self._borrowed.append(precon_diag)
+            _lib.check(self.lib.mk_solver_set_precon_diag(self.handle, self.d_prec.ptr))
         self.result = _lib.MkResult()
         self._setup_done = False
 
@@ -160,7 +183,7 @@ class DeviceRun(object):
         if getattr(self, 'handle', None) is not None and self.handle.value:
             self.lib.mk_solver_destroy(self.handle)
             self.handle = ctypes.c_void_p()
-        for b in (self.d_rhs, self.d_guess):
+        for b in (self.d_rhs, self.d_guess, getattr(self, 'd_prec', None)):
             if b is not None and not any(b is x for x in getattr(self, '_borrowed', [])):
                 b.free()
 
@@ -182,12 +205,12 @@ def solve_guess_matvec_max(solver, kind, rhs, kwargs, count_guess_product):
     (default 2n), result attributes `converged, nMatvec, bestSolution, x, residNorm, residNorm0`
     (reference bicgstab.py:148-151, cgs.py:120-123, tfqmr.py:156-159).  These solvers keep no history."""
     op = solver._device_operator()
-    solver._no_precon(solver.precon)
+    pdiag = solver._device_precon(solver.precon)
     n = rhs.shape[0]
     guess = kwargs.get('guess', None)
     matvec_max = kwargs.get('matvec_max', 2 * n)
-    with DeviceRun(op, kind, rhs, guess, abstol=float(solver.abstol), reltol=float(solver.reltol),
-                   matvec_max=int(matvec_max)) as run:
+    with DeviceRun(op, kind, rhs, guess, precon_diag=pdiag, abstol=float(solver.abstol),
+                   reltol=float(solver.reltol), matvec_max=int(matvec_max)) as run:
         res = run.run()
         x = run.x()
     # the product that forms the initial residual from a guess is counted by the operator, but by the

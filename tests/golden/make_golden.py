@@ -22,6 +22,8 @@ Fixture inventory:
   G7  lls_*.npz             LSQR / LSMR / CRAIG / CRAIG-MR on seeded matrices
   G8  large_summaries.npz   n=1e6 CG summary + integer checksums of the matrices
   G9  api_contract.npz      LinearOperator protocol facts (dtype promotion, counters)
+  G10 precon_jacobi.npz     all six solvers with a DiagonalOperator preconditioner (SURVEY.md 8f-1);
+                            `make_golden.py --only-precon` regenerates just this file
 """
 import contextlib
 import hashlib
@@ -215,6 +217,75 @@ def main():
         path = os.path.join(HERE, name)
         np.savez_compressed(path, **arrs)
         print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+    # ---------------- G10: diagonal (Jacobi) preconditioning -------------- #
+    def g10():
+        from pykrylov.linop import DiagonalOperator
+        out = {}
+        m = 30
+        n = m * m
+        A = canon(poisson2d(m) + sp.diags(np.linspace(0.5, 6.0, n)))       # SPD, varying diagonal
+        d = 1.0 / A.diagonal()
+        out.update(csr_arrays(A, "spd_A_"))
+        out["spd_d"] = d
+        rhs = A @ np.ones(n)
+        out["spd_rhs"] = rhs
+        for gtag in ("zero", "guess"):
+            kw = {} if gtag == "zero" else {"guess": 1.0 + np.arange(n)}
+            with traced(m_cg) as log:
+                s = m_cg.CG(csr_op(A, True), precon=DiagonalOperator(d))
+                s.solve(rhs, **kw)
+            k = "cg_%s_" % gtag
+            out.update({k + "x": s.x, k + "nMatvec": s.nMatvec, k + "residNorm": s.residNorm,
+                        k + "residNorm0": s.residNorm0, k + "residHistory": np.array(s.residHistory),
+                        k + "converged": s.converged, k + "trace": np.array(log)})
+        for shift in (0.0, 1.5):
+            b = rhs - shift * np.ones(n)
+            with traced(m_minres) as log:
+                s = m_minres.Minres(csr_op(A, True))
+                quiet(s.solve, b, precon=DiagonalOperator(d), shift=shift, show=False, check=False, etol=0.0,
+                      rtol=1e-10)
+            k = "minres_s%g_" % shift
+            out.update({k + "rhs": b, k + "x": s.x, k + "istop": s.istop, k + "itn": s.itn,
+                        k + "residHistory": np.array(s.residHistory), k + "rnorm": s.rnorm,
+                        k + "Anorm": s.Anorm, k + "Acond": s.Acond, k + "Arnorm": s.Arnorm,
+                        k + "ynorm": s.ynorm, k + "residNorm0": s.residNorm0, k + "trace": np.array(log)})
+            op = csr_op(A, True)
+            with traced(m_symmlq) as log:
+                s = m_symmlq.Symmlq(op, precon=DiagonalOperator(d))
+                s.matvec = lambda v, op=op: op * v        # symmlq.py:162 calls a missing attribute
+                kw = {} if shift == 0.0 else {"shift": shift}
+                s.solve(b, **kw)
+            k = "symmlq_s%g_" % shift
+            out.update({k + "x": s.x, k + "nMatvec": s.nMatvec, k + "residNorm": s.residNorm,
+                        k + "xNorm": s.xNorm, k + "anorm": s.anorm, k + "acond": s.acond,
+                        k + "trace": np.array(log)})
+        A = random_diagdom(2000, seed=3)
+        n = A.shape[0]
+        d = 1.0 / A.diagonal()
+        rhs = A @ np.ones(n)
+        out.update(csr_arrays(A, "ns_A_"))
+        out["ns_d"] = d
+        out["ns_rhs"] = rhs
+        for sname, mod, cls in (("bicgstab", m_bicgstab, "BiCGSTAB"), ("cgs", m_cgs, "CGS"),
+                                ("tfqmr", m_tfqmr, "TFQMR")):
+            for gtag in ("zero", "guess"):
+                kw = dict(matvec_max=2 * n)
+                if gtag == "guess":
+                    kw["guess"] = 1.0 + np.arange(n)
+                with traced(mod) as log:
+                    s = getattr(mod, cls)(csr_op(A), reltol=1e-8, precon=DiagonalOperator(d))
+                    s.solve(rhs, **kw)
+                k = "%s_%s_" % (sname, gtag)
+                out.update({k + "x": s.x, k + "nMatvec": s.nMatvec, k + "residNorm": s.residNorm,
+                            k + "residNorm0": s.residNorm0, k + "converged": s.converged,
+                            k + "trace": np.array(log)})
+        save("precon_jacobi.npz", **out)
+
+    g10()
+    if "--only-precon" in sys.argv:
+        shutil.rmtree(tmp, ignore_errors=True)
+        return
 
     # ---------------- G1: CG on 1138bus --------------------------------- #
     A = mm_csr("1138bus.mtx")
