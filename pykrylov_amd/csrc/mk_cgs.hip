@@ -6,6 +6,8 @@
 //   D  Az = A z, with r -= alpha Az and the partials <r,r>, <r0,r> in its row epilogue   (:95-105)
 //   F  [loop test on ||r||] beta = rho'/rho ; u = r + beta q ; p = beta (beta p + q) + u  (:101-114)
 // Algorithmic traffic per pass: 2 B_spmv + 8n (r0 in B) + 48n (C) + 24n (r, r0 in D) + 48n (F).
+// With a diagonal preconditioner (cgs.py:79-82,88-91): B reads y = d*p, which F writes beside p, and C forms
+// z = d*(u + q).
 #include "mk_solver.h"
 
 namespace {
@@ -42,6 +44,7 @@ struct OpC {
     int par;
     const double *u, *v;
     double *q, *z, *x;
+    const double *dg;                                                         // preconditioner diagonal or null
     double alpha;
     __device__ bool prologue(double *s4, bool lead) {
         const double sigma = mk_total(part + SLOT_SIGMA * MK_MAXP, np, s4);   // cgs.py:84
@@ -50,23 +53,25 @@ struct OpC {
         return false;
     }
     __device__ bool skip() const { return false; }
-    __device__ void elem(double uv, double vv, double &qv, double &zv, double &xv) {
+    __device__ void elem(double uv, double vv, double dv, double &qv, double &zv, double &xv) {
         qv = uv - alpha * vv;                                                 // cgs.py:86
         zv = uv + qv;                                                         // cgs.py:91
+        if (dg) zv = dv * zv;                                                 // cgs.py:88-89
         xv = xv + alpha * zv;                                                 // cgs.py:94
     }
     __device__ void pair(int64_t i, double *) {
         const double2 uv = mk_ld2(u, i), vv = mk_ld2(v, i);
-        double2 xv = mk_ld2(x, i), qv, zv;
-        elem(uv.x, vv.x, qv.x, zv.x, xv.x);
-        elem(uv.y, vv.y, qv.y, zv.y, xv.y);
+        double2 xv = mk_ld2(x, i), qv, zv, dv{0, 0};
+        if (dg) dv = mk_ld2(dg, i);
+        elem(uv.x, vv.x, dv.x, qv.x, zv.x, xv.x);
+        elem(uv.y, vv.y, dv.y, qv.y, zv.y, xv.y);
         mk_st2(q, i, qv);
         mk_st2(z, i, zv);
         mk_st2(x, i, xv);
     }
     __device__ void one(int64_t i, double *) {
         double qv, zv, xv = x[i];
-        elem(u[i], v[i], qv, zv, xv);
+        elem(u[i], v[i], dg ? dg[i] : 0.0, qv, zv, xv);
         q[i] = qv;
         z[i] = zv;
         x[i] = xv;
@@ -99,6 +104,8 @@ struct OpF {
     int64_t matvec_max, nmv;        // products done so far (host-known)
     const double *r, *q;
     double *u, *p;
+    const double *dg;                                                         // preconditioner diagonal or null
+    double *y;                                                                // y = precon * p (only with dg)
     double beta;
     bool fin;
     __device__ bool prologue(double *s4, bool lead) {
@@ -128,12 +135,20 @@ struct OpF {
         elem(rv.y, qv.y, uv.y, pv.y);
         mk_st2(u, i, uv);
         mk_st2(p, i, pv);
+        if (dg) {                                                             // cgs.py:79-80 (next pass)
+            const double2 dv = mk_ld2(dg, i);
+            double2 yv;
+            yv.x = dv.x * pv.x;
+            yv.y = dv.y * pv.y;
+            mk_st2(y, i, yv);
+        }
     }
     __device__ void one(int64_t i, double *) {
         double uv, pv = p[i];
         elem(r[i], q[i], uv, pv);
         u[i] = uv;
         p[i] = pv;
+        if (dg) y[i] = dg[i] * pv;
     }
 };
 
@@ -157,7 +172,8 @@ __global__ __launch_bounds__(MK_BLOCK) void cgs_init_kernel(const double *part, 
 
 struct CgsSolver : mk_solver {
     double *d_x = nullptr, *d_r0 = nullptr, *d_r = nullptr, *d_u = nullptr, *d_p = nullptr, *d_q = nullptr,
-           *d_v = nullptr, *d_z = nullptr;
+           *d_v = nullptr, *d_z = nullptr, *d_y = nullptr;
+    bool takes_precon() const override { return true; }
 
     int setup(const double *rhs, const double *guess) override {
         if (!d_x) {
@@ -166,6 +182,10 @@ struct CgsSolver : mk_solver {
                 (rc = alloc_vec(&d_u, n)) || (rc = alloc_vec(&d_p, nx)) || (rc = alloc_vec(&d_q, n)) ||
                 (rc = alloc_vec(&d_v, n)) || (rc = alloc_vec(&d_z, nx)))
                 return rc;
+        }
+        if (d_prec && !d_y) {
+            int rc = alloc_vec(&d_y, nx);
+            if (rc) return rc;
         }
         if (guess) {
             MK_HIP(hipMemcpyAsync(d_x, guess, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
@@ -185,21 +205,23 @@ struct CgsSolver : mk_solver {
         mk_launch_stream(this, MkOpCopy{d_r0, d_r}, n);                        // r = r0.copy()    cgs.py:72
         mk_launch_stream(this, MkOpCopy{d_r0, d_u}, n);                        // u = r0           cgs.py:73
         mk_launch_stream(this, MkOpCopy{d_r0, d_p}, n);                        // p = r0.copy()    cgs.py:74
+        if (d_prec) mk_launch_stream(this, MkOpMul{d_prec, d_r0, d_y}, n);     // y = precon * p   cgs.py:79-80
         return MK_OK;
     }
 
     int enqueue_pass() override {
         const int par = (int)(it & 1);
-        int rc = exchange(d_p);
+        double *yin = d_prec ? d_y : d_p;
+        int rc = exchange(yin);
         if (rc != MK_OK) return rc;
-        mk_launch_spmv(this, d_p, BEpi{d_r0, d_v}, true, CountGate{d_status, 2 * it});
+        mk_launch_spmv(this, yin, BEpi{d_r0, d_v}, true, CountGate{d_status, 2 * it});
         if ((rc = allreduce(SLOT_SIGMA, 1)) != MK_OK) return rc;
-        mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_u, d_v, d_q, d_z, d_x, 0.0}, n);
+        mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_u, d_v, d_q, d_z, d_x, d_prec, 0.0}, n);
         if ((rc = exchange(d_z)) != MK_OK) return rc;
         mk_launch_spmv(this, d_z, DEpi{d_scal, d_r0, d_r, 0.0}, true, CountGate{d_status, 2 * it + 1});
         if ((rc = allreduce(SLOT_RR, 2)) != MK_OK) return rc;
         mk_launch_stream(this, OpF{d_part, np_spmv, d_scal, d_status, par, prm.matvec_max, 2 * it + 2, d_r, d_q, d_u,
-                                   d_p, 0.0, false}, n);
+                                   d_p, d_prec, d_y, 0.0, false}, n);
         return MK_OK;
     }
 

@@ -8,6 +8,8 @@
 //   K3  beta ; the whole scalar recurrence (rotations, norm estimates, stopping tests, :250-361) ;
 //       w = (v - oldeps w1 - delta w2) / gamma (written over w1) ; x += phi w                        [:293-297]
 // Algorithmic traffic per pass: B_spmv + 24n (K1: r1 in, v and t out) + 24n (K2) + 48n (K3).
+// With a diagonal preconditioner (minres.py:162-163,249) y = d*r2 is a vector of its own: K2 writes it beside the
+// new r2 and sums <r2, y>; K1 scales and gathers y instead of r2.
 #include "mk_solver.h"
 
 namespace {
@@ -42,7 +44,7 @@ struct GateK1 {      // `while itn < itnlim` (minres.py:220)
 struct EpiK1 {
     static constexpr int NACC = 1, SLOT0 = SLOT_ALFA;
     const double *blk;        // state block of this pass
-    const double *r2, *r1;
+    const double *r2, *r1;    // r2 here is the vector the reference calls y: precon * r2, or r2 itself
     double *v, *t;
     double shift;
     int first;                // itn == 1: no r1 term (minres.py:242)
@@ -70,6 +72,8 @@ struct OpK2 {
     const double *blk;
     const double *r2, *t;
     double *ynew;             // r1's storage: it becomes r2 / y of the next pass
+    const double *dg;         // preconditioner diagonal or null
+    double *yprec;            // y = precon * r2 (only with dg)
     double c;
     __device__ bool prologue(double *s4, bool lead) {
         const double alfa = mk_total(part + SLOT_ALFA * MK_MAXP, np, s4);
@@ -84,13 +88,29 @@ struct OpK2 {
         yv.x = c * rv.x + tv.x;                                               // minres.py:246
         yv.y = c * rv.y + tv.y;
         mk_st2(ynew, i, yv);
-        acc[0] += yv.x * yv.x;                                                // minres.py:251
-        acc[0] += yv.y * yv.y;
+        if (dg) {                                                             // minres.py:249
+            const double2 gv = mk_ld2(dg, i);
+            double2 pv;
+            pv.x = gv.x * yv.x;
+            pv.y = gv.y * yv.y;
+            mk_st2(yprec, i, pv);
+            acc[0] += yv.x * pv.x;                                            // minres.py:251
+            acc[0] += yv.y * pv.y;
+        } else {
+            acc[0] += yv.x * yv.x;                                            // minres.py:251
+            acc[0] += yv.y * yv.y;
+        }
     }
     __device__ void one(int64_t i, double *acc) {
         const double yv = c * r2[i] + t[i];
         ynew[i] = yv;
-        acc[0] += yv * yv;
+        if (dg) {
+            const double pv = dg[i] * yv;
+            yprec[i] = pv;
+            acc[0] += yv * pv;
+        } else {
+            acc[0] += yv * yv;
+        }
     }
 };
 
@@ -275,6 +295,8 @@ struct MinresSolver : mk_solver {
     double *d_x = nullptr, *d_v = nullptr, *d_t = nullptr;
     double *d_r[2] = {nullptr, nullptr};          // r1 / r2 swap roles every pass
     double *d_w[3] = {nullptr, nullptr, nullptr}; // w1, w2, w rotate
+    double *d_y = nullptr;                        // precon * r2 (only with a preconditioner)
+    bool takes_precon() const override { return true; }
 
     int setup(const double *rhs, const double *guess) override {
         if (guess) return mk_fail(MK_ERR_UNSUPPORTED, "MINRES always starts from x = 0 (minres.py:136)");
@@ -288,11 +310,18 @@ struct MinresSolver : mk_solver {
                 (rc = alloc_vec(&d_w[1], n)) || (rc = alloc_vec(&d_w[2], n)))
                 return rc;
         }
+        int rc0 = MK_OK;
         MK_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)n, stream));
         for (int k = 0; k < 3; ++k) MK_HIP(hipMemsetAsync(d_w[k], 0, sizeof(double) * (size_t)n, stream));
         mk_launch_stream(this, MkOpCopy{rhs, d_r[0]}, n);                      // r1 = b            minres.py:161
         mk_launch_stream(this, MkOpCopy{rhs, d_r[1]}, n);                      // y = r2 = b.copy() minres.py:165,208
-        mk_launch_stream(this, MkOpDot<SLOT_YY>{d_r[0], d_r[1]}, n);           // beta1 = <b, y>    minres.py:166
+        if (d_prec) {
+            if (!d_y && (rc0 = alloc_vec(&d_y, nx))) return rc0;
+            mk_launch_stream(this, MkOpMul{d_prec, d_r[0], d_y}, n);           // y = precon * b    minres.py:162-163
+            mk_launch_stream(this, MkOpDot<SLOT_YY>{d_r[0], d_y}, n);          // beta1 = <b, y>    minres.py:166
+        } else {
+            mk_launch_stream(this, MkOpDot<SLOT_YY>{d_r[0], d_r[1]}, n);       // beta1 = <b, y>    minres.py:166
+        }
         int rc = allreduce(SLOT_YY, 1);
         if (rc != MK_OK) return rc;
         hipLaunchKernelGGL(minres_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_stream, d_scal, d_status,
@@ -308,12 +337,13 @@ struct MinresSolver : mk_solver {
         // (w1, w2, w) <- (w2, w, new): the new vector overwrites the storage of the vector that was w1 ... two
         // passes ago; at pass `it` the roles are w1 = d_w[it%3] (dead after this pass), w2, and the current w.
         // The reference reads w1 := old w2 and w2 := old w; see below.
-        int rc = exchange(r2);
+        double *y = d_prec ? d_y : r2;                                         // minres.py:249
+        int rc = exchange(y);
         if (rc != MK_OK) return rc;
-        mk_launch_spmv(this, r2, EpiK1{blk, r2, r1, d_v, d_t, prm.shift, it == 0 ? 1 : 0, 0.0, 0.0}, true,
+        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, it == 0 ? 1 : 0, 0.0, 0.0}, true,
                        GateK1{d_status, it, prm.itnlim});
         if ((rc = allreduce(SLOT_ALFA, 1)) != MK_OK) return rc;
-        mk_launch_stream(this, OpK2{d_part, np_spmv, d_scal, blk, r2, d_t, r1, 0.0}, n);
+        mk_launch_stream(this, OpK2{d_part, np_spmv, d_scal, blk, r2, d_t, r1, d_prec, d_y, 0.0}, n);
         if ((rc = allreduce(SLOT_YY, 1)) != MK_OK) return rc;
         // reference: w1 = w2 ; w2 = w ; w = f(v, w1, w2).  With storage (a, b, c) = (old w1, old w2, old w):
         // new w1 = b, new w2 = c, new w is written into a.

@@ -10,6 +10,9 @@
 //       estimates and stopping tests of the NEXT pass (:237-297), which decide whether to halt   (:313-349)
 // The epilogue (:361-382: transfer to the CG point, step along b, true residual) runs in finish().
 // Algorithmic traffic per pass: B_spmv + 24n (K1) + 24n (K2) + 40n (K3).
+// With a diagonal preconditioner (symmlq.py:131-132,188-189,308-309,372-373) y = d*r2 is a vector of its own,
+// written by the kernels that produce r2 (S4, K2) and read by the scaled gathers (S2, K1); the final step along
+// b uses d*b.
 #include "mk_solver.h"
 
 namespace {
@@ -157,6 +160,8 @@ struct OpS4 {        // y -= (z/s) v ; r2 = y ; <r2, y>
     double *scal;
     const double *t, *v;
     double *r2;
+    const double *dg;         // preconditioner diagonal or null
+    double *yprec;            // y = precon * r2 (only with dg)
     double c;
     __device__ bool prologue(double *s4, bool lead) {
         const double z = mk_total(part + SLOT_C * MK_MAXP, np, s4);
@@ -172,13 +177,29 @@ struct OpS4 {        // y -= (z/s) v ; r2 = y ; <r2, y>
         y.x = tv.x - c * vv.x;
         y.y = tv.y - c * vv.y;
         mk_st2(r2, i, y);
-        acc[0] += y.x * y.x;                                                  // symmlq.py:190
-        acc[0] += y.y * y.y;
+        if (dg) {                                                             // symmlq.py:188-189
+            const double2 gv = mk_ld2(dg, i);
+            double2 pv;
+            pv.x = gv.x * y.x;
+            pv.y = gv.y * y.y;
+            mk_st2(yprec, i, pv);
+            acc[0] += y.x * pv.x;                                             // symmlq.py:190
+            acc[0] += y.y * pv.y;
+        } else {
+            acc[0] += y.x * y.x;                                              // symmlq.py:190
+            acc[0] += y.y * y.y;
+        }
     }
     __device__ void one(int64_t i, double *acc) {
         const double y = t[i] - c * v[i];
         r2[i] = y;
-        acc[0] += y * y;
+        if (dg) {
+            const double pv = dg[i] * y;
+            yprec[i] = pv;
+            acc[0] += y * pv;
+        } else {
+            acc[0] += y * y;
+        }
     }
 };
 
@@ -279,6 +300,8 @@ struct OpK2 {
     const double *blk;
     const double *r2, *t;
     double *ynew;
+    const double *dg;         // preconditioner diagonal or null
+    double *yprec;            // y = precon * r2 (only with dg)
     double c;
     __device__ bool prologue(double *s4, bool lead) {
         const double alfa = mk_total(part + SLOT_A * MK_MAXP, np, s4);
@@ -293,13 +316,29 @@ struct OpK2 {
         y.x = tv.x - c * rv.x;
         y.y = tv.y - c * rv.y;
         mk_st2(ynew, i, y);
-        acc[0] += y.x * y.x;                                                  // symmlq.py:311
-        acc[0] += y.y * y.y;
+        if (dg) {                                                             // symmlq.py:308-309
+            const double2 gv = mk_ld2(dg, i);
+            double2 pv;
+            pv.x = gv.x * y.x;
+            pv.y = gv.y * y.y;
+            mk_st2(yprec, i, pv);
+            acc[0] += y.x * pv.x;                                             // symmlq.py:311
+            acc[0] += y.y * pv.y;
+        } else {
+            acc[0] += y.x * y.x;                                              // symmlq.py:311
+            acc[0] += y.y * y.y;
+        }
     }
     __device__ void one(int64_t i, double *acc) {
         const double y = t[i] - c * r2[i];
         ynew[i] = y;
-        acc[0] += y * y;
+        if (dg) {
+            const double pv = dg[i] * y;
+            yprec[i] = pv;
+            acc[0] += y * pv;
+        } else {
+            acc[0] += y * y;
+        }
     }
 };
 
@@ -413,6 +452,7 @@ struct OpFinX {      // x += zbar w (CG point) ; x += bstep b ; <x,x>        sym
     static constexpr int NACC = 1, SLOT0 = SLOT_A;
     const double *w, *b;
     double *x;
+    const double *dg;         // preconditioner diagonal or null: the step is along precon * b (symmlq.py:372-373)
     double zbar, bstep;
     int cg_point;
     __device__ bool prologue(double *, bool) { return false; }
@@ -422,7 +462,13 @@ struct OpFinX {      // x += zbar w (CG point) ; x += bstep b ; <x,x>        sym
         return xv + bstep * bv;
     }
     __device__ void pair(int64_t i, double *acc) {
-        const double2 wv = mk_ld2(w, i), bv = mk_ld2(b, i);
+        const double2 wv = mk_ld2(w, i);
+        double2 bv = mk_ld2(b, i);
+        if (dg) {
+            const double2 gv = mk_ld2(dg, i);
+            bv.x = gv.x * bv.x;
+            bv.y = gv.y * bv.y;
+        }
         double2 xv = mk_ld2(x, i);
         xv.x = f(xv.x, wv.x, bv.x);
         xv.y = f(xv.y, wv.y, bv.y);
@@ -431,7 +477,7 @@ struct OpFinX {      // x += zbar w (CG point) ; x += bstep b ; <x,x>        sym
         acc[0] += xv.y * xv.y;
     }
     __device__ void one(int64_t i, double *acc) {
-        const double xv = f(x[i], w[i], b[i]);
+        const double xv = f(x[i], w[i], dg ? dg[i] * b[i] : b[i]);
         x[i] = xv;
         acc[0] += xv * xv;
     }
@@ -465,6 +511,8 @@ __global__ __launch_bounds__(MK_BLOCK) void fin_norms_kernel(const double *part,
 struct SymmlqSolver : mk_solver {
     double *d_x = nullptr, *d_w = nullptr, *d_v = nullptr, *d_t = nullptr, *d_b = nullptr, *d_out = nullptr;
     double *d_r[2] = {nullptr, nullptr};
+    double *d_y = nullptr;            // precon * r2 (only with a preconditioner)
+    bool takes_precon() const override { return true; }
     int *d_nohalt = nullptr;
     bool finished = false;
     double rnorm = 0.0, xnorm = 0.0;
@@ -489,16 +537,19 @@ struct SymmlqSolver : mk_solver {
         mk_launch_stream(this, MkOpCopy{rhs, d_b}, n);
         mk_launch_stream(this, MkOpCopy{rhs, d_r[0]}, n);                      // r1 = rhs.copy()   symmlq.py:129
         mk_launch_stream(this, MkOpCopy{rhs, d_r[1]}, n);                      // y = rhs.copy()    symmlq.py:133
-        mk_launch_stream(this, MkOpDot<SLOT_A>{d_r[0], d_r[1]}, n);            // beta1             symmlq.py:134
-        int rc = allreduce(SLOT_A, 1);
-        if (rc != MK_OK) return rc;
-        if ((rc = exchange(d_r[1])) != MK_OK) return rc;
-        mk_launch_spmv(this, d_r[1], EpiS2{d_part, np_stream, d_r[1], d_v, d_t, prm.shift, prm.has_shift, 0.0}, false,
+        int rc;
+        if (d_prec && !d_y && (rc = alloc_vec(&d_y, nx))) return rc;
+        double *y0 = d_prec ? d_y : d_r[1];
+        if (d_prec) mk_launch_stream(this, MkOpMul{d_prec, d_r[0], d_y}, n);   // y = precon * r1   symmlq.py:131-132
+        mk_launch_stream(this, MkOpDot<SLOT_A>{d_r[0], y0}, n);                // beta1             symmlq.py:134
+        if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
+        if ((rc = exchange(y0)) != MK_OK) return rc;
+        mk_launch_spmv(this, y0, EpiS2{d_part, np_stream, y0, d_v, d_t, prm.shift, prm.has_shift, 0.0}, false,
                        GateS2{d_part, np_stream, d_scal, d_status});
         if ((rc = allreduce(SLOT_B, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpS3{d_part, np_spmv, d_scal, d_r[0], d_v, d_t, 0.0}, n);
         if ((rc = allreduce(SLOT_C, 2)) != MK_OK) return rc;
-        mk_launch_stream(this, OpS4{d_part, np_stream, d_scal, d_t, d_v, d_r[1], 0.0}, n);
+        mk_launch_stream(this, OpS4{d_part, np_stream, d_scal, d_t, d_v, d_r[1], d_prec, d_y, 0.0}, n);
         if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
         hipLaunchKernelGGL(symmlq_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_stream, d_scal, d_status,
                            next_halt(), prm.rtol, prm.matvec_max);
@@ -509,12 +560,13 @@ struct SymmlqSolver : mk_solver {
         const int par = (int)(it & 1);
         const double *blk = d_scal + S_BLK + par * BLK;
         double *r1 = d_r[it & 1], *r2 = d_r[(it + 1) & 1];
-        int rc = exchange(r2);
+        double *y = d_prec ? d_y : r2;                                         // symmlq.py:308-309
+        int rc = exchange(y);
         if (rc != MK_OK) return rc;
-        mk_launch_spmv(this, r2, EpiK1{blk, r2, r1, d_v, d_t, prm.shift, prm.has_shift, 0.0, 0.0}, true,
+        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, prm.has_shift, 0.0, 0.0}, true,
                        CountGate{d_status, 1 + it});
         if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
-        mk_launch_stream(this, OpK2{d_part, np_spmv, d_scal, blk, r2, d_t, r1, 0.0}, n);
+        mk_launch_stream(this, OpK2{d_part, np_spmv, d_scal, blk, r2, d_t, r1, d_prec, d_y, 0.0}, n);
         if ((rc = allreduce(SLOT_B, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpK3{d_part, np_stream, d_scal, d_status, par, 2 + it, prm.matvec_max, prm.rtol, d_v,
                                     d_w, d_x, 0, 0, 0, 0, false}, n);
@@ -539,7 +591,7 @@ struct SymmlqSolver : mk_solver {
             if (beta1 != 0) bstep = bstep / beta1;                            // symmlq.py:369
             const MkHalt nh{d_nohalt, 0};
             hipLaunchKernelGGL(mk_stream_kernel<OpFinX>, dim3(mk_grid_stream(n)), dim3(MK_BLOCK), 0, stream,
-                               OpFinX{d_w, d_b, d_x, zbar, bstep, cg_point}, n, nh, d_part);
+                               OpFinX{d_w, d_b, d_x, d_prec, zbar, bstep, cg_point}, n, nh, d_part);
             if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
             if ((rc = exchange(d_x)) != MK_OK) return rc;
             hipLaunchKernelGGL((mk_spmv_kernel<EpiFinR, MkNoGate>), dim3(mk_grid_spmv_for(A)), dim3(MK_BLOCK), 0,

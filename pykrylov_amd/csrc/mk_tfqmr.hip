@@ -6,6 +6,8 @@
 //   P4  u = A y, row epilogue: w -= alpha u ; d = (..) d + y ; partials <w,w>, <r0,w>           (:114-118,:128)
 //   P5  theta, c, tau, eta ; x += eta d ; [exit test] ; beta ; y = beta y + w ; v = beta (beta v + u)   (:118-139)
 //   P6  u = A y, row epilogue: v += u ; partial <r0, v> (the next pass's sigma)                  (:147-150, :88)
+// With a diagonal preconditioner (tfqmr.py:77-80,109-112,142-145) z = d*y is a vector of its own: P3 and P5
+// write it beside y; the products and the `d += z` updates read it.
 // Algorithmic traffic per pass: 2 B_spmv + 56n (P2) + 48n (P3) + 48n (P4 epilogue) + 72n (P5) + 32n (P6 epilogue).
 #include "mk_solver.h"
 
@@ -84,6 +86,8 @@ struct OpP3 {
     double k;
     const double *d, *v;
     double *x, *y;
+    const double *dg;                                                         // preconditioner diagonal or null
+    double *z;                                                                // z = precon * y (only with dg)
     double alpha, eta;
     bool fin;
     __device__ bool prologue(double *s4, bool lead) {
@@ -114,11 +118,21 @@ struct OpP3 {
             yv.x = yv.x - alpha * vv.x;                                       // tfqmr.py:107
             yv.y = yv.y - alpha * vv.y;
             mk_st2(y, i, yv);
+            if (dg) {                                                         // tfqmr.py:109-110
+                const double2 gv = mk_ld2(dg, i);
+                yv.x = gv.x * yv.x;
+                yv.y = gv.y * yv.y;
+                mk_st2(z, i, yv);
+            }
         }
     }
     __device__ void one(int64_t i, double *) {
         x[i] = x[i] + eta * d[i];
-        if (!fin) y[i] = y[i] - alpha * v[i];
+        if (!fin) {
+            const double yv = y[i] - alpha * v[i];
+            y[i] = yv;
+            if (dg) z[i] = dg[i] * yv;
+        }
     }
 };
 
@@ -156,6 +170,8 @@ struct OpP5 {
     double k;
     const double *d, *w, *u;
     double *x, *y, *v;
+    const double *dg;                                                         // preconditioner diagonal or null
+    double *z;                                                                // z = precon * y (only with dg)
     double eta, beta;
     bool fin;
     __device__ bool prologue(double *s4, bool lead) {
@@ -201,6 +217,12 @@ struct OpP5 {
         if (!fin) {
             mk_st2(y, i, yv);
             mk_st2(v, i, vv);
+            if (dg) {                                                         // tfqmr.py:142-143
+                const double2 gv = mk_ld2(dg, i);
+                yv.x = gv.x * yv.x;
+                yv.y = gv.y * yv.y;
+                mk_st2(z, i, yv);
+            }
         }
     }
     __device__ void one(int64_t i, double *) {
@@ -216,6 +238,7 @@ struct OpP5 {
         if (!fin) {
             y[i] = yv;
             v[i] = vv;
+            if (dg) z[i] = dg[i] * yv;
         }
     }
 };
@@ -258,7 +281,9 @@ __global__ __launch_bounds__(MK_BLOCK) void tfqmr_init_kernel(const double *part
 
 struct TfqmrSolver : mk_solver {
     double *d_x = nullptr, *d_r0 = nullptr, *d_y = nullptr, *d_w = nullptr, *d_d = nullptr, *d_u = nullptr,
-           *d_v = nullptr;
+           *d_v = nullptr, *d_z = nullptr;
+    bool takes_precon() const override { return true; }
+    double *zsrc() const { return d_prec ? d_z : d_y; }                        // what the products and `d += z` read
 
     int setup(const double *rhs, const double *guess) override {
         if (!d_x) {
@@ -267,6 +292,10 @@ struct TfqmrSolver : mk_solver {
                 (rc = alloc_vec(&d_w, n)) || (rc = alloc_vec(&d_d, n)) || (rc = alloc_vec(&d_u, n)) ||
                 (rc = alloc_vec(&d_v, n)))
                 return rc;
+        }
+        if (d_prec && !d_z) {
+            int rc = alloc_vec(&d_z, nx);
+            if (rc) return rc;
         }
         if (guess) {
             MK_HIP(hipMemcpyAsync(d_x, guess, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
@@ -286,9 +315,10 @@ struct TfqmrSolver : mk_solver {
         mk_launch_stream(this, MkOpCopy{d_r0, d_y}, n);                        // y = r0.copy()    tfqmr.py:70
         mk_launch_stream(this, MkOpCopy{d_r0, d_w}, n);                        // w = r0.copy()    tfqmr.py:71
         MK_HIP(hipMemsetAsync(d_d, 0, sizeof(double) * (size_t)n, stream));    // d = 0            tfqmr.py:72
-        if ((rc = exchange(d_y)) != MK_OK) return rc;
-        // u = A y ; v = u.copy() ; first sigma                               tfqmr.py:82-83
-        mk_launch_spmv(this, d_y, EpiP6<true>{d_r0, d_u, d_v}, false, CountGate{d_status, 0});
+        if (d_prec) mk_launch_stream(this, MkOpMul{d_prec, d_r0, d_z}, n);     // z = precon * y   tfqmr.py:77-78
+        if ((rc = exchange(zsrc())) != MK_OK) return rc;
+        // u = A z ; v = u.copy() ; first sigma                               tfqmr.py:82-83
+        mk_launch_spmv(this, zsrc(), EpiP6<true>{d_r0, d_u, d_v}, false, CountGate{d_status, 0});
         return allreduce(SLOT_SIGMA, 1);
     }
 
@@ -297,17 +327,18 @@ struct TfqmrSolver : mk_solver {
         const double k = (double)(it + 1);
         const int64_t nmv = 1 + 2 * it;          // products done when the pass starts
         int rc;
-        mk_launch_stream(this, OpP2{d_part, np_spmv, d_scal, par, d_u, d_y, d_w, d_d, 0.0, 0.0}, n);
+        double *zs = zsrc();
+        mk_launch_stream(this, OpP2{d_part, np_spmv, d_scal, par, d_u, zs, d_w, d_d, 0.0, 0.0}, n);
         if ((rc = allreduce(SLOT_WW, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpP3{d_part, np_stream, d_scal, d_status, prm.matvec_max, nmv, k, d_d, d_v, d_x, d_y,
-                                    0.0, 0.0, false}, n);
-        if ((rc = exchange(d_y)) != MK_OK) return rc;
-        mk_launch_spmv(this, d_y, EpiP4{d_scal, d_y, d_r0, d_u, d_w, d_d, 0.0, 0.0}, true, CountGate{d_status, nmv});
+                                    d_prec, d_z, 0.0, 0.0, false}, n);
+        if ((rc = exchange(zs)) != MK_OK) return rc;
+        mk_launch_spmv(this, zs, EpiP4{d_scal, zs, d_r0, d_u, d_w, d_d, 0.0, 0.0}, true, CountGate{d_status, nmv});
         if ((rc = allreduce(SLOT_WW, 2)) != MK_OK) return rc;
         mk_launch_stream(this, OpP5{d_part, np_spmv, d_scal, d_status, par, prm.matvec_max, nmv + 1, k, d_d, d_w, d_u,
-                                    d_x, d_y, d_v, 0.0, 0.0, false}, n);
-        if ((rc = exchange(d_y)) != MK_OK) return rc;
-        mk_launch_spmv(this, d_y, EpiP6<false>{d_r0, d_u, d_v}, true, CountGate{d_status, nmv + 1});
+                                    d_x, d_y, d_v, d_prec, d_z, 0.0, 0.0, false}, n);
+        if ((rc = exchange(zs)) != MK_OK) return rc;
+        mk_launch_spmv(this, zs, EpiP6<false>{d_r0, d_u, d_v}, true, CountGate{d_status, nmv + 1});
         return allreduce(SLOT_SIGMA, 1);
     }
 

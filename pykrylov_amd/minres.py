@@ -58,7 +58,7 @@ class Minres(KrylovMethod):
         """Solve with right-hand side `b`.
 
         :keywords:
-            :precon:  preconditioner (not available on the device path yet)
+            :precon:  preconditioner M^-1 given as a diagonal operator (`precon.diag`); must be positive definite
             :shift:   solve (A - shift I) x = b (default 0)
             :show:    print a summary (default True, as in the reference)
             :check:   verify symmetry of A first (default True; 20 extra products on the operator)
@@ -70,8 +70,8 @@ class Minres(KrylovMethod):
         """
         A = self._device_operator()
         n = b.shape[0]
-        precon = kwargs.get('precon', None)
-        self._no_precon(precon)
+        precon = kwargs.get('precon', None)                   # minres.py:121: a `solve` keyword, not a ctor one
+        pdiag = self._device_precon(precon)
         shift = kwargs.get('shift', 0.0)
         show = kwargs.get('show', True)
         check = kwargs.get('check', True)
@@ -93,7 +93,8 @@ class Minres(KrylovMethod):
             print('itnlim =  %3d     rtol   =  %11.2e\n' % (itnlim, rtol))
 
         symmetric_ok = True
-        with DeviceRun(A, _lib.MK_MINRES, b, None, shift=float(shift), itnlim=int(itnlim), rtol=float(rtol),
+        # (the reference also runs check_symmetric on the preconditioner, minres.py:192-196; a diagonal one passes)
+        with DeviceRun(A, _lib.MK_MINRES, b, None, precon_diag=pdiag, shift=float(shift), itnlim=int(itnlim), rtol=float(rtol),
                        etol=float(etol), window=int(window)) as run:
             run.setup()
             res = run.finish()

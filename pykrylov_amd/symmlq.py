@@ -41,7 +41,7 @@ class Symmlq(KrylovMethod):
             :store_iterates: keep every iterate (LQ points) in `self.iterates` (default False)
         """
         op = self._device_operator()
-        self._no_precon(self.precon)
+        pdiag = self._device_precon(self.precon)      # ctor keyword (symmlq.py:60); diagonal operators only
         n = rhs.shape[0]
         matvec_max = kwargs.get('matvec_max', 2 * n + 2)
         rtol = kwargs.get('rtol', 1.0e-9)
@@ -53,7 +53,9 @@ class Symmlq(KrylovMethod):
         eps = machine_epsilon()
 
         not_symmetric = False
-        with DeviceRun(op, _lib.MK_SYMMLQ, rhs, None, matvec_max=int(matvec_max), rtol=float(rtol),
+        # (with check=True the reference also tests the preconditioner for symmetry, symmlq.py:138-146; a diagonal
+        # one always passes)
+        with DeviceRun(op, _lib.MK_SYMMLQ, rhs, None, precon_diag=pdiag, matvec_max=int(matvec_max), rtol=float(rtol),
                        has_shift=int(shift is not None), shift=float(shift or 0.0)) as run:
             run.setup()
             lib = run.lib

@@ -84,7 +84,7 @@ def solver_class(name):
     return {"bicgstab": pykrylov_amd.BiCGSTAB, "cgs": pykrylov_amd.CGS, "tfqmr": pykrylov_amd.TFQMR}[name]
 
 
-NONSYM_READY = ["bicgstab"]
+NONSYM_READY = ["bicgstab", "cgs", "tfqmr"]
 
 
 @pytest.mark.parametrize("solver", NONSYM_READY)
@@ -112,3 +112,61 @@ def test_nonsymmetric_diagonal_precon(golden, solver, gtag):
     assert s.nMatvec == ref["nMatvec"]
     assert np.array_equal(s.x, ref["x"])
     assert s.residNorm == ref["residNorm"] and s.residNorm0 == ref["residNorm0"] and s.converged == ref["converged"]
+
+
+# ------------------------------------------------------------------ MINRES / SYMMLQ
+# shift = 1.5 makes the operator indefinite: after the Lanczos vectors lose orthogonality the recurrence is chaotic
+# in the summation order (see test_gpu_minres.py), so against the reference's np.dot-order run only the head of
+# the trajectory, the iteration count to a few, convergence and the solution are comparable; the bit-level check
+# against the oracle in the device's order has no such limit.
+@pytest.mark.parametrize("shift", [0.0, 1.5])
+def test_minres_diagonal_precon(golden, shift, monkeypatch):
+    from pykrylov_amd import Minres, DiagonalOperator
+    d = golden("precon_jacobi.npz")
+    A = golden_csr(d, "spd_A_")
+    n = A.shape[0]
+    dg = d["spd_d"]
+    k = "minres_s%g_" % shift
+    s = Minres(op_from(A, symmetric=True))
+    s.solve(d[k + "rhs"], precon=DiagonalOperator(dg), shift=shift, show=False, check=False, etol=0.0, rtol=1e-10)
+    definite = shift == 0.0
+    assert s.istop == int(d[k + "istop"]) and s.converged
+    assert abs(s.itn - int(d[k + "itn"])) <= (0 if definite else 2)
+    href = d[k + "residHistory"]
+    head = len(href) if definite else 30
+    assert rel_hist_err(s.residHistory[:head], href[:head]) <= 1e-11
+    assert relerr(s.x, d[k + "x"]) <= (1e-11 if definite else 1e-6)
+    for name in ("Anorm", "ynorm", "residNorm0"):
+        assert abs(getattr(s, name) - float(d[k + name])) <= (1e-10 if definite else 1e-2) * abs(float(d[k + name])), name
+    monkeypatch.setattr(kr, "_sq", lambda a: a * a)          # the reference's pow(x, 2) is not always x*x
+    ref = kr.minres(A, d[k + "rhs"], precon=lambda v: dg * v, shift=shift, check=False, etol=0.0, rtol=1e-10,
+                    red=dots_for("minres", n))
+    assert (s.istop, s.itn) == (ref["istop"], ref["itn"])
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"])
+    assert np.array_equal(s.x, ref["x"])
+    for name in ("Anorm", "Acond", "Arnorm", "ynorm", "rnorm"):
+        assert getattr(s, name) == ref[name], name
+
+
+@pytest.mark.parametrize("shift", [0.0, 1.5])
+def test_symmlq_diagonal_precon(golden, shift, monkeypatch):
+    from pykrylov_amd import Symmlq, DiagonalOperator
+    d = golden("precon_jacobi.npz")
+    A = golden_csr(d, "spd_A_")
+    n = A.shape[0]
+    dg = d["spd_d"]
+    k = "symmlq_s%g_" % shift
+    rhs = d["minres_s%g_rhs" % shift]
+    s = Symmlq(op_from(A, symmetric=True), precon=DiagonalOperator(dg))
+    s.solve(rhs, **({} if shift == 0.0 else {"shift": shift}))
+    definite = shift == 0.0
+    assert abs(s.nMatvec - int(d[k + "nMatvec"])) <= (0 if definite else 2)
+    assert relerr(s.x, d[k + "x"]) <= (1e-11 if definite else 1e-5)
+    assert abs(s.anorm - float(d[k + "anorm"])) <= (1e-10 if definite else 1e-2) * float(d[k + "anorm"])
+    assert abs(s.xNorm - float(d[k + "xNorm"])) <= (1e-10 if definite else 1e-5) * float(d[k + "xNorm"])
+    monkeypatch.setattr(kr, "_sq", lambda a: a * a)
+    ref = kr.symmlq(A, rhs, precon=lambda v: dg * v, shift=(shift or None), red=dots_for("symmlq", n))
+    assert s.nMatvec == ref["nMatvec"]
+    assert np.array_equal(s.x, ref["x"])
+    for name in ("residNorm", "xNorm", "anorm", "acond"):
+        assert getattr(s, name) == ref[name], name
