@@ -85,6 +85,61 @@ def cpu_baseline(name, seconds_budget=20.0):
             "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS", "default")}
 
 
+def other_configs(lib, passes=400, warm=20):
+    """BASELINE configs[2] and configs[3] on one GPU (`--all-configs`): loop passes per second with the
+    tolerances at zero so that exactly `passes` passes run, plus the iteration roofline with the
+    reference's op count."""
+    from pykrylov_amd import _lib, gallery
+    from pykrylov_amd.generic import DeviceRun
+    out = {}
+
+    def timed(op, kind, rhs, **params):
+        run = DeviceRun(op, kind, rhs, None, **params)
+        run.setup()
+        assert run.iterate(warm) == warm
+        _lib.check(lib.mk_sync())
+        t0 = time.perf_counter()
+        done = run.iterate(passes)
+        _lib.check(lib.mk_sync())
+        dt = time.perf_counter() - t0
+        assert done == passes, (done, passes)
+        run.close()
+        return dt
+
+    # configs[2]: BiCGSTAB, random nonsymmetric diagonally dominant CSR, n = 1e6, ~5 nnz/row.  With threshold 0
+    # the residual reaches 0 after ~25 passes and the recurrence then divides 0 by 0 (as the reference would):
+    # the kernels move the same bytes on NaNs, which is what is being timed.
+    n = 1000000
+    op = gallery.random_diagdom(n, seed=1)
+    ones = _lib.DeviceArray.from_numpy(np.ones(n))
+    rhs = _lib.DeviceArray(n)
+    op.spmv_device(ones.ptr, rhs.ptr)
+    dt = timed(op, _lib.MK_BICGSTAB, rhs, abstol=0.0, reltol=0.0, matvec_max=1 << 60)
+    b_iter = 2 * spmv_bytes(n, n, op.nnz) + 224 * n                        # SURVEY.md 8d
+    out["bicgstab-rand1m@1"] = {"value": passes / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / passes,
+                                "rows": n, "nnz": int(op.nnz), "matvecs_per_iteration": 2,
+                                "iteration_roofline": {"algorithmic_bytes_per_iter": b_iter,
+                                                       "frac_of_hbm": b_iter * passes / dt / 1e9 / HBM_PEAK_GBS}}
+    op.free()
+    # configs[3]: MINRES, 2-D Laplacian m = 2000 (n = 4e6) with the keyword shift 1.5 (symmetric indefinite)
+    m = 2000
+    n = m * m
+    op = gallery.poisson2d(m)
+    ones = _lib.DeviceArray.from_numpy(np.ones(n))
+    rhs_h = np.empty(n)
+    rhs = _lib.DeviceArray(n)
+    op.spmv_device(ones.ptr, rhs.ptr)
+    rhs_h[:] = rhs.to_numpy() - 1.5
+    dt = timed(op, _lib.MK_MINRES, rhs_h, shift=1.5, itnlim=1 << 60, rtol=0.0, etol=0.0, window=5)
+    b_iter = spmv_bytes(n, n, op.nnz) + 176 * n                            # SURVEY.md 8d (kwarg shift)
+    out["minres-shifted2d-2000@1"] = {"value": passes / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / passes,
+                                      "rows": n, "nnz": int(op.nnz), "shift": 1.5,
+                                      "iteration_roofline": {"algorithmic_bytes_per_iter": b_iter,
+                                                             "frac_of_hbm": b_iter * passes / dt / 1e9 / HBM_PEAK_GBS}}
+    op.free()
+    return out
+
+
 def main():
     global ARGS
     ap = argparse.ArgumentParser()
@@ -100,6 +155,8 @@ def main():
                     help="back-to-back launches of the fused SpMV kernel timed by one HIP event pair")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="also time BASELINE configs[2] (BiCGSTAB, random n=1e6) and configs[3] (MINRES, n=4e6)")
     ARGS = ap.parse_args()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,6 +282,8 @@ def main():
         line["extra"] = {"poisson2d-1000@1": {"value": e_its, "unit": "iterations/s", "steps": 2000, "warmup": 200,
                                               "ms_per_step": 1e3 * ex["elapsed"] / 2000, "roofline": e_roof,
                                               "iteration_roofline": e_it}}
+    if world_size == 1 and ARGS.all_configs:
+        line.setdefault("extra", {}).update(other_configs(lib))
     if rank == 0:
         print(json.dumps(line), flush=True)
     if td is not None:
