@@ -79,6 +79,24 @@ int mk_csr_transpose(const mk_csr *A, mk_csr **out);
 int mk_csr_poisson2d(int64_t m, int64_t row_begin, int64_t row_end, mk_csr **out);
 int mk_csr_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t row_begin, int64_t row_end, mk_csr **out);
 
+/* Operator algebra that stays on the device (linop.py:307-330 `alpha * op`, :375-398 `op + other`, :403-426
+ * `op - other`, :400-401 `-op`, with `other` a DiagonalOperator (:473-516), an IdentityOperator (:455-470) or a scalar
+ * multiple of one).  The reference evaluates such operators as `alpha * (op * x)`, `(op * x) + (other * x)`, ... one
+ * NumPy expression per node; mk_csr_compose makes an operator that shares A's arrays (A must outlive it) and applies
+ * the same expressions, in the same order, to every row sum before anything else sees it:
+ *     t = (A x)_r ; for each step:   term = x_r ; if diag: term = diag[r] * term ; if has_scale: term = scale * term
+ *        MK_ROW_SCALE  t = scale * t      MK_ROW_ADD  t = t + term      MK_ROW_SUB  t = t - term      MK_ROW_RSUB  t = term - t
+ * Steps of A itself (if it is a composed operator) run first.  Square matrices only when a step uses x_r.
+ * Every product of the library (mk_spmv and all solver kernels) honours the steps. */
+enum { MK_ROW_SCALE = 1, MK_ROW_ADD = 2, MK_ROW_SUB = 3, MK_ROW_RSUB = 4, MK_ROWPROG_MAX = 4 };
+typedef struct mk_rowop {
+    int32_t code;         /* MK_ROW_* */
+    int32_t has_scale;    /* term is multiplied by `scale` (always 1 for MK_ROW_SCALE) */
+    double scale;
+    const double *diag;   /* device array, nrows entries, borrowed; NULL: identity */
+} mk_rowop;
+int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops, mk_csr **out);
+
 /* y = A x   (K1; `self.op * p`, pykrylov/cg/cg.py:115 and every other solver).
  * Per row the products are added left to right with one rounding per multiply and per
  * add, so the result is bit-identical to a scalar CSR loop. */

@@ -199,3 +199,17 @@ def read_matrix_market(path):
         rows, cols, vals = (np.concatenate([rows, cols[off]]), np.concatenate([cols, rows[off]]),
                             np.concatenate([vals, vals[off]]))
     return from_coo(rows, cols, vals, (m, n))
+
+
+class Composed(object):
+    """The reference's operator algebra on top of a RefCsr, restated as closures: `fn(y, x)` receives the product
+    y = A x and the operand x and returns what the reference's composite operator returns (linop.py:307-330
+    `alpha * (op * x)`, :375-426 `(op * x) +/- (other * x)`).  Test infrastructure only."""
+
+    def __init__(self, A, fn):
+        self.A, self.fn, self.shape = A, fn, A.shape
+
+    def matvec(self, x):
+        return self.fn(self.A.matvec(x), x)
+
+    __call__ = matvec

@@ -26,6 +26,15 @@ class MkParams(ctypes.Structure):
                 ("damp", c_f64), ("atol", c_f64), ("btol", c_f64), ("conlim", c_f64)]
 
 
+class MkRowOp(ctypes.Structure):
+    "mk_rowop (include/mikrylov.h): one step of a composed operator."
+    _fields_ = [("code", ctypes.c_int32), ("has_scale", ctypes.c_int32), ("scale", ctypes.c_double),
+                ("diag", ctypes.c_void_p)]
+
+
+MK_ROW_SCALE, MK_ROW_ADD, MK_ROW_SUB, MK_ROW_RSUB, MK_ROWPROG_MAX = 1, 2, 3, 4, 4
+
+
 class MkResult(ctypes.Structure):
     _fields_ = [("struct_size", c_i32), ("halted", c_i32), ("nMatvec", c_i64), ("itn", c_i64),
                 ("hist_len", c_i64), ("converged", c_i32), ("definite", c_i32), ("istop", c_i32),
@@ -54,6 +63,7 @@ PROTOTYPES = {
     "mk_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),
     "mk_csr_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "mk_csr_transpose": (ctypes.c_int, [c_vp, P(c_vp)]),
+    "mk_csr_compose": (ctypes.c_int, [c_vp, ctypes.c_int32, P(MkRowOp), P(c_vp)]),
     "mk_csr_poisson2d": (ctypes.c_int, [c_i64, c_i64, c_i64, P(c_vp)]),
     "mk_csr_poisson3d": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, P(c_vp)]),
     "mk_spmv": (ctypes.c_int, [c_vp, c_vp, c_vp]),

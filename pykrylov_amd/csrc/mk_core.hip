@@ -198,8 +198,31 @@ extern "C" int mk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const in
     return MK_OK;
 }
 
+extern "C" int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr && out != nullptr && nops >= 0 && (nops == 0 || ops != nullptr));
+    if (A->nops + nops > MK_ROWPROG_MAX)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_compose: at most %d steps per operator", (int)MK_ROWPROG_MAX);
+    if (A->ex.mode >= 0)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_compose: compose before the operator is partitioned");
+    for (int k = 0; k < nops; ++k) {
+        MK_ARG(ops[k].code >= MK_ROW_SCALE && ops[k].code <= MK_ROW_RSUB);
+        if (ops[k].code != MK_ROW_SCALE && A->nrows != A->ncols)
+            return mk_fail(MK_ERR_ARG, "mk_csr_compose: adding a diagonal operator needs a square matrix");
+    }
+    mk_csr *B = new mk_csr(*A);
+    B->alias = true;
+    for (int k = 0; k < nops; ++k) B->ops[B->nops++] = ops[k];
+    *out = B;
+    return MK_OK;
+}
+
 extern "C" int mk_csr_destroy(mk_csr *A) {
     if (!A) return MK_OK;
+    if (A->alias) {
+        delete A;
+        return MK_OK;
+    }
     if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
     hipFree(A->d_indptr);
     hipFree(A->d_indices);
@@ -242,8 +265,7 @@ extern "C" int mk_spmv(const mk_csr *A, const double *x, double *y) {
     MK_ARG(A && x && y);
     if (A->nrows == 0) return MK_OK;
     MkPlainEpi epi{y};
-    hipLaunchKernelGGL((mk_spmv_kernel<MkPlainEpi, MkNoGate>), dim3(mk_grid_spmv_for(A)), dim3(MK_BLOCK), 0,
-                       mk_ctx().stream, mk_view(A), x, epi, MkNoGate(), never_halt(), mk_ctx().d_scratch);
+    mk_spmv_launch(A, mk_grid_spmv_for(A), mk_ctx().stream, x, epi, MkNoGate(), never_halt(), mk_ctx().d_scratch);
     MK_HIP(hipGetLastError());
     return MK_OK;
 }
@@ -493,6 +515,9 @@ extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
     MK_HIP(hipGetLastError());
     MK_HIP(hipStreamSynchronize(st));
     MK_HIP(hipFree(cursor));
+    // (alpha A + D)^T = alpha A^T + D: the row program of a composed operator carries over unchanged
+    B->nops = A->nops;
+    for (int k = 0; k < A->nops; ++k) B->ops[k] = A->ops[k];
     *out = B;
     return MK_OK;
 }

@@ -26,6 +26,8 @@ struct MkCsrView {
     int64_t nrows;
     int64_t ntiles;
     int xcd_chunks;          // 1: each XCD sweeps its own contiguous eighth of the tiles (cache-resident problems)
+    int nops;                // row program of a composed operator (mk_csr_compose); 0 for a plain matrix
+    mk_rowop ops[MK_ROWPROG_MAX];
 };
 
 // Working sets that fit the 256 MiB Infinity Cache profit from XCD-local tile ranges (every x line is then
@@ -48,13 +50,46 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
 }
 
 static inline MkCsrView mk_view(const mk_csr *A) {
-    return MkCsrView{A->d_indptr, A->d_indices, A->d_data, A->nrows, A->ntiles, mk_xcd_chunks(A)};
+    MkCsrView v{A->d_indptr, A->d_indices, A->d_data, A->nrows, A->ntiles, mk_xcd_chunks(A), A->nops, {}};
+    for (int k = 0; k < A->nops; ++k) v.ops[k] = A->ops[k];
+    return v;
 }
 
 #ifdef __HIPCC__
 
 typedef double mk_d2 __attribute__((ext_vector_type(2)));
 typedef int mk_i2 __attribute__((ext_vector_type(2)));
+
+// Composed operators (mk_csr_compose): the reference evaluates `alpha * op`, `op + D`, `op - D` as one NumPy
+// expression per node on the product vector (linop.py:307-330, :375-426); the same expressions, in the same order,
+// are applied here to the finished row sum.  x_r is the entry of the vector the product is applied to (after the
+// epilogue's on-the-fly scaling, e.g. MINRES' v = y / beta).
+template <class Epi>
+__device__ __forceinline__ double mk_rowprog(const MkCsrView &A, double t, const double *__restrict__ x, int64_t r,
+                                             const Epi &epi) {
+    double xr = 0.0;
+    bool have_x = false;
+#pragma unroll
+    for (int k = 0; k < MK_ROWPROG_MAX; ++k) {
+        if (k >= A.nops) break;
+        const mk_rowop op = A.ops[k];
+        if (op.code == MK_ROW_SCALE) {
+            t = op.scale * t;
+            continue;
+        }
+        if (!have_x) {
+            xr = epi.xin(x[r]);
+            have_x = true;
+        }
+        double term = xr;
+        if (op.diag) term = op.diag[r] * term;
+        if (op.has_scale) term = op.scale * term;
+        if (op.code == MK_ROW_ADD) t = t + term;
+        else if (op.code == MK_ROW_SUB) t = t - term;
+        else t = term - t;
+    }
+    return t;
+}
 
 // ---------------------------------------------------------------------------------------
 // CSR-stream SpMV.  A workgroup owns 256 consecutive rows per tile.  Pass 1: all lanes walk
@@ -76,7 +111,7 @@ struct MkHasPre : std::false_type {};
 template <class Epi>
 struct MkHasPre<Epi, std::void_t<decltype(std::declval<Epi &>().pre((int64_t)0))>> : std::true_type {};
 
-template <class Epi, int NACC>
+template <bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
                                               double *prod, double (&acc)[NACC]) {
     constexpr int PAIRS = MK_SPMV_TILE / (2 * MK_BLOCK);   // 4 pairs of nonzeros per lane per chunk
@@ -174,6 +209,9 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             __syncthreads();
         }
         if (first) load_meta(tile + per_xcd, nxt);           // empty tile: still advance the prefetch
+        if constexpr (PROG) {                                // composed operators only (separate instantiation)
+            if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
+        }
         if (r < rend) epi.row(r, sum, acc);
         cur = nxt;
     }
@@ -186,7 +224,7 @@ struct MkNoGate {
     __device__ bool open(double *, bool, bool *) { return true; }
 };
 
-template <class Epi, class Gate>
+template <class Epi, class Gate, bool PROG>
 __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     __shared__ double prod[MK_SPMV_TILE];
@@ -205,12 +243,24 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const do
     double acc[Epi::NACC > 0 ? Epi::NACC : 1];
 #pragma unroll
     for (int d = 0; d < (Epi::NACC > 0 ? Epi::NACC : 1); ++d) acc[d] = 0.0;
-    mk_spmv_tiles(A, x, epi, prod, acc);
+    mk_spmv_tiles<PROG>(A, x, epi, prod, acc);
 #pragma unroll
     for (int d = 0; d < Epi::NACC; ++d) {
         const double tot = mk_block_sum(acc[d], s4);
         if (threadIdx.x == 0) partials[(Epi::SLOT0 + d) * MK_MAXP + blockIdx.x] = tot;
     }
+}
+
+// Launch the instantiation that matches the operator: plain matrices never pay for the row program.
+template <class Epi, class Gate>
+static inline void mk_spmv_launch(const mk_csr *A, int grid, hipStream_t st, const double *x, const Epi &epi,
+                                  const Gate &gate, MkHalt halt, double *partials) {
+    if (A->nops > 0)
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, true>), dim3(grid), dim3(MK_BLOCK), 0, st, mk_view(A), x, epi,
+                           gate, halt, partials);
+    else
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, false>), dim3(grid), dim3(MK_BLOCK), 0, st, mk_view(A), x, epi,
+                           gate, halt, partials);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -81,6 +81,9 @@ struct mk_csr {
     double *d_data = nullptr;
     int64_t ntiles = 0;            // ceil(nrows / MK_ROWS_PER_TILE)
     MkExchange ex;
+    bool alias = false;            // composed operator: the arrays belong to another mk_csr
+    int32_t nops = 0;              // row program (mk_csr_compose)
+    mk_rowop ops[MK_ROWPROG_MAX] = {};
     // length of the vector an SpMV reads (ncols, or n_local + n_halo with a halo plan)
     int64_t x_len() const { return ex.mode == 0 ? ex.n_local + ex.n_halo : ncols; }
 };

@@ -200,8 +200,7 @@ static inline int mk_launch_stream(mk_solver *s, const Op &op, int64_t n) {
 template <class Epi, class Gate = MkNoGate>
 static inline int mk_launch_spmv_on(mk_solver *s, const mk_csr *M, const double *x, const Epi &epi,
                                     const Gate &gate = Gate()) {
-    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate>), dim3(mk_grid_spmv_for(M)), dim3(MK_BLOCK), 0, s->stream,
-                       mk_view(M), x, epi, gate, s->next_halt(), s->d_part);
+    mk_spmv_launch(M, mk_grid_spmv_for(M), s->stream, x, epi, gate, s->next_halt(), s->d_part);
     return MK_OK;
 }
 
@@ -210,8 +209,7 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
                                  const Gate &gate = Gate()) {
     const int grid = mk_grid_spmv_for(s->A);
     if (timed) s->spmv_begin();
-    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate>), dim3(grid), dim3(MK_BLOCK), 0, s->stream, mk_view(s->A), x, epi,
-                       gate, s->next_halt(), s->d_part);
+    mk_spmv_launch(s->A, grid, s->stream, x, epi, gate, s->next_halt(), s->d_part);
     if (timed) s->spmv_end();
     return MK_OK;
 }

@@ -594,9 +594,8 @@ struct SymmlqSolver : mk_solver {
                                OpFinX{d_w, d_b, d_x, d_prec, zbar, bstep, cg_point}, n, nh, d_part);
             if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
             if ((rc = exchange(d_x)) != MK_OK) return rc;
-            hipLaunchKernelGGL((mk_spmv_kernel<EpiFinR, MkNoGate>), dim3(mk_grid_spmv_for(A)), dim3(MK_BLOCK), 0,
-                               stream, mk_view(A), d_x, EpiFinR{d_x, d_b, prm.shift, prm.has_shift}, MkNoGate(), nh,
-                               d_part);
+            mk_spmv_launch(A, mk_grid_spmv_for(A), stream, d_x, EpiFinR{d_x, d_b, prm.shift, prm.has_shift},
+                           MkNoGate(), nh, d_part);
             if ((rc = allreduce(SLOT_B, 1)) != MK_OK) return rc;
             hipLaunchKernelGGL(fin_norms_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_stream, np_spmv, d_out);
             double out[2];

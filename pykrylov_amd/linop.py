@@ -52,6 +52,10 @@ class ShapeError(Exception):
         return repr(self.value)
 
 
+def _is_real_scalar(x):
+    return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, (bool, np.bool_))
+
+
 class BaseLinearOperator(object):
     """Shape / dtype / symmetry metadata and the product counter (linop.py:14-104)."""
 
@@ -208,10 +212,22 @@ class LinearOperator(BaseLinearOperator):
         return self._H.__mul__(x)
 
     # -- the three meanings of `*` (linop.py:307-369) ---------------------------------
+    # `_mk_term = (diag or None, scale or None)` marks an operator whose product is
+    # `[scale *] ([diag *] x)`: IdentityOperator, DiagonalOperator and one real scalar multiple of either.  A
+    # CsrOperator combined with such an operand stays a device operator (see CsrOperator._compose).
+    _mk_term = None
+
     def _times_scalar(self, x):
         result_type = np.result_type(self.dtype, type(x))
         if x == 0:
             return ZeroOperator(self.nargin, self.nargout, dtype=result_type)
+        res = self._times_scalar_host(x, result_type)
+        t = self._mk_term
+        if t is not None and t[1] is None and _is_real_scalar(x) and not _is_complex(result_type):
+            res._mk_term = (t[0], float(x))
+        return res
+
+    def _times_scalar_host(self, x, result_type):
         return LinearOperator(self.nargin, self.nargout,
                               symmetric=self.symmetric,
                               hermitian=(not _is_complex(result_type)) and self.hermitian,
@@ -255,6 +271,10 @@ class LinearOperator(BaseLinearOperator):
             raise ValueError('Cannot add')
         if self.shape != other.shape:
             raise ShapeError('Cannot add')
+        if self._mk_term is not None and isinstance(other, CsrOperator):
+            dev = other._compose_with_term(self._mk_term, 'add' if f is np.add else 'rsub')   # D + A, D - A
+            if dev is not None:
+                return dev
         return LinearOperator(self.nargin, self.nargout,
                               symmetric=self.symmetric and other.symmetric,
                               hermitian=self.hermitian and other.hermitian,
@@ -300,6 +320,7 @@ class IdentityOperator(LinearOperator):
         kwargs.pop('symmetric', None)
         kwargs.pop('matvec', None)
         super(IdentityOperator, self).__init__(nargin, nargin, symmetric=True, matvec=lambda x: x, **kwargs)
+        self._mk_term = (None, None)
 
 
 class DiagonalOperator(LinearOperator):
@@ -315,6 +336,8 @@ class DiagonalOperator(LinearOperator):
         self._diag = diag.copy()
         super(DiagonalOperator, self).__init__(diag.shape[0], diag.shape[0], symmetric=True,
                                                matvec=lambda x: diag * x, dtype=diag.dtype, **kwargs)
+        if _kind(diag.dtype) in _INT_KINDS + _REAL_KINDS:
+            self._mk_term = (self._diag, None)
 
     diag = property(lambda self: self._diag, doc="The diagonal as a Numpy array.")
 
@@ -492,6 +515,55 @@ class CsrOperator(LinearOperator):
 
     H = T
 
+    # -- operator algebra that stays on the device (reference linop.py:307-330, :375-426) --------
+    # `alpha * A`, `-A`, `A / alpha`, `A + D`, `A - D`, `D + A`, `D - A` with D an IdentityOperator, a
+    # DiagonalOperator or a real scalar multiple of one return a CsrOperator that shares A's arrays and applies the
+    # reference's expression (`alpha * (A*x)`, `(A*x) + (D*x)`, ...) to every row sum inside the SpMV kernel
+    # (mk_csr_compose): same bits as the host closures of the reference, and the result is still accepted by the
+    # device solvers.  Anything else (A + B, A * B, complex scalars) composes on the host as in the reference.
+    def _compose(self, steps, diag_bufs=()):
+        if getattr(self, 'local_size', None) is not None:
+            return None                                   # partitioned operators: compose before partitioning
+        if len(getattr(self, '_steps', ())) + len(steps) > _lib.MK_ROWPROG_MAX:
+            return None
+        ops = (_lib.MkRowOp * len(steps))()
+        for k, (code, has_scale, scale, dptr) in enumerate(steps):
+            ops[k].code, ops[k].has_scale, ops[k].scale, ops[k].diag = code, has_scale, scale, dptr
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.mk_csr_compose(self._handle, len(steps), ops, ctypes.byref(h)))
+        new = _ComposedCsrOperator.from_handle(h.value, symmetric=self.symmetric)
+        new._base = self                                  # keeps the arrays (and earlier diagonals) alive
+        new._diag_bufs = tuple(diag_bufs)
+        new._steps = tuple(getattr(self, '_steps', ())) + tuple(steps)
+        return new
+
+    def _times_scalar(self, x):
+        if x != 0 and _is_real_scalar(x):
+            dev = self._compose([(_lib.MK_ROW_SCALE, 1, float(x), None)])
+            if dev is not None:
+                return dev
+        return LinearOperator._times_scalar(self, x)
+
+    def _compose_with_term(self, term, how):
+        if self.nargin != self.nargout:
+            return None
+        diag, scale = term
+        bufs, dptr = [], None
+        if diag is not None:
+            buf = _lib.DeviceArray.from_numpy(np.ascontiguousarray(diag, dtype=np.float64))
+            bufs.append(buf)
+            dptr = buf.ptr
+        code = {'add': _lib.MK_ROW_ADD, 'sub': _lib.MK_ROW_SUB, 'rsub': _lib.MK_ROW_RSUB}[how]
+        return self._compose([(code, int(scale is not None), float(scale or 0.0), dptr)], bufs)
+
+    def _combine(self, other, f):
+        if isinstance(other, BaseLinearOperator) and self.shape == other.shape and \
+                getattr(other, '_mk_term', None) is not None:
+            dev = self._compose_with_term(other._mk_term, 'add' if f is np.add else 'sub')
+            if dev is not None:
+                return dev
+        return LinearOperator._combine(self, other, f)
+
     def _device_matvec(self, x):
         if x.dtype != np.float64:
             if _kind(x.dtype) not in _INT_KINDS + _REAL_KINDS:
@@ -528,6 +600,27 @@ class CsrOperator(LinearOperator):
 
     def __del__(self):
         self.free()
+
+
+class _ComposedCsrOperator(CsrOperator):
+    """A CsrOperator with a row program (see CsrOperator._compose).  Products are counted on this operator and on
+    the matrix it was built from, as the reference's composite closures do (linop.py:356-360 via `self(y)`)."""
+
+    def _get_count(self):
+        return self.__dict__.get('_count', 0)
+
+    def _set_count(self, v):
+        delta = v - self.__dict__.get('_count', 0)
+        self.__dict__['_count'] = v
+        base = self.__dict__.get('_base')
+        if base is not None and delta > 0:
+            base._nMatvec += delta
+
+    _nMatvec = property(_get_count, _set_count)
+
+    def to_csr_arrays(self):
+        "The arrays of the underlying matrix (the composed steps are not folded into them)."
+        return self._base.to_csr_arrays()
 
 
 def CoordLinearOperator(vals, rows, cols, nargin=0, nargout=0, symmetric=False):

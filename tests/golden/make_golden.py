@@ -23,7 +23,9 @@ Fixture inventory:
   G8  large_summaries.npz   n=1e6 CG summary + integer checksums of the matrices
   G9  api_contract.npz      LinearOperator protocol facts (dtype promotion, counters)
   G10 precon_jacobi.npz     all six solvers with a DiagonalOperator preconditioner (SURVEY.md 8f-1);
-                            `make_golden.py --only-precon` regenerates just this file
+                            `make_golden.py --only-precon` regenerates just this file and G11
+  G11 composed_ops.npz      solvers on operators built with the reference's algebra (A + D, A - sigma*I,
+                            alpha*A)
 """
 import contextlib
 import hashlib
@@ -282,7 +284,47 @@ def main():
                             k + "trace": np.array(log)})
         save("precon_jacobi.npz", **out)
 
+    # ---------------- G11: composed operators (linop.py:307-330, :375-426) -- #
+    def g11():
+        from pykrylov.linop import DiagonalOperator, IdentityOperator
+        out = {}
+        m = 30
+        n = m * m
+        A = poisson2d(m)
+        dv = np.linspace(0.5, 6.0, n)
+        out.update(csr_arrays(A, "A_"))
+        out["dv"] = dv
+        x = np.random.default_rng(5).standard_normal(n)
+        out["x"] = x
+        I = IdentityOperator(n)
+        D = DiagonalOperator(dv)
+        forms = {"Am15I": lambda o: o - 1.5 * I, "ApD": lambda o: o + D, "DmA": lambda o: D - o,
+                 "2p5A": lambda o: 2.5 * o, "negA": lambda o: -o, "Adiv3": lambda o: o / 3.0,
+                 "nested": lambda o: 2.0 * (o - 1.5 * I) + 0.25 * D}
+        for k, f in forms.items():
+            out["y_" + k] = f(csr_op(A, True)) * x
+        # CG on A + D (SPD), MINRES on A - 1.5 I (indefinite) and on 0.5 * A
+        op = csr_op(A, True) + D
+        rhs = op * np.ones(n)
+        with traced(m_cg) as log:
+            s = m_cg.CG(op)
+            s.solve(rhs)
+        out.update({"cg_ApD_rhs": rhs, "cg_ApD_x": s.x, "cg_ApD_nMatvec": s.nMatvec,
+                    "cg_ApD_residHistory": np.array(s.residHistory), "cg_ApD_trace": np.array(log)})
+        for k, f in (("Am15I", forms["Am15I"]), ("halfA", lambda o: 0.5 * o)):
+            op = f(csr_op(A, True))
+            rhs = op * np.ones(n)
+            with traced(m_minres) as log:
+                s = m_minres.Minres(op)
+                quiet(s.solve, rhs, show=False, check=False, etol=0.0, rtol=1e-10)
+            kk = "minres_%s_" % k
+            out.update({kk + "rhs": rhs, kk + "x": s.x, kk + "istop": s.istop, kk + "itn": s.itn,
+                        kk + "residHistory": np.array(s.residHistory), kk + "Anorm": s.Anorm,
+                        kk + "trace": np.array(log)})
+        save("composed_ops.npz", **out)
+
     g10()
+    g11()
     if "--only-precon" in sys.argv:
         shutil.rmtree(tmp, ignore_errors=True)
         return

@@ -269,6 +269,30 @@ def test_precon_minres_symmlq(golden, shift):
         assert out[name] == float(d[k2 + name]), name
 
 
+# ------------------------------------------------------------------ composed operators
+def test_composed_operator_closures_match_reference(golden):
+    """oracle/csr_ref.Composed restates the reference's operator algebra; products and solver runs on composed
+    operators reproduce the reference's bits."""
+    d = golden("composed_ops.npz")
+    A = csr_from(d, "A_")
+    dv, x = d["dv"], d["x"]
+    fns = {"Am15I": lambda y, x: y - 1.5 * x, "ApD": lambda y, x: y + dv * x, "DmA": lambda y, x: dv * x - y,
+           "2p5A": lambda y, x: 2.5 * y, "negA": lambda y, x: -1 * y, "Adiv3": lambda y, x: (1. / 3.0) * y,
+           "nested": lambda y, x: 2.0 * (y - 1.5 * x) + 0.25 * (dv * x)}
+    for k, fn in fns.items():
+        assert same(csr_ref.Composed(A, fn).matvec(x), d["y_" + k]), k
+    out = kr.cg(csr_ref.Composed(A, fns["ApD"]), d["cg_ApD_rhs"])
+    assert out["nMatvec"] == int(d["cg_ApD_nMatvec"])
+    assert same(out["residHistory"], d["cg_ApD_residHistory"]) and same(out["trace"], d["cg_ApD_trace"])
+    assert same(out["x"], d["cg_ApD_x"])
+    for k, fn in (("Am15I", fns["Am15I"]), ("halfA", lambda y, x: 0.5 * y)):
+        kk = "minres_%s_" % k
+        out = kr.minres(csr_ref.Composed(A, fn), d[kk + "rhs"], check=False, etol=0.0, rtol=1e-10)
+        assert (out["istop"], out["itn"]) == (int(d[kk + "istop"]), int(d[kk + "itn"]))
+        assert same(out["residHistory"], d[kk + "residHistory"]) and same(out["trace"], d[kk + "trace"])
+        assert same(out["x"], d[kk + "x"])
+
+
 # ------------------------------------------------------------------ large-n summaries
 def test_large_matrix_checksums(golden):
     import hashlib
