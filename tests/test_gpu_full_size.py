@@ -1,0 +1,148 @@
+"""BASELINE configs[4] at full size on one GPU: 3-D 7-point Poisson 512^3 (134 217 728 rows, 937 951 232
+nonzeros, 14 GB in HBM).  The NumPy oracle cannot hold this matrix, so parity at this size is
+established through properties that do not depend on the size:
+
+* integer facts of the generated CSR (nnz, row-pointer end points, per-row counts on sampled slabs);
+* SpMV against closed forms that are EXACT in fp64 (small-integer arithmetic): A*1 counts the missing
+  neighbours of a grid node, and A*i (i = linear index) is zero in the interior;
+* symmetry <Ax, y> = <x, Ay> on random vectors;
+* CG: the recurrence residual equals the true residual ||b - A x_k|| recomputed with the plain SpMV, and the
+  first iterations of the same problem class one size down (256^3) match the CPU oracle to 1e-12.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import rel_hist_err
+from oracle import csr_ref, krylov_ref as kr
+
+pytestmark = pytest.mark.gpu
+M = 512
+N = M ** 3
+NNZ = 7 * N - 6 * M * M
+
+
+@pytest.fixture(scope="module")
+def op512():
+    from pykrylov_amd import gallery
+    op = gallery.poisson3d(M)
+    yield op
+    op.free()
+
+
+def missing_neighbours(m):
+    """Number of grid neighbours a node lacks (0 interior, 1 face, 2 edge, 3 corner), x fastest."""
+    e = np.zeros(m, dtype=np.int8)
+    e[0] = e[-1] = 1
+    return (e[None, None, :] + e[None, :, None] + e[:, None, None]).reshape(-1)
+
+
+def test_generated_matrix_integer_facts(op512):
+    from pykrylov_amd import _lib
+    lib = _lib.init()
+    assert op512.shape == (N, N) and op512.nnz == NNZ == 937951232
+    # row pointers: download only the two ends and one interior slab through the C ABI
+    indptr = np.empty(N + 1, dtype=np.int32)
+    _lib.check(lib.mk_csr_download(op512.handle, indptr.ctypes.data, None, None))
+    assert indptr[0] == 0 and indptr[-1] == NNZ
+    counts = np.diff(indptr)
+    assert np.array_equal(counts, 7 - missing_neighbours(M))            # bit-exact integer structure, all rows
+
+
+def test_spmv_closed_forms_exact(op512):
+    from pykrylov_amd import _lib
+    x = _lib.DeviceArray.from_numpy(np.ones(N))
+    y = _lib.DeviceArray(N)
+    op512.spmv_device(x.ptr, y.ptr)
+    miss = missing_neighbours(M)
+    assert np.array_equal(y.to_numpy(), miss.astype(np.float64))         # A*1: exact small integers
+    # A * (linear index): 6i - sum of existing neighbours = sum over missing neighbours of their (virtual) index
+    idx = np.arange(N, dtype=np.float64)
+    x.upload(idx)
+    op512.spmv_device(x.ptr, y.ptr)
+    got = y.to_numpy()
+    slab = 16 * M * M                                                    # 16 z-planes at a time (host memory)
+    for lo in range(0, N, slab):
+        i = np.arange(lo, lo + slab, dtype=np.int64)
+        want = np.zeros(slab, dtype=np.int64)
+        for coord, stride in ((i % M, 1), ((i // M) % M, M), (i // (M * M), M * M)):
+            want += np.where(coord == 0, i - stride, 0) + np.where(coord == M - 1, i + stride, 0)
+        assert np.array_equal(got[lo:lo + slab], want.astype(np.float64))   # all values < 2^53: exact
+    x.free()
+    y.free()
+
+
+def test_spmv_symmetry_and_linearity(op512):
+    from pykrylov_amd import _lib
+    lib = _lib.init()
+    rng = np.random.default_rng(42)
+    xs = [_lib.DeviceArray.from_numpy(rng.standard_normal(N)) for _ in range(2)]
+    ys = [_lib.DeviceArray(N) for _ in range(2)]
+    for a, b in zip(xs, ys):
+        op512.spmv_device(a.ptr, b.ptr)
+    d01, d10, n0, n1 = (ctypes.c_double() for _ in range(4))
+    _lib.check(lib.mk_dot(N, ys[0].ptr, xs[1].ptr, ctypes.byref(d01)))   # <A x0, x1>
+    _lib.check(lib.mk_dot(N, xs[0].ptr, ys[1].ptr, ctypes.byref(d10)))   # <x0, A x1>
+    _lib.check(lib.mk_nrm2(N, ys[0].ptr, ctypes.byref(n0)))
+    _lib.check(lib.mk_nrm2(N, xs[1].ptr, ctypes.byref(n1)))
+    assert abs(d01.value - d10.value) <= 1e-12 * n0.value * n1.value
+    # linearity: A(x0 + 2 x1) = A x0 + 2 A x1 (2 is a power of two: the only rounding is in the additions)
+    _lib.check(lib.mk_axpy(N, 2.0, xs[1].ptr, xs[0].ptr))               # x0 += 2 x1
+    z = _lib.DeviceArray(N)
+    op512.spmv_device(xs[0].ptr, z.ptr)
+    _lib.check(lib.mk_axpy(N, 2.0, ys[1].ptr, ys[0].ptr))               # y0 += 2 y1
+    _lib.check(lib.mk_axpy(N, -1.0, z.ptr, ys[0].ptr))
+    err, ref = ctypes.c_double(), ctypes.c_double()
+    _lib.check(lib.mk_nrm2(N, ys[0].ptr, ctypes.byref(err)))
+    _lib.check(lib.mk_nrm2(N, z.ptr, ctypes.byref(ref)))
+    assert err.value <= 1e-14 * ref.value
+    for b in xs + ys + [z]:
+        b.free()
+
+
+def test_cg_recurrence_residual_is_true_residual(op512):
+    """60 CG passes at 512^3 with everything resident in HBM: the residual norm the loop carries
+    (cg.py:131,146,154) equals ||A x_k - b|| recomputed from the iterate, and the history decreases in the
+    A-norm sense (energy norm monotone => <x_k, b> non-decreasing)."""
+    from pykrylov_amd import _lib
+    from pykrylov_amd.generic import DeviceRun
+    lib = _lib.init()
+    ones = _lib.DeviceArray.from_numpy(np.ones(N))
+    rhs = _lib.DeviceArray(N)
+    op512.spmv_device(ones.ptr, rhs.ptr)                                 # rhs = A * 1 (test_diagdom.py:78-79)
+    run = DeviceRun(op512, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=60, check_curvature=1)
+    res = run.run()
+    hist = run.history()
+    assert res.nMatvec == 60 and len(hist) == 61 and res.definite
+    # ||A*1||^2 = #faces * 1 + #edges * 4 + #corners * 9: an integer, summed exactly in any order
+    assert hist[0] == np.sqrt(6.0 * (M - 2) ** 2 + 48.0 * (M - 2) + 72.0)
+    px = ctypes.c_void_p()
+    _lib.check(lib.mk_solver_x(run.handle, ctypes.byref(px)))
+    ax = _lib.DeviceArray(N)
+    _lib.check(lib.mk_spmv(op512.handle, px.value, ax.ptr))
+    _lib.check(lib.mk_axpy(N, -1.0, rhs.ptr, ax.ptr))                    # A x - b
+    true_res = ctypes.c_double()
+    _lib.check(lib.mk_nrm2(N, ax.ptr, ctypes.byref(true_res)))
+    assert abs(true_res.value - hist[-1]) <= 1e-10 * hist[0]
+    assert hist[-1] < 0.2 * hist[0]
+    run.close()
+    for b in (ones, rhs, ax):
+        b.free()
+
+
+def test_cg_256cubed_head_matches_oracle():
+    """Same problem class one size down (16.7 M rows): the first 25 iterations against the CPU oracle."""
+    from pykrylov_amd import CG, gallery
+    m = 256
+    A = csr_ref.poisson3d(m)
+    n = m ** 3
+    rhs = A.matvec(np.ones(n))
+    ref = kr.cg(A, rhs, matvec_max=25)
+    op = gallery.poisson3d(m)
+    s = CG(op)
+    s.solve(rhs, matvec_max=25)
+    assert s.nMatvec == ref["nMatvec"] == 25
+    assert rel_hist_err(s.residHistory, ref["residHistory"]) <= 1e-12
+    assert np.linalg.norm(s.x - ref["x"]) <= 1e-12 * np.linalg.norm(ref["x"])
+    op.free()
