@@ -164,12 +164,12 @@ int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out) {
     A->nnz = nnz;
     A->ntiles = (nrows + MK_ROWS_PER_TILE - 1) / MK_ROWS_PER_TILE;
     hipError_t e1 = hipMalloc((void **)&A->d_indptr, sizeof(int32_t) * (size_t)(nrows + 1));
-    // +2 entries: the SpMV kernel reads nonzeros in aligned pairs and may touch one slot past the end
-    hipError_t e2 = hipMalloc((void **)&A->d_indices, sizeof(int32_t) * (size_t)(nnz + 2));
-    hipError_t e3 = hipMalloc((void **)&A->d_data, sizeof(double) * (size_t)(nnz + 2));
+    // +4 entries: the SpMV kernel reads nonzeros in aligned groups of four and may touch three slots past the end
+    hipError_t e2 = hipMalloc((void **)&A->d_indices, sizeof(int32_t) * (size_t)(nnz + MK_CSR_PAD));
+    hipError_t e3 = hipMalloc((void **)&A->d_data, sizeof(double) * (size_t)(nnz + MK_CSR_PAD));
     // (on the library's stream: the legacy default stream is not ordered with a non-blocking stream)
-    if (e2 == hipSuccess) e2 = hipMemsetAsync(A->d_indices + nnz, 0, 2 * sizeof(int32_t), mk_ctx().stream);
-    if (e3 == hipSuccess) e3 = hipMemsetAsync(A->d_data + nnz, 0, 2 * sizeof(double), mk_ctx().stream);
+    if (e2 == hipSuccess) e2 = hipMemsetAsync(A->d_indices + nnz, 0, MK_CSR_PAD * sizeof(int32_t), mk_ctx().stream);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(A->d_data + nnz, 0, MK_CSR_PAD * sizeof(double), mk_ctx().stream);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         mk_csr_destroy(A);
         return mk_fail(MK_ERR_HIP, "mk_csr: hipMalloc failed for nrows=%lld nnz=%lld", (long long)nrows,

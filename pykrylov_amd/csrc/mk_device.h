@@ -59,6 +59,7 @@ static inline MkCsrView mk_view(const mk_csr *A) {
 
 typedef double mk_d2 __attribute__((ext_vector_type(2)));
 typedef int mk_i2 __attribute__((ext_vector_type(2)));
+typedef int mk_i4 __attribute__((ext_vector_type(4)));
 
 // Composed operators (mk_csr_compose): the reference evaluates `alpha * op`, `op + D`, `op - D` as one NumPy
 // expression per node on the product vector (linop.py:307-330, :375-426); the same expressions, in the same order,
@@ -93,9 +94,9 @@ __device__ __forceinline__ double mk_rowprog(const MkCsrView &A, double t, const
 
 // ---------------------------------------------------------------------------------------
 // CSR-stream SpMV.  A workgroup owns 256 consecutive rows per tile.  Pass 1: all lanes walk
-// the tile's nonzeros in storage order, two per lane -- `data` is read 16 bytes and `indices`
-// 8 bytes per lane, fully coalesced (the chunk starts at an even nonzero so that the accesses
-// are naturally aligned; at most one entry of the previous tile is read and ignored); x is
+// the tile's nonzeros in storage order, four per lane -- `indices` with one and `data` with two
+// 16-byte loads per lane, fully coalesced (the chunk starts at a multiple of four nonzeros so that
+// the accesses are naturally aligned; at most three entries of the previous tile are read and ignored); x is
 // gathered through L1/L2; the PRODUCTS go to LDS.  Pass 2: lane t owns row t and adds its LDS
 // segment left to right, so the per-row rounding sequence is that of a scalar CSR loop
 // (bit-identical to the oracle).  Rows longer than the LDS tile are handled by looping over
@@ -114,7 +115,7 @@ struct MkHasPre<Epi, std::void_t<decltype(std::declval<Epi &>().pre((int64_t)0))
 template <bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
                                               double *prod, double (&acc)[NACC]) {
-    constexpr int PAIRS = MK_SPMV_TILE / (2 * MK_BLOCK);   // 4 pairs of nonzeros per lane per chunk
+    constexpr int QUADS = MK_SPMV_TILE / (4 * MK_BLOCK);   // 2 groups of 4 nonzeros per lane per chunk
     const int tid = threadIdx.x;
     // XCD-aware tile order (optional).  Workgroup b is dispatched to XCD b % 8 (observed,
     // MI355X_MICROARCH.md) and each XCD has its own 4 MiB L2.  Placement only affects speed.
@@ -126,22 +127,20 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     const int64_t chunk_end = (chunk0 + chunk < A.ntiles) ? chunk0 + chunk : A.ntiles;
 
     // Row pointers of a tile; fetched one tile ahead so that their latency is not on the critical path.
+    // (one load per lane: a row's end is its neighbour's start and travels through LDS, see below)
     struct Meta {
-        int p_lo, p_hi, my_lo, my_hi;
+        int p_lo, p_hi, my_lo;
     };
+    __shared__ int sptr[MK_BLOCK + 1];
     auto load_meta = [&](int64_t tile, Meta &m) {
-        m.p_lo = m.p_hi = m.my_lo = m.my_hi = 0;
+        m.p_lo = m.p_hi = m.my_lo = 0;
         if (tile < chunk_end) {
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
             const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
             const int64_t r = r0 + tid;
             m.p_lo = A.indptr[r0];
             m.p_hi = A.indptr[rend];
-            m.my_lo = m.my_hi = m.p_hi;
-            if (r < rend) {
-                m.my_lo = A.indptr[r];
-                m.my_hi = A.indptr[r + 1];
-            }
+            m.my_lo = A.indptr[(r < rend) ? r : rend];      // rows past the end start (and end) at p_hi
         }
     };
     int64_t tile = chunk0 + blockIdx.x / nxcd;
@@ -154,42 +153,60 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         if constexpr (MkHasPre<Epi>::value) {
             if (r < rend) epi.pre(r);
         }
-        const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo, my_hi = cur.my_hi;
+        const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
+        int my_hi = p_hi;
         double sum = 0.0;
         bool first = true;
-        for (int base = p_lo & ~1; base < p_hi; base += MK_SPMV_TILE) {
+        for (int base = p_lo & ~3; base < p_hi; base += MK_SPMV_TILE) {
             const int cnt = (p_hi - base < MK_SPMV_TILE) ? p_hi - base : MK_SPMV_TILE;
-            // ---- pass 1: coalesced stream of the chunk, products into LDS.  Straight-line code: loads are
-            // clamped instead of predicated and every lane stores its (possibly unused) products, so that the
-            // compiler keeps all loads of the chunk in flight together.
-            mk_i2 col[PAIRS];
-            mk_d2 val[PAIRS];
+            // ---- pass 1: coalesced stream of the chunk, products into LDS.  Four nonzeros per lane and step: ONE
+            // 16-byte index load, two 16-byte value loads, four gathers -- the texture-address unit, not HBM, is
+            // the busiest resource of this kernel (~30 clocks per wave-level memory instruction whatever its
+            // width; tools/ubench/l1_bench.hip), so the instruction count is what is minimised.  Straight-line
+            // code: loads are clamped instead of predicated and every lane stores its (possibly unused)
+            // products, so that the compiler keeps all loads of the chunk in flight together.
+            mk_i4 col[QUADS];
+            mk_d2 val[QUADS][2];
 #pragma unroll
-            for (int k = 0; k < PAIRS; ++k) {
-                int j = 2 * (k * MK_BLOCK + tid);
-                j = (j < cnt) ? j : ((cnt - 1) & ~1);
-                col[k] = *reinterpret_cast<const mk_i2 *>(A.indices + base + j);
-                val[k] = *reinterpret_cast<const mk_d2 *>(A.data + base + j);
-                col[k].y = (j + 1 < cnt) ? col[k].y : col[k].x;   // the odd slot past the chunk: keep the gather in range
+            for (int k = 0; k < QUADS; ++k) {
+                int j = 4 * (k * MK_BLOCK + tid);
+                j = (j < cnt) ? j : ((cnt - 1) & ~3);
+                col[k] = *reinterpret_cast<const mk_i4 *>(A.indices + base + j);
+                val[k][0] = *reinterpret_cast<const mk_d2 *>(A.data + base + j);
+                val[k][1] = *reinterpret_cast<const mk_d2 *>(A.data + base + j + 2);
+                // slots past the chunk: keep the gathers in range
+                col[k].y = (j + 1 < cnt) ? col[k].y : col[k].x;
+                col[k].z = (j + 2 < cnt) ? col[k].z : col[k].x;
+                col[k].w = (j + 3 < cnt) ? col[k].w : col[k].x;
             }
             if (first) {
                 load_meta(tile + per_xcd, nxt);              // next tile's row pointers go in flight now
                 first = false;
             }
-            mk_d2 xv[PAIRS];
+            mk_d2 xv[QUADS][2];
 #pragma unroll
-            for (int k = 0; k < PAIRS; ++k) {
-                xv[k].x = x[col[k].x];
-                xv[k].y = x[col[k].y];
+            for (int k = 0; k < QUADS; ++k) {
+                xv[k][0].x = x[col[k].x];
+                xv[k][0].y = x[col[k].y];
+                xv[k][1].x = x[col[k].z];
+                xv[k][1].y = x[col[k].w];
             }
 #pragma unroll
-            for (int k = 0; k < PAIRS; ++k) {
-                mk_d2 pr;
-                pr.x = val[k].x * epi.xin(xv[k].x);
-                pr.y = val[k].y * epi.xin(xv[k].y);
-                *reinterpret_cast<mk_d2 *>(prod + 2 * (k * MK_BLOCK + tid)) = pr;
+            for (int k = 0; k < QUADS; ++k) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    mk_d2 pr;
+                    pr.x = val[k][h].x * epi.xin(xv[k][h].x);
+                    pr.y = val[k][h].y * epi.xin(xv[k][h].y);
+                    *reinterpret_cast<mk_d2 *>(prod + 4 * (k * MK_BLOCK + tid) + 2 * h) = pr;
+                }
+            }
+            if (base == (p_lo & ~3)) {                       // first chunk of the tile: publish the row starts
+                sptr[tid] = my_lo;
+                if (tid == 0) sptr[MK_BLOCK] = p_hi;
             }
             __syncthreads();
+            if (base == (p_lo & ~3)) my_hi = sptr[tid + 1];
             // ---- pass 2: one lane per row, left-to-right sum of its segment (clamped reads + selects)
             const int lo = ((my_lo > base) ? my_lo : base) - base;
             const int hi = ((my_hi < base + cnt) ? my_hi : base + cnt) - base;

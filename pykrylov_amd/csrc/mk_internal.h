@@ -64,6 +64,8 @@ int mk_fail(int code, const char *fmt, ...);
 // --------------------------------------------------------------------------------------
 // exchange plan (multi-GPU); empty for a single-device matrix
 // --------------------------------------------------------------------------------------
+constexpr int MK_CSR_PAD = 4;      // padding entries behind indices / data (aligned 4-entry reads of the SpMV kernel)
+
 struct MkExchange {
     int mode = -1;                 // -1 none, 0 halo send/recv, 1 allgather
     int64_t n_local = 0, n_halo = 0;

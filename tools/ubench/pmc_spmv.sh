@@ -19,7 +19,7 @@ for f in sorted(glob.glob(out+'/p*/**/*counter_collection.csv',recursive=True)):
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
         if 'spmv' not in k: continue
-        key=(k.split('(')[0][-40:], r['Grid_Size'], r['Counter_Name'])
+        key=(k[:60], r['Grid_Size'], r['Counter_Name'])
         a=acc.setdefault(key,[0,0.0]); a[0]+=1; a[1]+=float(r['Counter_Value'])
 last=None
 for (k,g,c),a in acc.items():
