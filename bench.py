@@ -24,7 +24,10 @@ import os
 import sys
 import time
 
-import numpy as np
+# the CPU baseline is a one-core number: keep OpenBLAS (np.dot in the oracle) from fanning out over the host
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

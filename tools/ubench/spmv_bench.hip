@@ -71,6 +71,50 @@ __global__ __launch_bounds__(BLOCK) void spmv(const int* __restrict__ ip, const 
                 for (int k = 8; k < len; ++k) sum += prod[lo + k] * x[sidx[lo + k]];
                 __syncthreads();
             }
+        } else if (VAR == 11) {
+            // VAR 9 (16-byte index loads) + own-block x window: x[r0 .. r0+255] sits in LDS (one coalesced load per
+            // row, which CG needs anyway for <p, Ap>); in the row phase entries whose column falls into the tile's
+            // own row range read LDS, only the others are gathered from memory.
+            typedef int i4v __attribute__((ext_vector_type(4)));
+            __shared__ int sidx[TILE + 4];
+            __shared__ double sx[ROWS];
+            const double xr = x[min(r, nrows - 1)];
+            const int abase = p_lo & ~3;
+            for (int base = abase; base < p_hi; base += TILE) {
+                const int cnt = min(TILE, p_hi - base);
+                i4v col[2]; d2v val[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    int j = 4 * (k * BLOCK + tid); j = (j < cnt) ? j : ((cnt - 1) & ~3);
+                    col[k] = *(const i4v*)(ix + base + j);
+                    val[k][0] = *(const d2v*)(dv + base + j); val[k][1] = *(const d2v*)(dv + base + j + 2);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int j = 4 * (k * BLOCK + tid);
+                    *(i4v*)(sidx + j) = col[k]; *(d2v*)(prod + j) = val[k][0]; *(d2v*)(prod + j + 2) = val[k][1];
+                }
+                if (base == abase) sx[tid] = xr;
+                __syncthreads();
+                const int lo = max(my_lo, max(base, p_lo)) - base, hi = min(my_hi, base + cnt) - base, len = hi - lo;
+                double a[8], xv[8]; int c[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const int q = (k < len) ? lo + k : 0; c[k] = sidx[q]; a[k] = prod[q]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned off = (unsigned)(c[k] - (int)r0);
+                    if (k < len && off >= (unsigned)ROWS) xv[k] = x[c[k]];        // outside the block: memory
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned off = (unsigned)(c[k] - (int)r0);
+                    if (off < (unsigned)ROWS) xv[k] = sx[off];                    // inside the block: LDS
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < len) sum += a[k] * xv[k];
+                for (int k = 8; k < len; ++k) sum += prod[lo + k] * x[sidx[lo + k]];
+                __syncthreads();
+            }
         } else if (VAR == 9) {
             // wide coalesced loads (16 B values, 8 B indices, 2 nnz per lane) staged in LDS in storage order, then the
             // row phase (lane = row) walks its segment left to right and gathers x: for banded matrices consecutive
@@ -395,9 +439,9 @@ int main(int argc, char** argv) {
     std::vector<double> h0(n), h1(n);
     int grids[] = {1024, 2048};
 #define RUN(VAR, XCD) for (int g : grids) { float ms = timeit([&] { hipLaunchKernelGGL((spmv<VAR, XCD>), dim3(g), dim3(BLOCK), 0, 0, ip, ix, dv, x, (VAR == 0 && XCD == 0) ? y0 : y, n, ntiles, part); }, reps); \
-        const char* ok = "-"; if (VAR <= 2 || VAR == 5 || VAR == 9 || VAR == 10) { CK(hipMemcpy(h0.data(), y0, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), (VAR == 0 && XCD == 0) ? y0 : y, n * 8, hipMemcpyDeviceToHost)); ok = "bit-exact"; for (long i = 0; i < n; ++i) if (h0[i] != h1[i]) { ok = "MISMATCH"; break; } } \
+        const char* ok = "-"; if (VAR <= 2 || VAR == 5 || VAR >= 9) { CK(hipMemcpy(h0.data(), y0, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), (VAR == 0 && XCD == 0) ? y0 : y, n * 8, hipMemcpyDeviceToHost)); ok = "bit-exact"; for (long i = 0; i < n; ++i) if (h0[i] != h1[i]) { ok = "MISMATCH"; break; } } \
         printf("var=%d xcd=%d grid=%4d : %9.1f us  %.2f TB/s  %s\n", VAR, XCD, g, ms * 1e3, bytes / ms / 1e9, ok); }
-    RUN(1, 0) RUN(10, 0) RUN(3, 0)
+    RUN(0, 0) RUN(10, 0) RUN(11, 0) RUN(11, 1) RUN(3, 0)
     return 0;
 #define RUNP(XCD) for (int g : {512, 1024, 2048}) { float ms = timeit([&] { hipLaunchKernelGGL((spmv_pipe<XCD>), dim3(g), dim3(BLOCK), 0, 0, ip, ix, dv, x, y, n, ntiles, part); }, reps); \
         CK(hipMemcpy(h0.data(), y0, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), y, n * 8, hipMemcpyDeviceToHost)); const char* ok = "bit-exact"; for (long i = 0; i < n; ++i) if (h0[i] != h1[i]) { ok = "MISMATCH"; break; } \
