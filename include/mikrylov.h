@@ -67,6 +67,14 @@ int mk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *indp
                   const int32_t *indices_host, const double *data_host, mk_csr **out);
 int mk_csr_destroy(mk_csr *A);
 int mk_csr_shape(const mk_csr *A, int64_t *nrows, int64_t *ncols, int64_t *nnz);
+/* Canonical CSR from coordinate triples (host arrays, borrowed), built on the device: the on-disk side of the
+ * path -- MatrixMarket coordinate files (examples/1138bus.mtx, jpwh_991.mtx; examples/demo_common.py:12-16 used
+ * Pysparse for this) and the reference's CoordLinearOperator (linop.py:638-685).  Columns sorted per row,
+ * duplicate entries summed in input order starting from 0.0 (the result of a stable host sort + np.add.at):
+ * integer arrays and values are bit-identical to that host construction.  Symmetric storage must be mirrored by
+ * the caller.  MK_ERR_UNSUPPORTED if one row holds more than 16384 entries (use mk_csr_create then). */
+int mk_csr_from_coo(int64_t nrows, int64_t ncols, int64_t nentries, const int32_t *rows_host,
+                    const int32_t *cols_host, const double *vals_host, mk_csr **out);
 /* Copy the arrays back (any pointer may be NULL). */
 int mk_csr_download(const mk_csr *A, int32_t *indptr_host, int32_t *indices_host, double *data_host);
 /* B = A^T as a new canonical CSR built on the device (operator `.T`, linop.py:148-171;

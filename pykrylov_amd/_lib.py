@@ -62,6 +62,7 @@ PROTOTYPES = {
     "mk_csr_destroy": (ctypes.c_int, [c_vp]),
     "mk_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),
     "mk_csr_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "mk_csr_from_coo": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),
     "mk_csr_transpose": (ctypes.c_int, [c_vp, P(c_vp)]),
     "mk_csr_compose": (ctypes.c_int, [c_vp, ctypes.c_int32, P(MkRowOp), P(c_vp)]),
     "mk_csr_poisson2d": (ctypes.c_int, [c_i64, c_i64, c_i64, P(c_vp)]),

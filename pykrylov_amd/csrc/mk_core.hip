@@ -523,6 +523,158 @@ extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
 }
 
 // ======================================================================================
+// coordinate triples -> canonical CSR on the device (the on-disk side of the path: MatrixMarket files and
+// the reference's CoordLinearOperator, linop.py:638-685).  Integer work is done with integer atomics (their
+// RESULT is order independent); the floating-point sums of duplicate entries are formed by one thread per
+// row, sequentially, in input order -- so the arrays are bit-identical to a stable host sort + np.add.at.
+// ======================================================================================
+__global__ __launch_bounds__(MK_BLOCK) void coo_count(int64_t ne, const int32_t *rows, int32_t *count) {
+    for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < ne; j += (int64_t)gridDim.x * MK_BLOCK)
+        atomicAdd(&count[rows[j] + 1], 1);
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void coo_scatter(int64_t ne, const int32_t *rows, const int32_t *cols,
+                                                        int32_t *cursor, int32_t *seg_col, int32_t *seg_src) {
+    for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < ne; j += (int64_t)gridDim.x * MK_BLOCK) {
+        const int32_t dst = atomicAdd(&cursor[rows[j]], 1);
+        seg_col[dst] = cols[j];
+        seg_src[dst] = (int32_t)j;
+    }
+}
+
+// per row: order by (column, input position) -- a total order, so the arbitrary arrival order of the scatter
+// does not matter -- and count the distinct columns
+__global__ __launch_bounds__(MK_BLOCK) void coo_sort_rows(int64_t nrows, const int32_t *start, int32_t *seg_col,
+                                                          int32_t *seg_src, int32_t *ucount) {
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        const int32_t lo = start[r], hi = start[r + 1];
+        for (int32_t i = lo + 1; i < hi; ++i) {
+            const int32_t ci = seg_col[i], si = seg_src[i];
+            int32_t j = i - 1;
+            while (j >= lo && (seg_col[j] > ci || (seg_col[j] == ci && seg_src[j] > si))) {
+                seg_col[j + 1] = seg_col[j];
+                seg_src[j + 1] = seg_src[j];
+                --j;
+            }
+            seg_col[j + 1] = ci;
+            seg_src[j + 1] = si;
+        }
+        int32_t u = 0;
+        for (int32_t i = lo; i < hi; ++i) u += (i == lo || seg_col[i] != seg_col[i - 1]) ? 1 : 0;
+        ucount[r + 1] = u;
+    }
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void coo_emit(int64_t nrows, const int32_t *start, const int32_t *seg_col,
+                                                     const int32_t *seg_src, const double *vals,
+                                                     const int32_t *indptr, int32_t *indices, double *data) {
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        const int32_t lo = start[r], hi = start[r + 1];
+        int32_t out = indptr[r] - 1;
+        double sum = 0.0;
+        for (int32_t i = lo; i < hi; ++i) {
+            if (i == lo || seg_col[i] != seg_col[i - 1]) {
+                if (i != lo) data[out] = sum;
+                ++out;
+                indices[out] = seg_col[i];
+                sum = 0.0;
+            }
+            sum = sum + vals[seg_src[i]];                   // duplicates: added in input order, starting from 0.0
+        }
+        if (hi > lo) data[out] = sum;
+    }
+}
+
+static inline int mk_grid_for(int64_t n) {
+    int64_t g = (n + MK_BLOCK - 1) / MK_BLOCK;
+    return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+extern "C" int mk_csr_from_coo(int64_t nrows, int64_t ncols, int64_t nentries, const int32_t *rows,
+                               const int32_t *cols, const double *vals, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(out && nrows >= 0 && ncols >= 0 && nentries >= 0 && (nentries == 0 || (rows && cols && vals)));
+    if (nentries > 2147483647LL || ncols > 2147483647LL || nrows > 2147483646LL)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_from_coo: sizes exceed the int32 index range");
+    std::vector<int32_t> h((size_t)nrows + 1, 0);
+    for (int64_t j = 0; j < nentries; ++j) {
+        if (rows[j] < 0 || rows[j] >= nrows || cols[j] < 0 || cols[j] >= ncols)
+            return mk_fail(MK_ERR_ARG, "mk_csr_from_coo: entry %lld = (%d, %d) outside a %lld x %lld matrix",
+                           (long long)j, rows[j], cols[j], (long long)nrows, (long long)ncols);
+        h[(size_t)rows[j] + 1] += 1;
+    }
+    int32_t longest = 0;
+    for (int64_t r = 0; r < nrows; ++r) {
+        longest = h[r + 1] > longest ? h[r + 1] : longest;
+        h[r + 1] += h[r];
+    }
+    if (longest > 16384)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_from_coo: a row with %d entries is too long for the per-row "
+                       "device sort; build the CSR arrays on the host (mk_csr_create)", (int)longest);
+    hipStream_t st = mk_ctx().stream;
+    const size_t pb = sizeof(int32_t) * (size_t)(nrows + 1), eb = sizeof(int32_t) * (size_t)(nentries ? nentries : 1);
+    int32_t *d_rows = nullptr, *d_cols = nullptr, *d_start = nullptr, *d_cursor = nullptr, *d_scol = nullptr,
+            *d_ssrc = nullptr, *d_ucount = nullptr;
+    double *d_vals = nullptr;
+    mk_csr *A = nullptr;
+    int rc = MK_OK;
+    auto cleanup = [&]() {
+        hipFree(d_rows); hipFree(d_cols); hipFree(d_start); hipFree(d_cursor); hipFree(d_scol); hipFree(d_ssrc);
+        hipFree(d_ucount); hipFree(d_vals);
+    };
+#define MK_TRY(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            cleanup();                                                                                 \
+            mk_csr_destroy(A);                                                                         \
+            return mk_fail(MK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));                 \
+        }                                                                                              \
+    } while (0)
+    MK_TRY(hipMalloc((void **)&d_rows, eb));
+    MK_TRY(hipMalloc((void **)&d_cols, eb));
+    MK_TRY(hipMalloc((void **)&d_scol, eb));
+    MK_TRY(hipMalloc((void **)&d_ssrc, eb));
+    MK_TRY(hipMalloc((void **)&d_vals, sizeof(double) * (size_t)(nentries ? nentries : 1)));
+    MK_TRY(hipMalloc((void **)&d_start, pb));
+    MK_TRY(hipMalloc((void **)&d_cursor, pb));
+    MK_TRY(hipMalloc((void **)&d_ucount, pb));
+    if (nentries) {
+        MK_TRY(hipMemcpyAsync(d_rows, rows, sizeof(int32_t) * (size_t)nentries, hipMemcpyHostToDevice, st));
+        MK_TRY(hipMemcpyAsync(d_cols, cols, sizeof(int32_t) * (size_t)nentries, hipMemcpyHostToDevice, st));
+        MK_TRY(hipMemcpyAsync(d_vals, vals, sizeof(double) * (size_t)nentries, hipMemcpyHostToDevice, st));
+    }
+    MK_TRY(hipMemcpyAsync(d_start, h.data(), pb, hipMemcpyHostToDevice, st));
+    MK_TRY(hipMemcpyAsync(d_cursor, h.data(), pb, hipMemcpyHostToDevice, st));
+    MK_TRY(hipMemsetAsync(d_ucount, 0, pb, st));
+    if (nentries)
+        hipLaunchKernelGGL(coo_scatter, dim3(mk_grid_for(nentries)), dim3(MK_BLOCK), 0, st, nentries, d_rows, d_cols,
+                           d_cursor, d_scol, d_ssrc);
+    if (nrows)
+        hipLaunchKernelGGL(coo_sort_rows, dim3(mk_grid_for(nrows)), dim3(MK_BLOCK), 0, st, nrows, d_start, d_scol,
+                           d_ssrc, d_ucount);
+    std::vector<int32_t> u((size_t)nrows + 1, 0);
+    MK_TRY(hipMemcpyAsync(u.data(), d_ucount, pb, hipMemcpyDeviceToHost, st));
+    MK_TRY(hipStreamSynchronize(st));
+    for (int64_t r = 0; r < nrows; ++r) u[r + 1] += u[r];
+    rc = mk_csr_alloc(nrows, ncols, u[(size_t)nrows], &A);
+    if (rc != MK_OK) {
+        cleanup();
+        return rc;
+    }
+    MK_TRY(hipMemcpyAsync(A->d_indptr, u.data(), pb, hipMemcpyHostToDevice, st));
+    if (nrows)
+        hipLaunchKernelGGL(coo_emit, dim3(mk_grid_for(nrows)), dim3(MK_BLOCK), 0, st, nrows, d_start, d_scol, d_ssrc,
+                           d_vals, A->d_indptr, A->d_indices, A->d_data);
+    MK_TRY(hipGetLastError());
+    MK_TRY(hipStreamSynchronize(st));
+#undef MK_TRY
+    cleanup();
+    *out = A;
+    return MK_OK;
+}
+
+// ======================================================================================
 // counter calibration helpers (profiles/: known byte counts at the access widths the solver
 // kernels use, to scale rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 -- MI355X_MICROARCH.md, HBM)
 // ======================================================================================

@@ -487,6 +487,32 @@ class CsrOperator(LinearOperator):
         self._finish_init(handle, (m.value, n.value), nnz.value, symmetric, kwargs)
         return self
 
+    @classmethod
+    def from_coo(cls, rows, cols, vals, shape, symmetric=False, **kwargs):
+        """Operator from 0-based coordinate triples, assembled into canonical CSR on the device
+        (``mk_csr_from_coo``: columns sorted per row, duplicates summed in input order).  `symmetric` only declares
+        A = A^T; mirror one-triangle storage yourself (see `CoordLinearOperator`)."""
+        lib = _lib.init()
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        if not (rows.shape == cols.shape == vals.shape) or rows.ndim != 1:
+            raise ValueError('rows, cols and vals must be 1-d arrays of equal length')
+        m, n = int(shape[0]), int(shape[1])
+        if rows.size and (rows.min() < 0 or rows.max() >= m or cols.min() < 0 or cols.max() >= n):
+            raise ValueError('coordinate index out of range for shape %s' % (shape,))
+        if rows.size and np.bincount(rows, minlength=m).max() > 16384:
+            # the device builder sorts each row with one thread; very long rows are assembled on the host instead
+            # (construction only -- products and solvers always run on the device)
+            from .sparse import coo_to_csr
+            indptr, indices, data = coo_to_csr(rows, cols, vals, (m, n))
+            return cls(indptr, indices, data, (m, n), symmetric=symmetric, **kwargs)
+        r32, c32 = rows.astype(np.int32), cols.astype(np.int32)
+        h = ctypes.c_void_p()
+        _lib.check(lib.mk_csr_from_coo(m, n, rows.size, r32.ctypes.data, c32.ctypes.data, vals.ctypes.data,
+                                       ctypes.byref(h)))
+        return cls.from_handle(h.value, symmetric=symmetric, **kwargs)
+
     def _finish_init(self, handle, shape, nnz, symmetric, kwargs):
         self._lib = _lib.init()
         self._handle = handle
@@ -627,7 +653,6 @@ def CoordLinearOperator(vals, rows, cols, nargin=0, nargout=0, symmetric=False):
     """Operator from a coordinate-format matrix (reference linop.py:638-685), compiled to a
     device CSR instead of the reference's per-nonzero Python loop.  If `symmetric`, the
     triples describe one triangle and are mirrored (MatrixMarket symmetric storage)."""
-    from .sparse import coo_to_csr
     vals = np.asarray(vals, dtype=np.float64)
     rows = np.asarray(rows).astype(np.int64)
     cols = np.asarray(cols).astype(np.int64)
@@ -639,5 +664,4 @@ def CoordLinearOperator(vals, rows, cols, nargin=0, nargout=0, symmetric=False):
         off = rows != cols
         rows, cols, vals = (np.concatenate([rows, cols[off]]), np.concatenate([cols, rows[off]]),
                             np.concatenate([vals, vals[off]]))
-    indptr, indices, data = coo_to_csr(rows, cols, vals, (nargout, nargin))
-    return CsrOperator(indptr, indices, data, (nargout, nargin), symmetric=symmetric)
+    return CsrOperator.from_coo(rows, cols, vals, (nargout, nargin), symmetric=symmetric)

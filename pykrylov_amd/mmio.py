@@ -8,8 +8,8 @@ import numpy as np
 from .sparse import coo_to_csr
 
 
-def read_mtx(path):
-    """Parse a MatrixMarket *coordinate* file; returns ``(indptr, indices, data, shape, symmetric)``
+def read_mtx_coo(path):
+    """Parse a MatrixMarket *coordinate* file; returns ``(rows, cols, vals, shape, symmetric)`` (0-based triples)
     with symmetric / skew-symmetric storage expanded to the full matrix."""
     with open(path, 'r') as fh:
         banner = fh.readline().split()
@@ -39,12 +39,20 @@ def read_mtx(path):
         sign = -1.0 if symm == 'skew-symmetric' else 1.0
         rows, cols, vals = (np.concatenate([rows, cols[off]]), np.concatenate([cols, rows[off]]),
                             np.concatenate([vals, sign * vals[off]]))
-    indptr, indices, data = coo_to_csr(rows, cols, vals, (m, n))
-    return indptr, indices, data, (m, n), symm == 'symmetric'
+    return rows, cols, vals, (m, n), symm == 'symmetric'
+
+
+def read_mtx(path):
+    """Parse a MatrixMarket *coordinate* file on the host; returns ``(indptr, indices, data, shape, symmetric)``
+    with symmetric / skew-symmetric storage expanded to the full matrix."""
+    rows, cols, vals, shape, symmetric = read_mtx_coo(path)
+    indptr, indices, data = coo_to_csr(rows, cols, vals, shape)
+    return indptr, indices, data, shape, symmetric
 
 
 def csr_operator_from_mtx(path):
-    """Device-resident operator for the matrix stored in `path`."""
+    """Device-resident operator for the matrix stored in `path`; the coordinate triples are sorted and
+    assembled into CSR on the GPU (``mk_csr_from_coo``), bit-identical to the host construction."""
     from .linop import CsrOperator
-    indptr, indices, data, shape, symmetric = read_mtx(path)
-    return CsrOperator(indptr, indices, data, shape, symmetric=symmetric)
+    rows, cols, vals, shape, symmetric = read_mtx_coo(path)
+    return CsrOperator.from_coo(rows, cols, vals, shape, symmetric=symmetric)

@@ -190,3 +190,63 @@ def test_check_symmetric_on_device(golden):
     B = golden_csr(golden("nonsym_jpwh991.npz"), "A_")
     assert not check_symmetric(op_from(B))
     assert np.random.random() == np.random.RandomState(1).random_sample(400 * 10 + 1)[-1] or True
+
+
+# ------------------------------------------------------------------ coordinate triples -> CSR on the device
+def test_from_coo_bit_exact_with_duplicates():
+    """mk_csr_from_coo vs the oracle's stable sort + sequential sums: integer arrays and values bit for bit,
+    with up to ~6 duplicates per position, empty rows, -0.0 and a rectangular shape."""
+    from pykrylov_amd import CsrOperator
+    rng = np.random.default_rng(17)
+    m, n, ne = 300, 211, 20000
+    rows = rng.integers(0, m, ne)
+    rows[rows % 7 == 3] = 5                                  # rows 3, 10, ... stay empty; row 5 gets long
+    cols = rng.integers(0, n, ne) % 40 + (rows % 5) * 30     # few distinct columns per row => many duplicates
+    vals = rng.standard_normal(ne) * 10.0 ** rng.integers(-8, 8, ne)
+    vals[::97] = -0.0
+    ref = csr_ref.from_coo(rows, cols, vals, (m, n))
+    op = CsrOperator.from_coo(rows, cols, vals, (m, n))
+    indptr, indices, data = op.to_csr_arrays()
+    assert op.shape == (m, n) and op.nnz == ref.nnz < ne
+    assert np.array_equal(indptr, ref.indptr) and np.array_equal(indices, ref.indices)
+    assert np.array_equal(data, ref.data) and np.array_equal(np.signbit(data), np.signbit(ref.data))
+    x = rng.standard_normal(n)
+    assert np.array_equal(op * x, ref.matvec(x))
+
+
+@pytest.mark.parametrize("fix,prefix", [("cg_1138bus.npz", "A_"), ("nonsym_jpwh991.npz", "A_")])
+def test_from_coo_rebuilds_reference_matrices(golden, fix, prefix):
+    """The CSR arrays the reference side produced for the MatrixMarket examples, taken apart into shuffled
+    triples and reassembled on the device (and, for the symmetric one, from its lower triangle only)."""
+    from pykrylov_amd import CsrOperator, CoordLinearOperator
+    d = golden(fix)
+    indptr, indices, data, shape = (d[prefix + k] for k in ("indptr", "indices", "data", "shape"))
+    rows = np.repeat(np.arange(shape[0]), np.diff(indptr))
+    perm = np.random.default_rng(3).permutation(len(rows))
+    op = CsrOperator.from_coo(rows[perm], indices[perm], data[perm], tuple(shape))
+    got = op.to_csr_arrays()
+    assert all(np.array_equal(a, b) for a, b in zip(got, (indptr, indices, data)))
+    if fix == "cg_1138bus.npz":
+        low = rows >= indices                                # MatrixMarket symmetric storage: one triangle
+        op2 = CoordLinearOperator(data[low], rows[low], indices[low], shape[1], shape[0], symmetric=True)
+        got = op2.to_csr_arrays()
+        assert op2.symmetric and all(np.array_equal(a, b) for a, b in zip(got, (indptr, indices, data)))
+
+
+def test_from_coo_edge_cases():
+    from pykrylov_amd import CsrOperator
+    op = CsrOperator.from_coo([], [], [], (4, 3))
+    assert op.nnz == 0 and np.array_equal(op * np.ones(3), np.zeros(4))
+    with pytest.raises(ValueError):
+        CsrOperator.from_coo([4], [0], [1.0], (4, 3))
+    with pytest.raises(ValueError):
+        CsrOperator.from_coo([0, 1], [0], [1.0], (4, 3))
+    # one very long row takes the host assembly route and must give the same arrays
+    ne = 20000
+    rng = np.random.default_rng(5)
+    rows = np.zeros(ne, dtype=np.int64)
+    cols = rng.integers(0, 500, ne)
+    vals = rng.standard_normal(ne)
+    ref = csr_ref.from_coo(rows, cols, vals, (2, 500))
+    got = CsrOperator.from_coo(rows, cols, vals, (2, 500)).to_csr_arrays()
+    assert np.array_equal(got[0], ref.indptr) and np.array_equal(got[1], ref.indices) and np.array_equal(got[2], ref.data)
