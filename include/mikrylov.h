@@ -125,6 +125,21 @@ int mk_scal(int64_t n, double alpha, double *x_dev);                            
  * unique_id: 128 bytes from mk_comm_unique_id on rank 0, broadcast by the caller. */
 int mk_comm_unique_id(void *id128);
 int mk_comm_init(int nranks, int rank, const void *id128);
+/* Host-staged transport: the same collectives carried by caller-supplied functions on HOST buffers (for instance
+ * torch.distributed with the gloo backend).  Every collective stages through pinned memory and synchronises the
+ * stream: meant for exercising the multi-rank logic where RCCL cannot be used (several ranks on one GPU, CI), not
+ * for speed.  Callbacks return 0 on success.
+ *   allreduce(buf, count)                       in-place sum over all ranks
+ *   exchange(send, send_count, send_off, recv, recv_count, recv_off)
+ *                                               rank r gets send[send_off[r] .. +send_count[r]) and delivers
+ *                                               recv_count[r] entries to recv + recv_off[r] (arrays of nranks)
+ *   allgather(send, count, recv)                recv = concatenation over ranks of `count` entries each */
+typedef int (*mk_host_allreduce_fn)(double *buf, int64_t count);
+typedef int (*mk_host_exchange_fn)(const double *send, const int64_t *send_count, const int64_t *send_off,
+                                   double *recv, const int64_t *recv_count, const int64_t *recv_off);
+typedef int (*mk_host_allgather_fn)(const double *send, int64_t count, double *recv);
+int mk_comm_init_host(int nranks, int rank, mk_host_allreduce_fn allreduce, mk_host_exchange_fn exchange,
+                      mk_host_allgather_fn allgather);
 int mk_comm_destroy(void);
 int mk_comm_info(int *nranks, int *rank);
 /* Attach an exchange plan to a local matrix whose columns are already remapped to

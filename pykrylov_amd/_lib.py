@@ -35,6 +35,14 @@ class MkRowOp(ctypes.Structure):
 MK_ROW_SCALE, MK_ROW_ADD, MK_ROW_SUB, MK_ROW_RSUB, MK_ROWPROG_MAX = 1, 2, 3, 4, 4
 
 
+# host-staged transport callbacks (mk_comm_init_host)
+HOST_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64)
+HOST_EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                    ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
+                                    ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64))
+HOST_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+
 class MkResult(ctypes.Structure):
     _fields_ = [("struct_size", c_i32), ("halted", c_i32), ("nMatvec", c_i64), ("itn", c_i64),
                 ("hist_len", c_i64), ("converged", c_i32), ("definite", c_i32), ("istop", c_i32),
@@ -75,6 +83,8 @@ PROTOTYPES = {
     "mk_scal": (ctypes.c_int, [c_i64, c_f64, c_vp]),
     "mk_comm_unique_id": (ctypes.c_int, [c_vp]),
     "mk_comm_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_vp]),
+    "mk_comm_init_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN,
+                                         HOST_ALLGATHER_FN]),
     "mk_comm_destroy": (ctypes.c_int, []),
     "mk_comm_info": (ctypes.c_int, [P(ctypes.c_int), P(ctypes.c_int)]),
     "mk_csr_set_exchange": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),

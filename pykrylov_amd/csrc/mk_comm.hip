@@ -32,6 +32,28 @@ Rccl g_rccl;
 ncclComm_t g_comm = nullptr;
 int g_nranks = 1, g_rank = 0;
 
+// Host-staged transport (mk_comm_init_host): the same collectives carried by caller-supplied functions that work
+// on HOST buffers (e.g. torch.distributed/gloo).  Every call stages through pinned memory and synchronises the
+// stream -- for tests of the multi-rank logic on machines without a second GPU, not for speed.
+struct HostComm {
+    bool active = false;
+    mk_host_allreduce_fn allreduce = nullptr;
+    mk_host_exchange_fn exchange = nullptr;
+    mk_host_allgather_fn allgather = nullptr;
+    double *send = nullptr, *recv = nullptr;      // pinned staging
+    size_t send_cap = 0, recv_cap = 0;
+    int reserve(double **buf, size_t *cap, size_t count) {
+        if (count <= *cap) return MK_OK;
+        if (*buf) hipHostFree(*buf);
+        *buf = nullptr;
+        *cap = 0;
+        MK_HIP(hipHostMalloc((void **)buf, sizeof(double) * count));
+        *cap = count;
+        return MK_OK;
+    }
+};
+HostComm g_host;
+
 int load_rccl() {
     if (g_rccl.handle) return MK_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -75,9 +97,19 @@ __global__ __launch_bounds__(MK_BLOCK) void pack_kernel(int64_t cnt, const int32
 
 }  // namespace
 
-int mk_comm_active() { return g_comm != nullptr && g_nranks > 1; }
+int mk_comm_active() { return (g_comm != nullptr || g_host.active) && g_nranks > 1; }
 
 int mk_comm_allreduce_sum(double *buf, int64_t count, hipStream_t stream) {
+    if (g_host.active) {
+        int rc = g_host.reserve(&g_host.send, &g_host.send_cap, (size_t)count);
+        if (rc != MK_OK) return rc;
+        MK_HIP(hipMemcpyAsync(g_host.send, buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, stream));
+        MK_HIP(hipStreamSynchronize(stream));
+        if (g_host.allreduce(g_host.send, count) != 0) return mk_fail(MK_ERR_COMM, "host all-reduce callback failed");
+        MK_HIP(hipMemcpyAsync(buf, g_host.send, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, stream));
+        MK_HIP(hipStreamSynchronize(stream));
+        return MK_OK;
+    }
     if (!g_comm) return mk_fail(MK_ERR_COMM, "all-reduce without a communicator");
     MK_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_comm, stream));
     return MK_OK;
@@ -108,7 +140,27 @@ extern "C" int mk_comm_init(int nranks, int rank, const void *id128) {
     return MK_OK;
 }
 
+extern "C" int mk_comm_init_host(int nranks, int rank, mk_host_allreduce_fn allreduce, mk_host_exchange_fn exchange,
+                                 mk_host_allgather_fn allgather) {
+    MK_REQUIRE_INIT();
+    MK_ARG(nranks >= 1 && rank >= 0 && rank < nranks && allreduce && exchange && allgather);
+    if (g_comm || g_host.active) return mk_fail(MK_ERR_STATE, "mk_comm_init_host: communicator already exists");
+    g_host.allreduce = allreduce;
+    g_host.exchange = exchange;
+    g_host.allgather = allgather;
+    g_host.active = true;
+    g_nranks = nranks;
+    g_rank = rank;
+    return MK_OK;
+}
+
 extern "C" int mk_comm_destroy(void) {
+    if (g_host.active) {
+        if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+        if (g_host.send) hipHostFree(g_host.send);
+        if (g_host.recv) hipHostFree(g_host.recv);
+        g_host = HostComm();
+    }
     if (g_comm) {
         if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
         g_rccl.CommDestroy(g_comm);
@@ -234,6 +286,20 @@ extern "C" int mk_exchange(const mk_csr *A, double *x_ext) {
     const MkExchange &ex = A->ex;
     if (ex.mode < 0) return MK_OK;
     hipStream_t st = mk_ctx().stream;
+    if (ex.mode == 1 && g_host.active) {
+        const size_t cnt = (size_t)(ex.n_halo / g_nranks);
+        int rc = g_host.reserve(&g_host.send, &g_host.send_cap, cnt);
+        if (rc == MK_OK) rc = g_host.reserve(&g_host.recv, &g_host.recv_cap, (size_t)ex.n_halo);
+        if (rc != MK_OK) return rc;
+        MK_HIP(hipMemcpyAsync(g_host.send, x_ext, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        if (g_host.allgather(g_host.send, (int64_t)cnt, g_host.recv) != 0)
+            return mk_fail(MK_ERR_COMM, "host all-gather callback failed");
+        MK_HIP(hipMemcpyAsync(x_ext + ex.n_local, g_host.recv, sizeof(double) * (size_t)ex.n_halo,
+                              hipMemcpyHostToDevice, st));
+        MK_HIP(hipStreamSynchronize(st));
+        return MK_OK;
+    }
     if (ex.mode == 1) {
         if (!g_comm) return mk_fail(MK_ERR_COMM, "all-gather exchange without a communicator");
         const size_t cnt = (size_t)(ex.n_halo / g_nranks);
@@ -241,12 +307,29 @@ extern "C" int mk_exchange(const mk_csr *A, double *x_ext) {
         return MK_OK;
     }
     if (ex.n_halo == 0 && ex.send_total == 0) return MK_OK;
-    if (!g_comm) return mk_fail(MK_ERR_COMM, "halo exchange without a communicator");
+    if (!g_comm && !g_host.active) return mk_fail(MK_ERR_COMM, "halo exchange without a communicator");
     if (ex.send_total > 0) {
         int grid = (int)((ex.send_total + MK_BLOCK - 1) / MK_BLOCK);
         if (grid > 4096) grid = 4096;
         hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, ex.send_total, ex.d_send_idx, x_ext,
                            ex.d_send_buf);
+    }
+    if (g_host.active) {
+        int rc = g_host.reserve(&g_host.send, &g_host.send_cap, (size_t)(ex.send_total ? ex.send_total : 1));
+        if (rc == MK_OK) rc = g_host.reserve(&g_host.recv, &g_host.recv_cap, (size_t)(ex.n_halo ? ex.n_halo : 1));
+        if (rc != MK_OK) return rc;
+        if (ex.send_total > 0)
+            MK_HIP(hipMemcpyAsync(g_host.send, ex.d_send_buf, sizeof(double) * (size_t)ex.send_total,
+                                  hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        if (g_host.exchange(g_host.send, ex.send_count.data(), ex.send_off.data(), g_host.recv, ex.recv_count.data(),
+                            ex.recv_off.data()) != 0)
+            return mk_fail(MK_ERR_COMM, "host exchange callback failed");
+        if (ex.n_halo > 0)
+            MK_HIP(hipMemcpyAsync(x_ext + ex.n_local, g_host.recv, sizeof(double) * (size_t)ex.n_halo,
+                                  hipMemcpyHostToDevice, st));
+        MK_HIP(hipStreamSynchronize(st));
+        return MK_OK;
     }
     MK_NCCL(g_rccl.GroupStart());
     for (int r = 0; r < g_nranks; ++r) {

@@ -258,7 +258,7 @@ extern "C" int mk_csr_download(const mk_csr *A, int32_t *indptr, int32_t *indice
 // ======================================================================================
 // standalone SpMV and BLAS-1
 // ======================================================================================
-static MkHalt never_halt() { return MkHalt{g_halt0, 0}; }
+static MkHalt never_halt() { return MkHalt{g_halt0, 0, 0}; }
 
 extern "C" int mk_spmv(const mk_csr *A, const double *x, double *y) {
     MK_REQUIRE_INIT();

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const do
         const double tot = mk_block_sum(acc[d], s4);
         if (threadIdx.x == 0) partials[(Epi::SLOT0 + d) * MK_MAXP + blockIdx.x] = tot;
     }
+    halt.template clear_tail<Epi::NACC, Epi::SLOT0>(partials);
 }
 
 // Launch the instantiation that matches the operator: plain matrices never pay for the row program.
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_stream_kernel(Op op, int64_t n, M
         const double tot = mk_block_sum(acc[d], s4);
         if (threadIdx.x == 0) partials[(Op::SLOT0 + d) * MK_MAXP + blockIdx.x] = tot;
     }
+    halt.template clear_tail<Op::NACC, Op::SLOT0>(partials);
 }
 
 __device__ __forceinline__ double2 mk_ld2(const double *p, int64_t i) {

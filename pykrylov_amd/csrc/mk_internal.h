@@ -144,8 +144,21 @@ __device__ __forceinline__ double mk_total(const double *part, int np, double *s
 struct MkHalt {
     int *flags;      // 2 ints
     int parity;      // q & 1
+    int ptail;       // multi-rank runs: consumers add MK_MAXP entries of every (all-reduced) partial-sum slot, so a
+                     // producer clears its slots from gridDim.x up to here; 0 = nothing to clear (single rank)
     __device__ __forceinline__ bool in() const { return flags[parity] != 0; }
     __device__ __forceinline__ void out(bool v) const { flags[parity ^ 1] = v ? 1 : 0; }
+    // a slot is written by kernels of different grid sizes (stream vs SpMV) over a solve: without this, entries of
+    // the wider producer would survive, already all-reduced, behind the narrower one's
+    template <int NACC, int SLOT0>
+    __device__ __forceinline__ void clear_tail(double *partials) const {
+        if (NACC > 0 && ptail > 0 && blockIdx.x == 0) {
+#pragma unroll
+            for (int d = 0; d < NACC; ++d)
+                for (int i = (int)gridDim.x + (int)threadIdx.x; i < ptail; i += MK_BLOCK)
+                    partials[(SLOT0 + d) * MK_MAXP + i] = 0.0;
+        }
+    }
 };
 
 #endif  // __HIPCC__

@@ -74,7 +74,7 @@ struct mk_solver {
 
     int init_common(const mk_csr *A_, const mk_params *p);
     int alloc_vec(double **out, int64_t len);
-    MkHalt next_halt() { return MkHalt{d_halt, (int)(q++ & 1)}; }
+    MkHalt next_halt() { return MkHalt{d_halt, (int)(q++ & 1), mk_comm_active() ? MK_MAXP : 0}; }
     int poll();                                     // status + scalars + history -> host
     int iterate(int64_t max_iters, int64_t *done);
     int allreduce(int slot0, int nslots);           // partial sums across ranks (multi-GPU only)

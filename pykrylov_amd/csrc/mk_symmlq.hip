@@ -589,7 +589,7 @@ struct SymmlqSolver : mk_solver {
                 cg_point = 1;
             }
             if (beta1 != 0) bstep = bstep / beta1;                            // symmlq.py:369
-            const MkHalt nh{d_nohalt, 0};
+            const MkHalt nh{d_nohalt, 0, mk_comm_active() ? MK_MAXP : 0};
             hipLaunchKernelGGL(mk_stream_kernel<OpFinX>, dim3(mk_grid_stream(n)), dim3(MK_BLOCK), 0, stream,
                                OpFinX{d_w, d_b, d_x, d_prec, zbar, bstep, cg_point}, n, nh, d_part);
             if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;

@@ -127,14 +127,82 @@ class World(object):
         self.td.all_gather_object(out, obj)
         return out
 
-    def init_device_comm(self):
-        """Create the RCCL communicator inside libmikrylov (one per process)."""
+    def _init_host_comm(self, lib):
+        self._host_cbs = _host_comm_callbacks(self)          # keep the ctypes thunks alive
+        _lib.check(lib.mk_comm_init_host(self.nranks, self.rank, *self._host_cbs))
+
+    def init_device_comm(self, transport="rccl"):
+        """Create the communicator inside libmikrylov (one per process).
+
+        `transport="rccl"`: RCCL over xGMI, one process per GPU (the production path).
+        `transport="host"`: the same collectives staged through host memory and carried by `torch.distributed`
+        (any backend that moves CPU tensors, i.e. gloo) -- slow, but it lets several ranks share one GPU, which
+        RCCL refuses; used to test the multi-rank device path on a single-GPU box."""
         lib = _lib.init()
+        if transport == "host":
+            return self._init_host_comm(lib)
         buf = ctypes.create_string_buffer(128)
         if self.rank == 0:
             _lib.check(lib.mk_comm_unique_id(buf))
         uid = self.allgather_object(bytes(buf.raw))[0]
         _lib.check(lib.mk_comm_init(self.nranks, self.rank, ctypes.c_char_p(uid)))
+
+
+def _host_comm_callbacks(world):
+    """ctypes callbacks for mk_comm_init_host built on torch.distributed (CPU tensors)."""
+    import torch
+    td, nranks, rank = world.td, world.nranks, world.rank
+
+    def view(ptr, count):
+        if count == 0:
+            return torch.zeros(0, dtype=torch.float64)
+        arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), shape=(count,))
+        return torch.from_numpy(arr)
+
+    def allreduce(buf, count):
+        try:
+            if nranks > 1:
+                td.all_reduce(view(buf, count))
+            return 0
+        except Exception:                                    # pragma: no cover - reported through mk_last_error
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def exchange(send, send_count, send_off, recv, recv_count, recv_off):
+        try:
+            stotal = sum(send_count[r] for r in range(nranks))
+            rtotal = sum(recv_count[r] for r in range(nranks))
+            s, rv = view(send, stotal), view(recv, rtotal)
+            reqs = []
+            for r in range(nranks):
+                if r != rank and recv_count[r] > 0:
+                    reqs.append(td.irecv(rv[recv_off[r]:recv_off[r] + recv_count[r]], src=r))
+            for r in range(nranks):
+                if r != rank and send_count[r] > 0:
+                    reqs.append(td.isend(s[send_off[r]:send_off[r] + send_count[r]].clone(), dst=r))
+            for q in reqs:
+                q.wait()
+            return 0
+        except Exception:                                    # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def allgather(send, count, recv):
+        try:
+            out = view(recv, count * nranks)
+            if nranks > 1:
+                td.all_gather([out[r * count:(r + 1) * count] for r in range(nranks)], view(send, count).clone())
+            else:
+                out.copy_(view(send, count))
+            return 0
+        except Exception:                                    # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return (_lib.HOST_ALLREDUCE_FN(allreduce), _lib.HOST_EXCHANGE_FN(exchange), _lib.HOST_ALLGATHER_FN(allgather))
 
 
 def attach_exchange(op, mode, n_local, n_halo, send_count=None, recv_count=None, send_idx=None):

@@ -1,0 +1,132 @@
+"""Worker of tests/test_gpu_multirank.py: several ranks share ONE GPU (launched with torch.distributed.run, backend
+gloo) and run the row-partitioned device solvers through the host-staged transport (mk_comm_init_host).  Everything
+except RCCL itself is the production multi-GPU path: partition plans, column localisation on the device, the pack
+kernel, the [own | halo] vector layout, the all-reduce of the per-workgroup partial sums and the halting protocol
+taking identical decisions on every rank."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: F401,E402  (before libmikrylov: DESIGN.md section 5)
+import torch.distributed as td  # noqa: E402
+
+from oracle import csr_ref, krylov_ref as kr  # noqa: E402
+from pykrylov_amd import _lib, dist  # noqa: E402
+
+
+def rel_hist_err(h, href):
+    h, href = np.asarray(h), np.asarray(href)
+    if len(h) != len(href):
+        return float("inf")
+    return float(np.max(np.abs(h - href) / np.maximum(href, 1e-4 * href[0])))
+
+
+def gather_x(world, x_local):
+    parts = world.allgather_object(np.asarray(x_local))
+    return np.concatenate(parts)
+
+
+def main():
+    td.init_process_group(backend="gloo")
+    rank, nranks = td.get_rank(), td.get_world_size()
+    _lib.init(0)                                            # every rank on GPU 0
+    world = dist.World(rank, nranks, td)
+    world.init_device_comm(transport="host")
+    from pykrylov_amd import CG, BiCGSTAB, CGS, TFQMR, Minres, Symmlq, DiagonalOperator
+    out = {}
+
+    # ---- CG on the 3-D Poisson matrix generated per rank in HBM (the bench.py path), both exchange modes
+    m = 24
+    A = csr_ref.poisson3d(m)
+    n = m ** 3
+    rhs = A.matvec(np.ones(n))
+    ref = kr.cg(A, rhs)
+    for mode in ("halo", "allgather"):
+        op, ranges = dist.partition_poisson3d(world, m, m, m, mode=mode)
+        c0, c1 = ranges[rank]
+        s = CG(op)
+        s.solve(rhs[c0:c1])
+        x = gather_x(world, s.x)
+        out["cg3d/" + mode] = dict(nMatvec=int(s.nMatvec), ref=int(ref["nMatvec"]),
+                                   hist_err=rel_hist_err(s.residHistory, ref["residHistory"]),
+                                   x_err=float(np.linalg.norm(x - ref["x"]) / np.linalg.norm(ref["x"])),
+                                   halo=int(op.halo_size))
+        # warm start + matvec_max: setup product goes through the exchange as well
+        g = 1.0 + np.arange(n) / n
+        s2 = CG(op)
+        s2.solve(rhs[c0:c1], guess=g[c0:c1], matvec_max=30)
+        ref2 = kr.cg(A, rhs, guess=g, matvec_max=30)
+        out["cg3d_guess/" + mode] = dict(nMatvec=int(s2.nMatvec), ref=int(ref2["nMatvec"]),
+                                         hist_err=rel_hist_err(s2.residHistory, ref2["residHistory"]), x_err=0.0)
+        op.free()
+
+    # ---- general matrices through the NumPy partition plans (pack kernel with a gather list)
+    B = csr_ref.random_diagdom(2000 - 2000 % nranks + nranks * 2, seed=3)
+    nb = B.shape[0]
+    rhs_b = B.matvec(np.ones(nb))
+    dgl = 1.0 / np.array([B.data[B.indptr[i]:B.indptr[i + 1]][B.indices[B.indptr[i]:B.indptr[i + 1]] == i][0]
+                          for i in range(nb)])
+    for mode in ("halo", "allgather"):
+        if mode == "allgather" and nb % nranks:
+            continue
+        for name, cls, fn in (("bicgstab", BiCGSTAB, kr.bicgstab), ("cgs", CGS, kr.cgs), ("tfqmr", TFQMR, kr.tfqmr)):
+            op, ranges = dist.partition_host_csr(world, B.indptr, B.indices, B.data, nb, mode=mode)
+            c0, c1 = ranges[rank]
+            s = cls(op, reltol=1e-8)
+            s.solve(rhs_b[c0:c1], matvec_max=200)
+            r = fn(B, rhs_b, reltol=1e-8, matvec_max=200)
+            x = gather_x(world, s.x)
+            out["%s/%s" % (name, mode)] = dict(nMatvec=int(s.nMatvec), ref=int(r["nMatvec"]), hist_err=0.0,
+                                               x_err=float(np.linalg.norm(x - r["x"]) / np.linalg.norm(r["x"])),
+                                               conv=bool(s.converged))
+            op.free()
+        # diagonal preconditioner, sliced like every other vector
+        op, ranges = dist.partition_host_csr(world, B.indptr, B.indices, B.data, nb, mode=mode)
+        c0, c1 = ranges[rank]
+        s = BiCGSTAB(op, reltol=1e-8, precon=DiagonalOperator(dgl[c0:c1]))
+        s.solve(rhs_b[c0:c1], matvec_max=200)
+        r = kr.bicgstab(B, rhs_b, reltol=1e-8, matvec_max=200, precon=lambda v: dgl * v)
+        x = gather_x(world, s.x)
+        out["bicgstab_precon/" + mode] = dict(nMatvec=int(s.nMatvec), ref=int(r["nMatvec"]), hist_err=0.0,
+                                              x_err=float(np.linalg.norm(x - r["x"]) / np.linalg.norm(r["x"])))
+        op.free()
+
+    # ---- MINRES / SYMMLQ on a partitioned 2-D Laplacian
+    mm = 42
+    C = csr_ref.poisson2d(mm)
+    nc = mm * mm
+    rhs_c = C.matvec(np.ones(nc))
+    refm = kr.minres(C, rhs_c, check=False, etol=0.0, rtol=1e-10)
+    refs = kr.symmlq(C, rhs_c)
+    for mode in ("halo", "allgather"):
+        if mode == "allgather" and nc % nranks:
+            continue
+        op, ranges = dist.partition_host_csr(world, C.indptr, C.indices, C.data, nc, mode=mode)
+        c0, c1 = ranges[rank]
+        s = Minres(op)
+        s.solve(rhs_c[c0:c1], show=False, check=False, etol=0.0, rtol=1e-10)
+        x = gather_x(world, s.x)
+        out["minres/" + mode] = dict(nMatvec=int(s.itn), ref=int(refm["itn"]),
+                                     hist_err=rel_hist_err(s.residHistory, refm["residHistory"]),
+                                     x_err=float(np.linalg.norm(x - refm["x"]) / np.linalg.norm(refm["x"])))
+        s = Symmlq(op)
+        s.solve(rhs_c[c0:c1])
+        x = gather_x(world, s.x)
+        out["symmlq/" + mode] = dict(nMatvec=int(s.nMatvec), ref=int(refs["nMatvec"]), hist_err=0.0,
+                                     x_err=float(np.linalg.norm(x - refs["x"]) / np.linalg.norm(refs["x"])))
+        op.free()
+
+    _lib.load().mk_comm_destroy()
+    if rank == 0:
+        print("RESULT " + json.dumps(out))
+    td.barrier()
+    td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
