@@ -95,6 +95,52 @@ __global__ __launch_bounds__(MK_BLOCK) void pack_kernel(int64_t cnt, const int32
         buf[k] = x[idx[k]];
 }
 
+// a tile (256 rows) is "boundary" if one of its rows references a received entry (column >= n_local)
+__global__ __launch_bounds__(MK_BLOCK) void classify_tiles_kernel(int64_t nrows, int64_t n_local,
+                                                                  const int32_t *__restrict__ indptr,
+                                                                  const int32_t *__restrict__ indices,
+                                                                  int *__restrict__ flags) {
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        bool halo = false;
+        for (int32_t j = indptr[r]; j < indptr[r + 1]; ++j) halo |= (indices[j] >= n_local);
+        if (halo) atomicOr(&flags[r / MK_ROWS_PER_TILE], 1);
+    }
+}
+
+// interior / boundary tile lists and the second stream (halo mode with a non-empty halo)
+int build_overlap_plan(mk_csr *A) {
+    MkExchange &ex = A->ex;
+    if (getenv("MK_NO_OVERLAP") || A->ntiles < 2 || ex.n_halo == 0) return MK_OK;
+    hipStream_t st = mk_ctx().stream;
+    int *d_flags = nullptr;
+    MK_HIP(hipMalloc((void **)&d_flags, sizeof(int) * (size_t)A->ntiles));
+    MK_HIP(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)A->ntiles, st));
+    int grid = (int)((A->nrows + MK_BLOCK - 1) / MK_BLOCK);
+    grid = grid < 1 ? 1 : (grid > 65536 ? 65536 : grid);
+    hipLaunchKernelGGL(classify_tiles_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, ex.n_local, A->d_indptr,
+                       A->d_indices, d_flags);
+    std::vector<int> flags((size_t)A->ntiles);
+    MK_HIP(hipMemcpyAsync(flags.data(), d_flags, sizeof(int) * (size_t)A->ntiles, hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    MK_HIP(hipFree(d_flags));
+    std::vector<int32_t> list;
+    list.reserve((size_t)A->ntiles);
+    for (int64_t t = 0; t < A->ntiles; ++t)
+        if (!flags[t]) list.push_back((int32_t)t);
+    const int64_t n_int = (int64_t)list.size();
+    for (int64_t t = 0; t < A->ntiles; ++t)
+        if (flags[t]) list.push_back((int32_t)t);
+    if (n_int == 0 || n_int == A->ntiles) return MK_OK;      // nothing to overlap
+    MK_HIP(hipMalloc((void **)&ex.d_tiles, sizeof(int32_t) * list.size()));
+    MK_HIP(hipMemcpy(ex.d_tiles, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice));
+    ex.n_int = n_int;
+    ex.n_bnd = A->ntiles - n_int;
+    MK_HIP(hipStreamCreateWithFlags(&ex.comm_stream, hipStreamNonBlocking));
+    MK_HIP(hipEventCreateWithFlags(&ex.ev_pack, hipEventDisableTiming));
+    MK_HIP(hipEventCreateWithFlags(&ex.ev_comm, hipEventDisableTiming));
+    return MK_OK;
+}
+
 }  // namespace
 
 int mk_comm_active() { return (g_comm != nullptr || g_host.active) && g_nranks > 1; }
@@ -214,6 +260,7 @@ extern "C" int mk_csr_set_exchange(mk_csr *A, int mode, int64_t n_local, int64_t
         MK_ARG(n_halo % g_nranks == 0 && n_halo / g_nranks >= n_local);
     }
     ex.mode = mode;
+    if (mode == 0) return build_overlap_plan(A);
     return MK_OK;
 }
 
@@ -278,6 +325,59 @@ extern "C" int mk_csr_localize(mk_csr *A, int mode, int64_t col_begin, int64_t c
     A->ncols = new_cols;
     if (halo_lo) *halo_lo = lo;
     if (halo_hi) *halo_hi = hi;
+    return MK_OK;
+}
+
+// Start the exchange for the next product.  With an overlap plan the messages go to a second stream and the
+// product runs in two launches (interior tiles now, boundary tiles after mk_exchange_wait); otherwise this is the
+// plain in-stream exchange.
+int mk_exchange_begin(const mk_csr *A, double *x_ext) {
+    const MkExchange &ex = A->ex;
+    ex.pending = ex.in_flight = false;
+    if (ex.mode != 0 || !ex.d_tiles) return mk_exchange(A, x_ext);
+    if (g_host.active) {                                     // host-staged transport: synchronous, same two launches
+        int rc = mk_exchange(A, x_ext);
+        ex.pending = (rc == MK_OK);
+        return rc;
+    }
+    if (!g_comm) return mk_fail(MK_ERR_COMM, "halo exchange without a communicator");
+    hipStream_t st = mk_ctx().stream;
+    if (ex.send_total > 0) {
+        int grid = (int)((ex.send_total + MK_BLOCK - 1) / MK_BLOCK);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, ex.send_total, ex.d_send_idx, x_ext,
+                           ex.d_send_buf);
+    }
+    // the messages read the packed buffer (written above) and write only the halo part of x_ext, which no kernel
+    // touches until mk_exchange_wait; the previous exchange's messages were waited for before the buffer is reused
+    MK_HIP(hipEventRecord(ex.ev_pack, st));
+    MK_HIP(hipStreamWaitEvent(ex.comm_stream, ex.ev_pack, 0));
+    MK_NCCL(g_rccl.GroupStart());
+    for (int r = 0; r < g_nranks; ++r) {
+        if (ex.send_count[r] > 0)
+            MK_NCCL(g_rccl.Send(ex.d_send_buf + ex.send_off[r], (size_t)ex.send_count[r], ncclDouble, r, g_comm,
+                                ex.comm_stream));
+        if (ex.recv_count[r] > 0)
+            MK_NCCL(g_rccl.Recv(x_ext + ex.n_local + ex.recv_off[r], (size_t)ex.recv_count[r], ncclDouble, r, g_comm,
+                                ex.comm_stream));
+    }
+    MK_NCCL(g_rccl.GroupEnd());
+    MK_HIP(hipEventRecord(ex.ev_comm, ex.comm_stream));
+    ex.pending = ex.in_flight = true;
+    return MK_OK;
+}
+
+int mk_exchange_wait(const mk_csr *A, hipStream_t stream) {
+    const MkExchange &ex = A->ex;
+    if (ex.in_flight) MK_HIP(hipStreamWaitEvent(stream, ex.ev_comm, 0));
+    ex.pending = ex.in_flight = false;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_overlap_info(const mk_csr *A, int64_t *n_interior_tiles, int64_t *n_boundary_tiles) {
+    MK_ARG(A != nullptr);
+    if (n_interior_tiles) *n_interior_tiles = A->ex.d_tiles ? A->ex.n_int : 0;
+    if (n_boundary_tiles) *n_boundary_tiles = A->ex.d_tiles ? A->ex.n_bnd : 0;
     return MK_OK;
 }
 

@@ -229,6 +229,10 @@ extern "C" int mk_csr_destroy(mk_csr *A) {
     hipFree(A->d_data);
     hipFree(A->ex.d_send_idx);
     hipFree(A->ex.d_send_buf);
+    hipFree(A->ex.d_tiles);
+    if (A->ex.comm_stream) hipStreamDestroy(A->ex.comm_stream);
+    if (A->ex.ev_pack) hipEventDestroy(A->ex.ev_pack);
+    if (A->ex.ev_comm) hipEventDestroy(A->ex.ev_comm);
     delete A;
     return MK_OK;
 }

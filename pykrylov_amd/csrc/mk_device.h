@@ -28,6 +28,13 @@ struct MkCsrView {
     int xcd_chunks;          // 1: each XCD sweeps its own contiguous eighth of the tiles (cache-resident problems)
     int nops;                // row program of a composed operator (mk_csr_compose); 0 for a plain matrix
     mk_rowop ops[MK_ROWPROG_MAX];
+    // a launch may cover a subset of the tiles (overlap of the halo exchange, mk_comm.hip): `tiles` lists them
+    // (null: all tiles 0 .. ntl-1), `poff` is where this launch's partial sums start, `part` 0 = whole product,
+    // 1 = first of two launches, 2 = second (repeats the gate's decision without its side effects)
+    const int32_t *tiles;
+    int64_t ntl;
+    int poff;
+    int part;
 };
 
 // Working sets that fit the 256 MiB Infinity Cache profit from XCD-local tile ranges (every x line is then
@@ -50,8 +57,20 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
 }
 
 static inline MkCsrView mk_view(const mk_csr *A) {
-    MkCsrView v{A->d_indptr, A->d_indices, A->d_data, A->nrows, A->ntiles, mk_xcd_chunks(A), A->nops, {}};
+    MkCsrView v{A->d_indptr, A->d_indices, A->d_data, A->nrows, A->ntiles, mk_xcd_chunks(A), A->nops, {},
+                nullptr, A->ntiles, 0, 0};
     for (int k = 0; k < A->nops; ++k) v.ops[k] = A->ops[k];
+    return v;
+}
+
+// view of the interior (part 1) or boundary (part 2) tiles of a partitioned matrix; poff2 = grid of part 1
+static inline MkCsrView mk_view_part(const mk_csr *A, int part, int poff2) {
+    MkCsrView v = mk_view(A);
+    v.tiles = A->ex.d_tiles + (part == 2 ? A->ex.n_int : 0);
+    v.ntl = (part == 2) ? A->ex.n_bnd : A->ex.n_int;
+    v.poff = (part == 2) ? poff2 : 0;
+    v.part = part;
+    v.xcd_chunks = 0;
     return v;
 }
 
@@ -122,9 +141,9 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     const int G = gridDim.x;
     const int nxcd = (A.xcd_chunks && G % 8 == 0) ? 8 : 1;
     const int per_xcd = G / nxcd;
-    const int64_t chunk = (A.ntiles + nxcd - 1) / nxcd;
+    const int64_t chunk = (A.ntl + nxcd - 1) / nxcd;
     const int64_t chunk0 = (int64_t)(blockIdx.x % nxcd) * chunk;
-    const int64_t chunk_end = (chunk0 + chunk < A.ntiles) ? chunk0 + chunk : A.ntiles;
+    const int64_t chunk_end = (chunk0 + chunk < A.ntl) ? chunk0 + chunk : A.ntl;
 
     // Row pointers of a tile; fetched one tile ahead so that their latency is not on the critical path.
     // (one load per lane: a row's end is its neighbour's start and travels through LDS, see below)
@@ -132,9 +151,10 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         int p_lo, p_hi, my_lo;
     };
     __shared__ int sptr[MK_BLOCK + 1];
-    auto load_meta = [&](int64_t tile, Meta &m) {
+    auto load_meta = [&](int64_t pos, Meta &m) {            // pos: position in the tile list of this launch
         m.p_lo = m.p_hi = m.my_lo = 0;
-        if (tile < chunk_end) {
+        if (pos < chunk_end) {
+            const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
             const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
             const int64_t r = r0 + tid;
@@ -143,10 +163,11 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             m.my_lo = A.indptr[(r < rend) ? r : rend];      // rows past the end start (and end) at p_hi
         }
     };
-    int64_t tile = chunk0 + blockIdx.x / nxcd;
+    int64_t pos = chunk0 + blockIdx.x / nxcd;
     Meta cur, nxt;
-    load_meta(tile, cur);
-    for (; tile < chunk_end; tile += per_xcd) {
+    load_meta(pos, cur);
+    for (; pos < chunk_end; pos += per_xcd) {
+        const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
         const int64_t r0 = tile * MK_ROWS_PER_TILE;
         const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
         const int64_t r = r0 + tid;
@@ -180,7 +201,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                 col[k].w = (j + 3 < cnt) ? col[k].w : col[k].x;
             }
             if (first) {
-                load_meta(tile + per_xcd, nxt);              // next tile's row pointers go in flight now
+                load_meta(pos + per_xcd, nxt);              // next tile's row pointers go in flight now
                 first = false;
             }
             mk_d2 xv[QUADS][2];
@@ -225,7 +246,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             for (int k = 8; k < len; ++k) sum += prod[lo + k];
             __syncthreads();
         }
-        if (first) load_meta(tile + per_xcd, nxt);           // empty tile: still advance the prefetch
+        if (first) load_meta(pos + per_xcd, nxt);           // empty tile: still advance the prefetch
         if constexpr (PROG) {                                // composed operators only (separate instantiation)
             if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
         }
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const do
         return;
     }
     bool stop = false;
-    const bool go = gate.open(s4, lead, &stop);
+    const bool go = gate.open(s4, lead && A.part != 2, &stop);     // part 2 repeats the decision, not the writes
     if (lead) halt.out(stop);
     if (!go) return;
     epi.prologue(s4);
@@ -264,21 +285,27 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const do
 #pragma unroll
     for (int d = 0; d < Epi::NACC; ++d) {
         const double tot = mk_block_sum(acc[d], s4);
-        if (threadIdx.x == 0) partials[(Epi::SLOT0 + d) * MK_MAXP + blockIdx.x] = tot;
+        if (threadIdx.x == 0) partials[(Epi::SLOT0 + d) * MK_MAXP + A.poff + blockIdx.x] = tot;
     }
-    halt.template clear_tail<Epi::NACC, Epi::SLOT0>(partials);
+    if (A.part != 1) halt.template clear_tail<Epi::NACC, Epi::SLOT0>(partials, A.poff + (int)gridDim.x);
 }
 
 // Launch the instantiation that matches the operator: plain matrices never pay for the row program.
 template <class Epi, class Gate>
+static inline void mk_spmv_launch_view(const MkCsrView &v, int grid, hipStream_t st, const double *x, const Epi &epi,
+                                       const Gate &gate, MkHalt halt, double *partials) {
+    if (v.nops > 0)
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, true>), dim3(grid), dim3(MK_BLOCK), 0, st, v, x, epi, gate, halt,
+                           partials);
+    else
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, false>), dim3(grid), dim3(MK_BLOCK), 0, st, v, x, epi, gate, halt,
+                           partials);
+}
+
+template <class Epi, class Gate>
 static inline void mk_spmv_launch(const mk_csr *A, int grid, hipStream_t st, const double *x, const Epi &epi,
                                   const Gate &gate, MkHalt halt, double *partials) {
-    if (A->nops > 0)
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, true>), dim3(grid), dim3(MK_BLOCK), 0, st, mk_view(A), x, epi,
-                           gate, halt, partials);
-    else
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, false>), dim3(grid), dim3(MK_BLOCK), 0, st, mk_view(A), x, epi,
-                           gate, halt, partials);
+    mk_spmv_launch_view(mk_view(A), grid, st, x, epi, gate, halt, partials);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -74,6 +74,14 @@ struct MkExchange {
     double *d_send_buf = nullptr;  // packed values to send
     int64_t send_total = 0;
     bool contiguous_send = false;  // every rank's list is a contiguous range: send straight from x
+    // overlap of the halo exchange with the product (halo mode): tiles whose rows reference only owned columns
+    // ("interior") are multiplied while the messages travel on a second stream, the others afterwards
+    int32_t *d_tiles = nullptr;    // interior tile ids followed by boundary tile ids
+    int64_t n_int = 0, n_bnd = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
+    mutable bool pending = false;  // an exchange was started and the next product must run in two parts
+    mutable bool in_flight = false; // ... and its messages are on comm_stream (wait for ev_comm)
 };
 
 struct mk_csr {
@@ -151,11 +159,12 @@ struct MkHalt {
     // a slot is written by kernels of different grid sizes (stream vs SpMV) over a solve: without this, entries of
     // the wider producer would survive, already all-reduced, behind the narrower one's
     template <int NACC, int SLOT0>
-    __device__ __forceinline__ void clear_tail(double *partials) const {
+    __device__ __forceinline__ void clear_tail(double *partials, int first = -1) const {
         if (NACC > 0 && ptail > 0 && blockIdx.x == 0) {
+            const int from = (first >= 0) ? first : (int)gridDim.x;
 #pragma unroll
             for (int d = 0; d < NACC; ++d)
-                for (int i = (int)gridDim.x + (int)threadIdx.x; i < ptail; i += MK_BLOCK)
+                for (int i = from + (int)threadIdx.x; i < ptail; i += MK_BLOCK)
                     partials[(SLOT0 + d) * MK_MAXP + i] = 0.0;
         }
     }

@@ -25,6 +25,8 @@ constexpr int64_t MK_BATCH_MAX = 256;
 // Collective hooks (implemented in mk_comm.hip; no-ops without a communicator).
 int mk_comm_active();
 int mk_comm_allreduce_sum(double *buf_dev, int64_t count, hipStream_t stream);
+int mk_exchange_begin(const mk_csr *A, double *x_ext);     // may leave the messages in flight on a second stream
+int mk_exchange_wait(const mk_csr *A, hipStream_t stream); // ... until here
 
 struct mk_solver {
     const mk_csr *A = nullptr;
@@ -207,9 +209,18 @@ static inline int mk_launch_spmv_on(mk_solver *s, const mk_csr *M, const double 
 template <class Epi, class Gate = MkNoGate>
 static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, bool timed = true,
                                  const Gate &gate = Gate()) {
-    const int grid = mk_grid_spmv_for(s->A);
+    const mk_csr *A = s->A;
     if (timed) s->spmv_begin();
-    mk_spmv_launch(s->A, grid, s->stream, x, epi, gate, s->next_halt(), s->d_part);
+    if (A->ex.pending) {
+        // halo exchange in flight: rows that need no received entry first, the others once the messages are in
+        const int g1 = mk_grid_spmv(A->ex.n_int), g2 = mk_grid_spmv(A->ex.n_bnd);
+        mk_spmv_launch_view(mk_view_part(A, 1, 0), g1, s->stream, x, epi, gate, s->next_halt(), s->d_part);
+        int rc = mk_exchange_wait(A, s->stream);
+        if (rc != MK_OK) return rc;
+        mk_spmv_launch_view(mk_view_part(A, 2, g1), g2, s->stream, x, epi, gate, s->next_halt(), s->d_part);
+    } else {
+        mk_spmv_launch(A, mk_grid_spmv_for(A), s->stream, x, epi, gate, s->next_halt(), s->d_part);
+    }
     if (timed) s->spmv_end();
     return MK_OK;
 }

@@ -62,7 +62,7 @@ int mk_solver::allreduce(int slot0, int nslots) {
 
 int mk_solver::exchange(double *x_ext) {
     if (A->ex.mode < 0) return MK_OK;
-    return mk_exchange(A, x_ext);
+    return mk_exchange_begin(A, x_ext);                    // mk_launch_spmv completes it
 }
 
 void mk_solver::spmv_begin() {

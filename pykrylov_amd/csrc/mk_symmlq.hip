@@ -594,6 +594,7 @@ struct SymmlqSolver : mk_solver {
                                OpFinX{d_w, d_b, d_x, d_prec, zbar, bstep, cg_point}, n, nh, d_part);
             if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
             if ((rc = exchange(d_x)) != MK_OK) return rc;
+            if ((rc = mk_exchange_wait(A, stream)) != MK_OK) return rc;      // one launch over all tiles below
             mk_spmv_launch(A, mk_grid_spmv_for(A), stream, d_x, EpiFinR{d_x, d_b, prm.shift, prm.has_shift},
                            MkNoGate(), nh, d_part);
             if ((rc = allreduce(SLOT_B, 1)) != MK_OK) return rc;

@@ -3,6 +3,7 @@ gloo) and run the row-partitioned device solvers through the host-staged transpo
 except RCCL itself is the production multi-GPU path: partition plans, column localisation on the device, the pack
 kernel, the [own | halo] vector layout, the all-reduce of the per-workgroup partial sums and the halting protocol
 taking identical decisions on every rank."""
+import ctypes
 import json
 import os
 import sys
@@ -49,6 +50,13 @@ def main():
     for mode in ("halo", "allgather"):
         op, ranges = dist.partition_poisson3d(world, m, m, m, mode=mode)
         c0, c1 = ranges[rank]
+        ni, nb_ = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.load().mk_csr_overlap_info(op.handle, ctypes.byref(ni), ctypes.byref(nb_)))
+        if mode == "halo":          # the product runs as interior launch + boundary launch (1 or 2 neighbour planes)
+            assert ni.value > 0 and nb_.value in (3, 6) and ni.value + nb_.value == (c1 - c0 + 255) // 256, \
+                (ni.value, nb_.value)
+        else:
+            assert ni.value == 0 and nb_.value == 0
         s = CG(op)
         s.solve(rhs[c0:c1])
         x = gather_x(world, s.x)
