@@ -158,6 +158,9 @@ def main():
                     help="back-to-back launches of the fused SpMV kernel timed by one HIP event pair")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="host: collectives staged through host memory over gloo, all ranks on GPU 0 -- a smoke test "
+                         "of the N > 1 path on a single-GPU box, not a measurement")
     ap.add_argument("--all-configs", action="store_true",
                     help="also time BASELINE configs[2] (BiCGSTAB, random n=1e6) and configs[3] (MINRES, n=4e6)")
     ARGS = ap.parse_args()
@@ -172,19 +175,29 @@ def main():
     if world_size > 1:
         import torch
         import torch.distributed as td
-        torch.cuda.set_device(local_rank)
-        td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if ARGS.transport == "host":
+            local_rank = 0
+            td.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            td.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from pykrylov_amd import _lib, dist
     from pykrylov_amd.generic import DeviceRun
     lib = _lib.init(local_rank)
     world = dist.World(rank, world_size, td)
     if world_size > 1:
-        world.init_device_comm()
+        world.init_device_comm(transport=ARGS.transport)
 
     name = ARGS.workload
     if name == "auto":
         name = "poisson3d-512"
+
+    def barrier():
+        if ARGS.transport == "rccl":
+            td.barrier(device_ids=[local_rank])
+        else:
+            td.barrier()
 
     def run_cg(workload, steps, warmup, stride):
         op, n_global, meta = build_workload(workload, world)
@@ -200,7 +213,7 @@ def main():
         _lib.check(lib.mk_sync())
         if td is not None:
             torch.cuda.synchronize()
-            td.barrier(device_ids=[local_rank])
+            barrier()
         t0 = time.perf_counter()
         done = run.iterate(steps)
         _lib.check(lib.mk_sync())
@@ -208,10 +221,10 @@ def main():
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if td is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if ARGS.transport == "rccl" else "cpu")
             td.all_reduce(t, op=td.ReduceOp.MAX)
             elapsed = float(t.item())
-            td.barrier(device_ids=[local_rank])
+            barrier()
         timing = run.timing()
         res = run.finish()
         # dominant kernel: the loop's fused SpMV, launched back to back with one HIP-event pair around the
@@ -269,8 +282,8 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "CG %s (%d rows, %d nnz), rhs=A*1, x0=0, tolerances 0" % (name, n_g, nnz_global),
                    "solver": "cg", "rows": n_g, "nnz": nnz_global,
-                   "parallelism": "1 GPU" if world_size == 1 else "row-partition x%d, %s exchange + allreduce(dots), RCCL"
-                                  % (world_size, ARGS.exchange)},
+                   "parallelism": "1 GPU" if world_size == 1 else "row-partition x%d, %s exchange + allreduce(dots), %s"
+                                  % (world_size, ARGS.exchange, "RCCL" if ARGS.transport == "rccl" else "host-staged gloo (smoke test)")},
         "roofline": roof,
         "iteration_roofline": it_roof,
         "device_loop_ms": tm["iterate_ms"],
