@@ -879,6 +879,9 @@ struct LlsSolver : mk_solver {
     int setup(const double *rhs, const double *guess) override {
         if (guess) return mk_fail(MK_ERR_UNSUPPORTED, "the least-squares solvers start from x = 0");
         if (!At) return mk_fail(MK_ERR_STATE, "least-squares solver: call mk_solver_set_transpose first");
+        if (A->ex.mode >= 0 || At->ex.mode >= 0 || mk_comm_active())
+            return mk_fail(MK_ERR_UNSUPPORTED, "the least-squares solvers run on one GPU only: A^T u of a row-partitioned "
+                           "A needs a reduce-scatter that is not implemented");
         if (prm.window < 1 || prm.window > MAXWIN) return mk_fail(MK_ERR_ARG, "window must be in 1..%d", MAXWIN);
         use_hist2 = true;
         m = A->nrows;
