@@ -230,6 +230,11 @@ int mk_solver_set_transpose(mk_solver *s, const mk_csr *At);
  * linop.DiagonalOperator(diag) (linop.py:473-516) multiplies by.  Borrowed: it must stay alive until the solver
  * is destroyed.  NULL removes it.  Call before mk_solver_setup.  MK_ERR_UNSUPPORTED for the lls kinds. */
 int mk_solver_set_precon_diag(mk_solver *s, const double *diag);
+/* The least-squares kinds take two preconditioners, applied by the reference as `u = M(Mu)` in the m-space and
+ * `v = N(Nv)` in the n-space of the Golub-Kahan process (lls/lsqr.py:189-190,201-202,253-254,265-266 and the same
+ * lines of lsmr.py, craig.py, craigmr.py): device arrays with the diagonals of M (nrows(A) entries) and N
+ * (ncols(A) entries), either may be NULL; borrowed until the solver is destroyed.  Call before mk_solver_setup. */
+int mk_solver_set_lls_precon(mk_solver *s, const double *diag_m, const double *diag_n);
 /* Everything before the `while` loop of the reference's solve().  rhs_dev has n_local
  * entries; guess_dev may be NULL (x0 = 0).  Neither is modified. */
 int mk_solver_setup(mk_solver *s, const double *rhs_dev, const double *guess_dev);

@@ -33,32 +33,62 @@ def _hyp4(a, b, c, d):
     return sqrt(a * a + b * b + c * c + d * d)                   # lsqr.py:24 normof4
 
 
-def _gk_start(A, At, b, red, tag):
-    """First bidiagonalisation vectors (lsqr.py:190-209): beta u = b, alpha v = A' u."""
-    u = b.copy()
+class _Metric(object):
+    """The optional preconditioners of the lls solvers: callables M (m-space) and N (n-space) applied as
+    `u = M(Mu)`, `v = N(Nv)` (lsqr.py:189-190,201-202,253-254,265-266 and the same lines of lsmr / craig /
+    craigmr), together with the unpreconditioned companions Mu, Nv the reference carries along."""
+
+    def __init__(self, M=None, N=None):
+        self.M, self.N = M, N
+        self.Mu = self.Nv = None
+
+
+def _gk_start(A, At, b, red, tag, met=None):
+    """First bidiagonalisation vectors (lsqr.py:188-209): beta M u = b, alpha N v = A' u."""
+    met = met or _Metric()
+    Mu = b.copy()
+    u = met.M(Mu) if met.M is not None else Mu
     alpha = 0.0
-    v = None
-    beta = sqrt(red.dot(u, u, tag + ".beta0"))
+    v = Nv = None
+    beta = sqrt(red.dot(u, Mu, tag + ".beta0"))
     if beta > 0:
         u /= beta
-        v = At(u)
-        alpha = sqrt(red.dot(v, v, tag + ".alpha0"))
+        if met.M is not None:
+            Mu /= beta
+        Nv = At(u)
+        v = met.N(Nv) if met.N is not None else Nv
+        alpha = sqrt(red.dot(v, Nv, tag + ".alpha0"))
     if alpha > 0:
         v /= alpha
+        if met.N is not None:
+            Nv /= alpha
+    met.Mu, met.Nv = Mu, Nv
     return u, v, alpha, beta
 
 
-def _gk_step(A, At, u, v, alpha, red, tag):
-    """One bidiagonalisation step; u and v are updated in place like the aliased Mu / Nv of the reference."""
-    u_new = A(v) - alpha * u
-    beta = sqrt(red.dot(u_new, u_new, tag + ".beta"))
+def _gk_step(A, At, u, v, alpha, red, tag, met=None):
+    """One bidiagonalisation step (lsqr.py:252-272); without preconditioners u is Mu and v is Nv, as in the
+    reference, where the names alias."""
+    met = met or _Metric()
+    Mu = met.Mu if met.M is not None else u
+    Nv = met.Nv if met.N is not None else v
+    Mu_new = A(v) - alpha * Mu
+    u_new = met.M(Mu_new) if met.M is not None else Mu_new
+    beta = sqrt(red.dot(u_new, Mu_new, tag + ".beta"))
     if beta > 0:
         u_new /= beta
-        v_new = At(u_new) - beta * v
-        alpha = sqrt(red.dot(v_new, v_new, tag + ".alpha"))
+        if met.M is not None:
+            Mu_new /= beta
+        Nv_new = At(u_new) - beta * Nv
+        v_new = met.N(Nv_new) if met.N is not None else Nv_new
+        alpha = sqrt(red.dot(v_new, Nv_new, tag + ".alpha"))
         if alpha > 0:
             v_new /= alpha
+            if met.N is not None:
+                Nv_new /= alpha
         v = v_new
+        met.Nv = Nv_new
+    met.Mu = Mu_new
     return u_new, v, alpha, beta
 
 
@@ -66,7 +96,7 @@ def _gk_step(A, At, u, v, alpha, red, tag):
 # LSQR   -- reference pykrylov/lls/lsqr.py:86-453
 # --------------------------------------------------------------------------- #
 def lsqr(A, At, shape, rhs, itnlim=0, damp=0.0, atol=1.0e-9, btol=1.0e-9, conlim=1.0e+8, etol=1.0e-6,
-         window=5, red=None):
+         window=5, red=None, M=None, N=None):
     red = red or Reductions()
     m, n = shape
     if itnlim == 0:
@@ -82,7 +112,8 @@ def lsqr(A, At, shape, rhs, itnlim=0, damp=0.0, atol=1.0e-9, btol=1.0e-9, conlim
     x_nrg2 = 0.0
     d_err = np.zeros(window)
     dir_errors = []
-    u, v, alpha, beta = _gk_start(A, At, rhs[:m], red, "lsqr")
+    met = _Metric(M, N)
+    u, v, alpha, beta = _gk_start(A, At, rhs[:m], red, "lsqr", met)
     if alpha > 0:
         w = v.copy()
     x_is_zero = False
@@ -98,7 +129,7 @@ def lsqr(A, At, shape, rhs, itnlim=0, damp=0.0, atol=1.0e-9, btol=1.0e-9, conlim
     r2norm = rnorm
     while itn < itnlim and not x_is_zero:
         itn += 1
-        u, v, alpha_new, beta = _gk_step(A, At, u, v, alpha, red, "lsqr")
+        u, v, alpha_new, beta = _gk_step(A, At, u, v, alpha, red, "lsqr", met)
         if beta > 0:
             Anorm = _hyp4(Anorm, alpha, beta, damp)              # lsqr.py:262 (alpha is still the old one)
         alpha = alpha_new
@@ -203,12 +234,13 @@ def sym_ortho(a, b):
 # LSMR   -- reference pykrylov/lls/lsmr.py:64-492
 # --------------------------------------------------------------------------- #
 def lsmr(A, At, shape, b, damp=0.0, atol=1e-9, btol=1e-9, conlim=1e8, itnlim=None, etol=1.0e-6, window=5,
-         red=None):
+         red=None, M=None, N=None):
     red = red or Reductions()
     m, n = shape
     if itnlim is None:
         itnlim = min(m, n)
-    u, v, alpha, beta = _gk_start(A, At, b, red, "lsmr")
+    met = _Metric(M, N)
+    u, v, alpha, beta = _gk_start(A, At, b, red, "lsmr", met)
     if v is None:
         v = np.zeros(n)
     itn = 0
@@ -249,7 +281,7 @@ def lsmr(A, At, shape, b, damp=0.0, atol=1e-9, btol=1e-9, conlim=1e8, itnlim=Non
                     dir_errors_window=np.array(dir_errors), trace=np.array(red.trace))
     while itn < itnlim:
         itn += 1
-        u, v, alpha, beta = _gk_step(A, At, u, v, alpha, red, "lsmr")
+        u, v, alpha, beta = _gk_step(A, At, u, v, alpha, red, "lsmr", met)
         chat, shat, alphahat = sym_ortho(alphabar, damp)         # lsmr.py:338
         rhoold = rho                                             # lsmr.py:342-345
         c, s, rho = sym_ortho(alphahat, beta)
@@ -317,7 +349,7 @@ def lsmr(A, At, shape, b, damp=0.0, atol=1e-9, btol=1e-9, conlim=1e8, itnlim=Non
 # --------------------------------------------------------------------------- #
 # CRAIG   -- reference pykrylov/lls/craig.py:104-520
 # --------------------------------------------------------------------------- #
-def craig(A, At, shape, rhs, itnlim=0, atol=1.0e-9, btol=1.0e-9, etol=1.0e-6, window=5, red=None):
+def craig(A, At, shape, rhs, itnlim=0, atol=1.0e-9, btol=1.0e-9, etol=1.0e-6, window=5, red=None, M=None, N=None):
     red = red or Reductions()
     m, n = shape
     if itnlim == 0:
@@ -327,7 +359,8 @@ def craig(A, At, shape, rhs, itnlim=0, atol=1.0e-9, btol=1.0e-9, etol=1.0e-6, wi
     x_nrg2 = 0.0
     d_err = np.zeros(window)
     dir_errors = []
-    u, v, alpha, beta = _gk_start(A, At, rhs[:m], red, "craig")
+    met = _Metric(M, N)
+    u, v, alpha, beta = _gk_start(A, At, rhs[:m], red, "craig", met)
     if v is None:
         v = np.zeros(n)          # (the reference would fail on an unbound v for b = 0; irrelevant: the loop is skipped)
     x_is_zero = False
@@ -354,16 +387,26 @@ def craig(A, At, shape, rhs, itnlim=0, atol=1.0e-9, btol=1.0e-9, etol=1.0e-6, wi
     Arnorm = 0.0
     while itn < itnlim and not x_is_zero:
         itn += 1
-        u_new = A(v) - alpha * u                                 # craig.py:302-309
-        beta = sqrt(red.dot(u_new, u_new, "craig.beta"))
+        Mu = met.Mu if M is not None else u                      # craig.py:302-331
+        Nv = met.Nv if N is not None else v
+        Mu_new = A(v) - alpha * Mu
+        u_new = M(Mu_new) if M is not None else Mu_new
+        beta = sqrt(red.dot(u_new, Mu_new, "craig.beta"))
         Arnorm = abs(alpha * beta * s * zeta)
         if beta > 0:
             u_new /= beta
-            v_new = At(u_new) - beta * v
-            alpha = sqrt(red.dot(v_new, v_new, "craig.alpha"))
+            if M is not None:
+                Mu_new /= beta
+            Nv_new = At(u_new) - beta * Nv
+            v_new = N(Nv_new) if N is not None else Nv_new
+            alpha = sqrt(red.dot(v_new, Nv_new, "craig.alpha"))
             if alpha > 0:
                 v_new /= alpha
+                if N is not None:
+                    Nv_new /= alpha
             v = v_new
+            met.Nv = Nv_new
+        met.Mu = Mu_new
         u = u_new
         beta_hat = c * beta                                      # craig.py:333-342
         gamma = s * beta
@@ -414,12 +457,13 @@ def craig(A, At, shape, rhs, itnlim=0, atol=1.0e-9, btol=1.0e-9, etol=1.0e-6, wi
 # --------------------------------------------------------------------------- #
 # CRAIG-MR   -- reference pykrylov/lls/craigmr.py:51-241  (its per-iteration print at :190 is dropped)
 # --------------------------------------------------------------------------- #
-def craigmr(A, At, shape, b, itnlim=None, etol=1.0e-6, window=5, red=None):
+def craigmr(A, At, shape, b, itnlim=None, etol=1.0e-6, window=5, red=None, M=None, N=None):
     red = red or Reductions()
     m, n = shape
     if itnlim is None:
         itnlim = min(m, n)
-    u, v, alpha, beta = _gk_start(A, At, b, red, "craigmr")
+    met = _Metric(M, N)
+    u, v, alpha, beta = _gk_start(A, At, b, red, "craigmr", met)
     if v is None:
         v = np.zeros(n)
     itn = 0
@@ -438,7 +482,7 @@ def craigmr(A, At, shape, b, itnlim=None, etol=1.0e-6, window=5, red=None):
     istop = 0
     while itn < itnlim:
         itn += 1
-        u, v, alpha, beta = _gk_step(A, At, u, v, alpha, red, "craigmr")
+        u, v, alpha, beta = _gk_step(A, At, u, v, alpha, red, "craigmr", met)
         beta_hat = c * beta                                      # craigmr.py:161-170
         gamma = s * beta
         delta = sqrt(_sq(gamma) + 1)

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "mk_solver_destroy": (ctypes.c_int, [c_vp]),
     "mk_solver_set_transpose": (ctypes.c_int, [c_vp, c_vp]),
     "mk_solver_set_precon_diag": (ctypes.c_int, [c_vp, c_vp]),
+    "mk_solver_set_lls_precon": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mk_solver_setup": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mk_solver_iterate": (ctypes.c_int, [c_vp, c_i64, P(c_i64)]),
     "mk_solver_finish": (ctypes.c_int, [c_vp, P(MkResult)]),

@@ -1,4 +1,4 @@
-// mk_lls.hip -- LSQR, LSMR, CRAIG, CRAIG-MR, device resident (unpreconditioned: M = N = None).
+// mk_lls.hip -- LSQR, LSMR, CRAIG, CRAIG-MR, device resident; M and N may be diagonal preconditioners.
 // Reference: pykrylov/lls/lsqr.py:86-453, lsmr.py:64-492, craig.py:104-520, craigmr.py:51-241.
 //
 // All four run on the Golub-Kahan bidiagonalisation (lsqr.py:252-271): with u, v normalised in place,
@@ -46,17 +46,29 @@ __device__ __forceinline__ double window_test(const double *bi, double *bo, bool
 }
 
 // ------------------------------------------------------------------ bidiagonalisation kernels
-struct EpiU {        // u <- A v - alpha u ; <u,u>
+// With a diagonal M (u = M(Mu), lsqr.py:253-254) the recurrence runs on Mu and u = dm * Mu is written beside it;
+// without, u and Mu are one vector, as in the reference where the names alias.  Same for N, v and Nv.
+struct EpiU {        // Mu <- A v - alpha Mu ; u = M(Mu) ; <u, Mu>
     static constexpr int NACC = 1, SLOT0 = SLOT_UU;
     const double *blk;
     double *u;
+    const double *dm;
+    double *Mu;
     double alpha;
     __device__ void prologue(double *) { alpha = blk[B_ALPHA]; }
     __device__ double xin(double x) const { return x; }
     __device__ void row(int64_t i, double sum, double *acc) {
-        const double t = sum - alpha * u[i];                      // lsqr.py:252
-        u[i] = t;
-        acc[0] += t * t;                                          // lsqr.py:257
+        if (dm) {
+            const double t = sum - alpha * Mu[i];                 // lsqr.py:252
+            Mu[i] = t;
+            const double uu = dm[i] * t;                          // lsqr.py:254
+            u[i] = uu;
+            acc[0] += uu * t;                                     // lsqr.py:257
+        } else {
+            const double t = sum - alpha * u[i];                  // lsqr.py:252
+            u[i] = t;
+            acc[0] += t * t;                                      // lsqr.py:257
+        }
     }
 };
 
@@ -66,6 +78,7 @@ struct OpNormU {     // beta ; u /= beta
     int np;
     double *scal;
     double *u;
+    double *Mu;          // scaled as well when M is given (lsqr.py:260), else null
     double beta;
     __device__ bool prologue(double *s4, bool lead) {
         beta = __dsqrt_rn(mk_total(part + SLOT_UU * MK_MAXP, np, s4));
@@ -78,8 +91,17 @@ struct OpNormU {     // beta ; u /= beta
         v.x = v.x / beta;                                         // lsqr.py:259
         v.y = v.y / beta;
         mk_st2(u, i, v);
+        if (Mu) {
+            double2 w = mk_ld2(Mu, i);
+            w.x = w.x / beta;                                     // lsqr.py:260
+            w.y = w.y / beta;
+            mk_st2(Mu, i, w);
+        }
     }
-    __device__ void one(int64_t i, double *) { u[i] = u[i] / beta; }
+    __device__ void one(int64_t i, double *) {
+        u[i] = u[i] / beta;
+        if (Mu) Mu[i] = Mu[i] / beta;
+    }
 };
 
 struct GateV {       // the A' product happens only if beta > 0 (lsqr.py:258)
@@ -87,18 +109,51 @@ struct GateV {       // the A' product happens only if beta > 0 (lsqr.py:258)
     __device__ bool open(double *, bool, bool *) { return scal[S_BETA] > 0; }
 };
 
-struct EpiV {        // v <- A' u - beta v ; <v,v>
+struct EpiV {        // Nv <- A' u - beta Nv ; v = N(Nv) ; <v, Nv>
     static constexpr int NACC = 1, SLOT0 = SLOT_VV;
     const double *scal;
     double *v;
+    const double *dn;
+    double *Nv;
     double beta;
     __device__ void prologue(double *) { beta = scal[S_BETA]; }
     __device__ double xin(double x) const { return x; }
     __device__ void row(int64_t j, double sum, double *acc) {
-        const double t = sum - beta * v[j];                       // lsqr.py:264
-        v[j] = t;
-        acc[0] += t * t;                                          // lsqr.py:269
+        if (dn) {
+            const double t = sum - beta * Nv[j];                  // lsqr.py:264
+            Nv[j] = t;
+            const double vv = dn[j] * t;                          // lsqr.py:266
+            v[j] = vv;
+            acc[0] += vv * t;                                     // lsqr.py:269
+        } else {
+            const double t = sum - beta * v[j];                   // lsqr.py:264
+            v[j] = t;
+            acc[0] += t * t;                                      // lsqr.py:269
+        }
     }
+};
+
+struct OpScaleNv {   // Nv /= alpha where the solver's G4 did v /= alpha (lsqr.py:272): only with a preconditioner N
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *scal;
+    const double *blk;   // the state block that holds the new alpha
+    int need_beta;       // loop: the normalisation happens inside `if beta > 0` (lsqr.py:258-272)
+    double *Nv;
+    double alpha;
+    bool on;
+    __device__ bool prologue(double *, bool) {
+        alpha = blk[B_ALPHA];
+        on = (alpha > 0) && (!need_beta || scal[S_BETA] > 0);
+        return false;
+    }
+    __device__ bool skip() const { return !on; }
+    __device__ void pair(int64_t i, double *) {
+        double2 w = mk_ld2(Nv, i);
+        w.x = w.x / alpha;
+        w.y = w.y / alpha;
+        mk_st2(Nv, i, w);
+    }
+    __device__ void one(int64_t i, double *) { Nv[i] = Nv[i] / alpha; }
 };
 
 // new alpha exactly as the reference leaves it: unchanged when beta == 0
@@ -871,6 +926,8 @@ struct LlsSolver : mk_solver {
     double *d_u = nullptr, *d_v = nullptr, *d_x = nullptr;
     double *d_a = nullptr, *d_b = nullptr;      // LSQR: w ; LSMR: h, hbar ; CRAIG: w, wbar
     double *d_d = nullptr, *d_r = nullptr, *d_dbar = nullptr;
+    double *d_Mu = nullptr, *d_Nv = nullptr;     // only with preconditioners
+    const double *d_dm = nullptr, *d_dn = nullptr; // diagonals of M (m entries) and N (n entries), borrowed
     int np_A = 1, np_At = 1, np_n = 1, np_m = 1;
     int64_t itnlim = 0;
 
@@ -902,14 +959,25 @@ struct LlsSolver : mk_solver {
         for (double *p : {d_v, d_a, d_b}) MK_HIP(hipMemsetAsync(p, 0, sizeof(double) * (size_t)nn, stream));
         for (double *p : {d_d, d_r, d_dbar}) MK_HIP(hipMemsetAsync(p, 0, sizeof(double) * (size_t)m, stream));
         MK_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)(kind == MK_CRAIGMR ? m : nn), stream));
-        mk_launch_stream(this, MkOpCopy{rhs, d_u}, m);                                 // Mu = rhs.copy()   lsqr.py:190
-        mk_launch_stream(this, MkOpDot<SLOT_UU>{d_u, d_u}, m);                         // lsqr.py:197
-        mk_launch_stream(this, OpNormU{d_part, np_m, d_scal, d_u, 0.0}, m);            // u /= beta         lsqr.py:199
-        // Nv = A' u (v is zero: the epilogue's "- beta v" term vanishes exactly)       lsqr.py:202
-        mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, 0.0}, GateV{d_scal});
+        int rc2;
+        if (d_dm && !d_Mu && (rc2 = alloc_vec(&d_Mu, m))) return rc2;
+        if (d_dn && !d_Nv && (rc2 = alloc_vec(&d_Nv, nn))) return rc2;
+        if (d_Nv) MK_HIP(hipMemsetAsync(d_Nv, 0, sizeof(double) * (size_t)nn, stream));
+        if (d_dm) {
+            mk_launch_stream(this, MkOpCopy{rhs, d_Mu}, m);                            // Mu = rhs.copy()   lsqr.py:188
+            mk_launch_stream(this, MkOpMul{d_dm, d_Mu, d_u}, m);                       // u = M(Mu)         lsqr.py:190
+            mk_launch_stream(this, MkOpDot<SLOT_UU>{d_u, d_Mu}, m);                    // <u, Mu>           lsqr.py:195
+        } else {
+            mk_launch_stream(this, MkOpCopy{rhs, d_u}, m);                             // Mu = rhs.copy()   lsqr.py:188
+            mk_launch_stream(this, MkOpDot<SLOT_UU>{d_u, d_u}, m);                     // lsqr.py:195
+        }
+        mk_launch_stream(this, OpNormU{d_part, np_m, d_scal, d_u, d_dm ? d_Mu : nullptr, 0.0}, m);   // lsqr.py:197-198
+        // Nv = A' u (Nv is zero: the epilogue's "- beta Nv" term vanishes exactly)     lsqr.py:200
+        mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, d_dn, d_Nv, 0.0}, GateV{d_scal});
         hipLaunchKernelGGL(lls_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_At, d_scal, d_status,
                            next_halt(), kind, itnlim);
         mk_launch_stream(this, OpInitN{d_scal, kind, d_v, d_a, d_b, d_x, 0, 0, 0, 0}, nn);
+        if (d_dn) mk_launch_stream(this, OpScaleNv{d_scal, d_scal + S_BLK, 0, d_Nv, 0.0, false}, nn);   // lsqr.py:209
         if (kind == MK_CRAIG || kind == MK_CRAIGMR)
             mk_launch_stream(this, OpInitM{d_scal, kind, d_u, d_d, d_r, 0, 0}, m);
         return MK_OK;
@@ -922,16 +990,16 @@ struct LlsSolver : mk_solver {
         const int64_t itn = it + 1;
         // G1: u <- A v - alpha u, gated by what is left of the previous pass
         if (kind == MK_LSQR)
-            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, 0.0},
+            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0},
                               lsqr::Gate{d_part, np_n, d_scal, d_status, it, itnlim, prm.atol});
         else if (kind == MK_LSMR)
-            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, 0.0},
+            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0},
                               lsmr::Gate{d_part, np_n, d_scal, d_status, it, itnlim, prm.atol, prm.btol,
                                          prm.conlim > 0 ? 1.0 / prm.conlim : 0.0});
         else
-            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, 0.0}, craig::CountGate{d_status, it, itnlim});
-        mk_launch_stream(this, OpNormU{d_part, np_A, d_scal, d_u, 0.0}, m);                              // G2
-        mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, 0.0}, GateV{d_scal});                         // G3
+            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0}, craig::CountGate{d_status, it, itnlim});
+        mk_launch_stream(this, OpNormU{d_part, np_A, d_scal, d_u, d_dm ? d_Mu : nullptr, 0.0}, m);       // G2
+        mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, d_dn, d_Nv, 0.0}, GateV{d_scal});             // G3
         if (kind == MK_LSQR) {
             mk_launch_stream(this, lsqr::OpN{d_part, np_At, d_scal, d_status, d_hist, par, itn, prm.window, prm.damp,
                                              prm.atol, prm.btol, prm.etol, d_v, d_a, d_x, 0, 0, 0, 0, false}, nn);
@@ -947,6 +1015,7 @@ struct LlsSolver : mk_solver {
                                                 prm.etol, d_v, 0, false}, nn);
             mk_launch_stream(this, craig::OpMmr{blk_next, d_u, d_d, d_dbar, d_x, 0, 0, 0, 0, 0}, m);
         }
+        if (d_dn) mk_launch_stream(this, OpScaleNv{d_scal, blk_next, 1, d_Nv, 0.0, false}, nn);          // lsqr.py:272
         return MK_OK;
     }
 
@@ -974,8 +1043,17 @@ struct LlsSolver : mk_solver {
 
     const double *x() const override { return d_x; }
     const double *vector(int i) const override { return i == 0 ? d_r : (i == 1 ? d_u : (i == 2 ? d_v : nullptr)); }
+    int set_metric(const double *dm, const double *dn) {
+        d_dm = dm;
+        d_dn = dn;
+        return MK_OK;
+    }
 };
 
 }  // namespace
 
 mk_solver *mk_make_lls(int kind) { return new LlsSolver(kind); }
+
+int mk_lls_set_metric(mk_solver *s, const double *dm, const double *dn) {
+    return static_cast<LlsSolver *>(s)->set_metric(dm, dn);
+}

@@ -95,6 +95,7 @@ mk_solver *mk_make_tfqmr();
 mk_solver *mk_make_minres();
 mk_solver *mk_make_symmlq();
 mk_solver *mk_make_lls(int kind);
+int mk_lls_set_metric(mk_solver *s, const double *dm, const double *dn);
 
 #ifdef __HIPCC__
 // ------------------------------------------------------------------ small shared kernels

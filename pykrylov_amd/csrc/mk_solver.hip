@@ -213,6 +213,13 @@ extern "C" int mk_solver_set_precon_diag(mk_solver *s, const double *diag) {
     return MK_OK;
 }
 
+extern "C" int mk_solver_set_lls_precon(mk_solver *s, const double *diag_m, const double *diag_n) {
+    MK_ARG(s);
+    if (s->prm.kind < MK_LSQR || s->prm.kind > MK_CRAIGMR)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_solver_set_lls_precon: not a least-squares solver");
+    return mk_lls_set_metric(s, diag_m, diag_n);
+}
+
 extern "C" int mk_solver_destroy(mk_solver *s) {
     delete s;
     return MK_OK;

@@ -39,11 +39,21 @@ class _LlsBase(KrylovMethod):
                     'The iteration limit has been reached                      ',
                     'The truncated direct error is small enough, given etol    ']
 
+    def _lls_diag(self, P, size, which):
+        if P is None:
+            return None
+        diag = getattr(P, 'diag', None)
+        if diag is None or callable(diag):
+            raise NotImplementedError('%s: only diagonal preconditioners (an operator with a `.diag` array) run on the '
+                                      'device path; %s is a %s' % (self.__class__.__name__, which, type(P).__name__))
+        return as_f64_vector(diag, size, which + '.diag')
+
     def _run(self, rhs, itnlim, damp, atol, btol, conlim, M, N, kwargs, x_rows=False):
         A = self._device_operator()
-        if M is not None or N is not None:
-            raise NotImplementedError('%s: preconditioners M, N are not available on the device path yet'
-                                      % self.__class__.__name__)
+        # M and N: the reference calls them as functions, `u = M(Mu)`, `v = N(Nv)` (lsqr.py:190,202); on the device
+        # path they must be diagonal (an operator with a `.diag` array: DiagonalOperator, linop.py:473-516)
+        dm = self._lls_diag(M, A.shape[0], 'M')
+        dn = self._lls_diag(N, A.shape[1], 'N')
         if kwargs.get('wantvar', False):
             raise NotImplementedError('wantvar is broken in the reference as well (lsqr.py:155)')
         m, n = A.shape
@@ -64,8 +74,13 @@ class _LlsBase(KrylovMethod):
         p.window = int(window)
         handle = ctypes.c_void_p()
         _lib.check(lib.mk_solver_create(A.handle, ctypes.byref(p), ctypes.byref(handle)))
+        d_dm = None if dm is None else _lib.DeviceArray.from_numpy(dm)
+        d_dn = None if dn is None else _lib.DeviceArray.from_numpy(dn)
         try:
             _lib.check(lib.mk_solver_set_transpose(handle, At.handle))
+            if d_dm is not None or d_dn is not None:
+                _lib.check(lib.mk_solver_set_lls_precon(handle, None if d_dm is None else d_dm.ptr,
+                                                        None if d_dn is None else d_dn.ptr))
             _lib.check(lib.mk_solver_setup(handle, d_rhs.ptr, None))
             res = _lib.MkResult()
             _lib.check(lib.mk_solver_finish(handle, ctypes.byref(res)))
@@ -97,6 +112,9 @@ class _LlsBase(KrylovMethod):
         finally:
             lib.mk_solver_destroy(handle)
             d_rhs.free()
+            for buf in (d_dm, d_dn):
+                if buf is not None:
+                    buf.free()
         itn = int(res.itn)
         A._nMatvec += itn
         At._nMatvec += itn + (1 if res.residNorm0 > 0 else 0)

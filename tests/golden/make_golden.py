@@ -26,6 +26,7 @@ Fixture inventory:
                             `make_golden.py --only-precon` regenerates just this file and G11
   G11 composed_ops.npz      solvers on operators built with the reference's algebra (A + D, A - sigma*I,
                             alpha*A)
+  G12 lls_precon.npz        LSQR / LSMR / CRAIG / CRAIG-MR with diagonal preconditioners M, N
 """
 import contextlib
 import hashlib
@@ -323,8 +324,44 @@ def main():
                         kk + "trace": np.array(log)})
         save("composed_ops.npz", **out)
 
+    # ---------------- G12: lls solvers with diagonal M, N ------------------ #
+    def g12():
+        from pykrylov.linop import DiagonalOperator
+        out = {}
+        mm, nn = 60, 40
+        rng = np.random.default_rng(7)
+        A = canon(sp.random(mm, nn, density=0.2, random_state=rng, data_rvs=rng.standard_normal) + sp.eye(mm, nn))
+        out.update(csr_arrays(A, "A_"))
+        dm = np.linspace(0.5, 2.0, mm)
+        dn = np.linspace(3.0, 0.25, nn)
+        b_cons = A @ np.ones(nn)
+        b_ls = b_cons + 0.1 * np.random.default_rng(8).standard_normal(mm)
+        out.update(dm=dm, dn=dn, b_cons=b_cons, b_ls=b_ls)
+        for sname, mod, cls in (("lsqr", m_lsqr, "LSQRFramework"), ("lsmr", m_lsmr, "LSMRFramework"),
+                                ("craig", m_craig, "CRAIGFramework"), ("craigmr", m_craigmr, "CRAIGMRFramework")):
+            for btag, b in (("cons", b_cons), ("ls", b_ls)):
+                if sname.startswith("craig") and btag == "ls":
+                    continue
+                for ptag, kwp in (("MN", dict(M=DiagonalOperator(dm), N=DiagonalOperator(dn))),
+                                  ("M", dict(M=DiagonalOperator(dm))), ("N", dict(N=DiagonalOperator(dn)))):
+                    with traced(mod) as log:
+                        s = getattr(mod, cls)(csr_op(A))
+                        ret = quiet(s.solve, b.copy(), show=False, etol=0.0, **kwp)
+                    k = "%s_%s_%s_" % (sname, btag, ptag)
+                    rec = {k + "x": s.x, k + "trace": np.array(log)}
+                    for attr in ("istop", "itn", "nMatvec", "r1norm", "r2norm", "Anorm", "Acond", "Arnorm", "xnorm"):
+                        v = getattr(s, attr, None)
+                        if v is not None and np.isscalar(v):
+                            rec[k + attr] = v
+                    if sname == "lsmr":
+                        names = ("istop", "itn", "normr", "normar", "normA", "condA", "normx")
+                        rec.update({k + nme: val for nme, val in zip(names, ret[1:])})
+                    out.update(rec)
+        save("lls_precon.npz", **out)
+
     g10()
     g11()
+    g12()
     if "--only-precon" in sys.argv:
         shutil.rmtree(tmp, ignore_errors=True)
         return

@@ -138,3 +138,52 @@ def test_lls_edge_cases(golden):
         s.solve(d["s_b_ls"], M=op)
     with pytest.raises(NotImplementedError):
         s.solve(d["s_b_ls"], wantvar=True)
+
+
+# ------------------------------------------------------------------ diagonal preconditioners M, N
+def precon_cases():
+    for solver in ("lsqr", "lsmr", "craig", "craigmr"):
+        for btag in ("cons", "ls"):
+            if solver.startswith("craig") and btag == "ls":
+                continue
+            for ptag in ("MN", "M", "N"):
+                yield solver, btag, ptag
+
+
+@pytest.mark.parametrize("solver,btag,ptag", list(precon_cases()))
+def test_lls_diagonal_preconditioners(golden, solver, btag, ptag, monkeypatch):
+    """`u = M(Mu)`, `v = N(Nv)` with DiagonalOperators (lsqr.py:189-190,201-202,253-254,265-266 and the same lines
+    of the other three): (i) the reference's own run (fixture lls_precon.npz), (ii) bit equality with the oracle in
+    the device's summation order."""
+    from pykrylov_amd import DiagonalOperator
+    d = golden("lls_precon.npz")
+    A = golden_csr(d, "A_")
+    dm, dn = d["dm"], d["dn"]
+    b = d["b_" + btag]
+    kw_dev, kw_ref = {}, {}
+    if "M" in ptag:
+        kw_dev["M"], kw_ref["M"] = DiagonalOperator(dm), (lambda u: dm * u)
+    if "N" in ptag:
+        kw_dev["N"], kw_ref["N"] = DiagonalOperator(dn), (lambda v: dn * v)
+    got, s = run_device(solver, op_from(A), b, 0.0, 0.0, **kw_dev)
+    k = "%s_%s_%s_" % (solver, btag, ptag)
+    # these 60 x 40 runs take ~n iterations: the Golub-Kahan vectors lose orthogonality on the way and the tail is
+    # sensitive to the summation order (see test_lls_vs_golden); istop and the solution are what is comparable
+    assert got["istop"] == int(d[k + "istop"]) and abs(got["itn"] - int(d[k + "itn"])) <= 3
+    # (LSMR and CRAIG-MR stop at itnlim = min(m, n) here, short of convergence: 1e-4 between summation orders)
+    assert np.linalg.norm(got["x"] - d[k + "x"]) <= 1e-4 * np.linalg.norm(d[k + "x"])
+    monkeypatch.setattr(lls_ref, "_sq", lambda a: a * a)
+
+    class Dots(gpu_order.GpuDots):
+        def __call__(self, a, bb, site):
+            if site.endswith(".beta"):
+                return gpu_order.total(gpu_order.spmv_partials(a, bb, (A.shape[0] + 255) // 256))
+            if site.endswith(".alpha") or site.endswith(".alpha0"):
+                return gpu_order.total(gpu_order.spmv_partials(a, bb, (A.shape[1] + 255) // 256))
+            return gpu_order.stream_dot(a, bb)
+    ref = run_oracle(solver, A, b, 0.0, 0.0, red=kr.Reductions(Dots(0, [])), **kw_ref)
+    assert (got["istop"], got["itn"]) == (ref["istop"], ref["itn"])
+    assert np.array_equal(got["x"], ref["x"])
+    for key, v in got.items():
+        if key not in ("x", "r", "istop", "itn"):
+            assert v == ref[key], key

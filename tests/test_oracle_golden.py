@@ -343,3 +343,38 @@ def test_lls(golden, tag, solver, btag, damp, etol):
         assert out[name] == d[k + name].item(), name
     assert same(out["trace"], d[k + "trace"])
     assert same(out["x"], d[k + "x"])
+
+
+def _lls_precon_cases():
+    for solver in ("lsqr", "lsmr", "craig", "craigmr"):
+        for btag in ("cons", "ls"):
+            if solver.startswith("craig") and btag == "ls":
+                continue
+            for ptag in ("MN", "M", "N"):
+                yield solver, btag, ptag
+
+
+@pytest.mark.parametrize("solver,btag,ptag", list(_lls_precon_cases()))
+def test_lls_diagonal_preconditioners(golden, solver, btag, ptag):
+    """M (m-space) and N (n-space) as DiagonalOperators in the reference run (lsqr.py:189-190,201-202, ...)."""
+    from oracle import lls_ref
+    d = golden("lls_precon.npz")
+    A = csr_from(d, "A_")
+    At = A.transpose()
+    dm, dn = d["dm"], d["dn"]
+    kw = dict(etol=0.0)
+    if "M" in ptag:
+        kw["M"] = lambda u: dm * u
+    if "N" in ptag:
+        kw["N"] = lambda v: dn * v
+    b = d["b_" + btag]
+    k = "%s_%s_%s_" % (solver, btag, ptag)
+    out = getattr(lls_ref, solver)(A.matvec, At.matvec, A.shape, b.copy(), **kw)
+    names = {"lsqr": ("istop", "itn", "nMatvec", "r1norm", "r2norm", "Anorm", "Acond", "Arnorm", "xnorm"),
+             "lsmr": ("istop", "itn", "normr", "normar", "normA", "condA", "normx"),
+             "craig": ("istop", "itn", "nMatvec", "r1norm", "r2norm", "Arnorm", "xnorm"),
+             "craigmr": ("istop", "itn", "nMatvec")}[solver]
+    for name in names:
+        assert out[name] == d[k + name].item(), name
+    assert same(out["trace"], d[k + "trace"])
+    assert same(out["x"], d[k + "x"])
