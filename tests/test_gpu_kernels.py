@@ -250,3 +250,40 @@ def test_from_coo_edge_cases():
     ref = csr_ref.from_coo(rows, cols, vals, (2, 500))
     got = CsrOperator.from_coo(rows, cols, vals, (2, 500)).to_csr_arrays()
     assert np.array_equal(got[0], ref.indptr) and np.array_equal(got[1], ref.indices) and np.array_equal(got[2], ref.data)
+
+
+def test_spmv_randomised_structures_bit_exact():
+    """Fuzz over shapes and row-length patterns (seeded): empty rows at tile edges, rows straddling the 2048-entry
+    LDS chunk, totals that are not multiples of four (the kernel reads indices 16 bytes at a time), one-row and
+    one-column matrices -- product, transposed product and the fused dot against the oracle, bit for bit."""
+    from pykrylov_amd import _lib
+    lib = _lib.init()
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        m = int(rng.choice([1, 2, 255, 256, 257, 511, 513, 1000, 2049]))
+        n = int(rng.choice([1, 3, 64, 257, 1000, 4099]))
+        kind = trial % 5
+        if kind == 0:
+            lens = rng.integers(0, 9, m)
+        elif kind == 1:
+            lens = np.where(rng.random(m) < 0.7, 0, rng.integers(1, min(n, 40) + 1, m))      # mostly empty rows
+        elif kind == 2:
+            lens = np.full(m, min(n, 7))
+            lens[rng.integers(0, m)] = min(n, 3000)                                          # one long row
+        elif kind == 3:
+            lens = rng.integers(0, min(n, 300) + 1, m)                                       # chunks straddle tiles
+        else:
+            lens = np.zeros(m, dtype=np.int64)
+            lens[-1] = min(n, 5)                                                             # everything in the last row
+        lens = np.minimum(lens, n)
+        rows = np.repeat(np.arange(m), lens)
+        cols = np.concatenate([rng.choice(n, size=int(k), replace=False) for k in lens]) if rows.size else \
+            np.zeros(0, dtype=np.int64)
+        vals = rng.standard_normal(rows.size) * 10.0 ** rng.integers(-6, 6, rows.size)
+        A = csr_ref.from_coo(rows, cols, vals, (m, n))
+        op = op_from(A)
+        x = rng.standard_normal(n)
+        assert same(op * x, A.matvec(x)), (trial, m, n, kind)
+        u = rng.standard_normal(m)
+        assert same(op.T * u, A.transpose().matvec(u)), (trial, m, n, kind)
+        op.free()
