@@ -256,8 +256,14 @@ extern "C" int mk_csr_set_exchange(mk_csr *A, int mode, int64_t n_local, int64_t
                              hipMemcpyHostToDevice));
         }
     } else {
-        // all-gather: every rank contributes exactly n_halo / nranks entries (the last rank's tail is padding)
+        // all-gather: every rank contributes exactly n_halo / nranks entries; a rank that owns fewer rows (the last
+        // one when n is not a multiple of the rank count) sends a zero-padded copy
         MK_ARG(n_halo % g_nranks == 0 && n_halo / g_nranks >= n_local);
+        if (n_halo / g_nranks > n_local) {
+            ex.send_total = n_halo / g_nranks;
+            MK_HIP(hipMalloc((void **)&ex.d_send_buf, sizeof(double) * (size_t)ex.send_total));
+            MK_HIP(hipMemset(ex.d_send_buf, 0, sizeof(double) * (size_t)ex.send_total));
+        }
     }
     ex.mode = mode;
     if (mode == 0) return build_overlap_plan(A);
@@ -386,12 +392,17 @@ extern "C" int mk_exchange(const mk_csr *A, double *x_ext) {
     const MkExchange &ex = A->ex;
     if (ex.mode < 0) return MK_OK;
     hipStream_t st = mk_ctx().stream;
+    const double *ag_src = x_ext;                           // all-gather contribution of this rank
+    if (ex.mode == 1 && ex.d_send_buf) {
+        MK_HIP(hipMemcpyAsync(ex.d_send_buf, x_ext, sizeof(double) * (size_t)ex.n_local, hipMemcpyDeviceToDevice, st));
+        ag_src = ex.d_send_buf;                             // (its tail beyond n_local stays zero)
+    }
     if (ex.mode == 1 && g_host.active) {
         const size_t cnt = (size_t)(ex.n_halo / g_nranks);
         int rc = g_host.reserve(&g_host.send, &g_host.send_cap, cnt);
         if (rc == MK_OK) rc = g_host.reserve(&g_host.recv, &g_host.recv_cap, (size_t)ex.n_halo);
         if (rc != MK_OK) return rc;
-        MK_HIP(hipMemcpyAsync(g_host.send, x_ext, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
+        MK_HIP(hipMemcpyAsync(g_host.send, ag_src, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
         MK_HIP(hipStreamSynchronize(st));
         if (g_host.allgather(g_host.send, (int64_t)cnt, g_host.recv) != 0)
             return mk_fail(MK_ERR_COMM, "host all-gather callback failed");
@@ -403,7 +414,7 @@ extern "C" int mk_exchange(const mk_csr *A, double *x_ext) {
     if (ex.mode == 1) {
         if (!g_comm) return mk_fail(MK_ERR_COMM, "all-gather exchange without a communicator");
         const size_t cnt = (size_t)(ex.n_halo / g_nranks);
-        MK_NCCL(g_rccl.AllGather(x_ext, x_ext + ex.n_local, cnt, ncclDouble, g_comm, st));
+        MK_NCCL(g_rccl.AllGather(ag_src, x_ext + ex.n_local, cnt, ncclDouble, g_comm, st));
         return MK_OK;
     }
     if (ex.n_halo == 0 && ex.send_total == 0) return MK_OK;

@@ -37,9 +37,9 @@ def row_ranges(n, nranks, align=1):
 def equal_ranges(n, nranks):
     """Blocks of ceil(n / nranks) rows (the layout an all-gather needs); trailing blocks may be short."""
     cnt = -(-n // nranks)
-    if cnt * nranks != n:
-        raise NotImplementedError("all-gather exchange needs n divisible by the number of ranks "
-                                  "(got n=%d, ranks=%d); use mode='halo'" % (n, nranks))
+    if cnt * (nranks - 1) >= n:
+        raise NotImplementedError("all-gather exchange: %d rows leave a rank without rows on %d ranks; "
+                                  "use fewer ranks or mode='halo'" % (n, nranks))
     return [(min(n, r * cnt), min(n, (r + 1) * cnt)) for r in range(nranks)], cnt
 
 

@@ -44,8 +44,9 @@ def test_planning_single_rank():
     assert p["n_halo"] == 0 and p["n_local"] == 81 and np.array_equal(p["indices"], A.indices)
     q = dist.plan_host_csr(w, A.indptr, A.indices, A.data, 81, mode="allgather")
     assert q["n_halo"] == 81 and np.array_equal(q["indices"], A.indices + 81)
+    assert dist.equal_ranges(10, 4) == ([(0, 3), (3, 6), (6, 9), (9, 10)], 3)      # last block short: padded on the wire
     with pytest.raises(NotImplementedError):
-        dist.equal_ranges(10, 4)
+        dist.equal_ranges(5, 4)                                                   # would leave a rank without rows
     need = dist.banded_needs(10, 20, 3, 2)
     assert need.tolist() == [7, 8, 9, 20, 21]
     sc, rc, si = dist.halo_plan(1, [(0, 10), (10, 20), (20, 30)], [np.array([10, 11]), need, np.array([19])])
