@@ -34,6 +34,17 @@ def main():
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
         print("%-72s %7d %10.2f %6.2f%%" % (short(k), a[0], a[1] / a[0] / 1e3, 100.0 * a[1] / tot))
 
+    # idle time between consecutive dispatches of the timed loop (launch-bound or not?)
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in tr)
+    gaps = collections.defaultdict(list)
+    for (s0, e0, n0), (s1, e1, n1) in zip(ev[:-1], ev[1:]):
+        gaps[(short(n0)[:44], short(n1)[:44])].append(s1 - e0)
+    print("\n== idle gap between consecutive dispatches (pairs seen > 50 times): median / mean us")
+    for (a, b), v in sorted(gaps.items(), key=lambda kv: -len(kv[1])):
+        if len(v) > 50:
+            v.sort()
+            print("%-46s -> %-46s n=%6d  %6.2f / %6.2f" % (a, b, len(v), v[len(v) // 2] / 1e3, sum(v) / len(v) / 1e3))
+
     def counters(sub, prefix):
         rows = read_csv(os.path.join(out, sub, "**", "*counter_collection.csv"))
         acc = collections.OrderedDict()
