@@ -160,6 +160,9 @@ int mk_csr_localize(mk_csr *A, int mode, int64_t col_begin, int64_t col_end, int
                     int64_t *halo_lo, int64_t *halo_hi);
 /* x_ext_dev has n_local + n_halo entries: the rank's own slice first, received entries after. */
 int mk_exchange(const mk_csr *A, double *x_ext_dev);
+/* Sum `count` (<= 2048) host doubles over all ranks, in place; a no-op without a communicator.  For the few
+ * reductions the host side of a partitioned run needs (e.g. tools.check_symmetric, utils.py:63-85). */
+int mk_comm_allreduce_host(double *vals_host, int64_t count);
 /* Halo mode overlaps the messages with the product: tiles (256 rows) whose rows reference only owned columns are
  * multiplied while the neighbours' entries travel on a second stream, the remaining tiles afterwards.  Reports the
  * split (0, 0: no overlap plan -- single rank, all-gather mode, or every tile touches the halo). */

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "mk_csr_set_exchange": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "mk_csr_localize": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, c_i64, c_i64, P(c_i64), P(c_i64)]),
     "mk_exchange": (ctypes.c_int, [c_vp, c_vp]),
+    "mk_comm_allreduce_host": (ctypes.c_int, [P(c_f64), c_i64]),
     "mk_csr_overlap_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
     "mk_solver_create": (ctypes.c_int, [c_vp, P(MkParams), P(c_vp)]),
     "mk_solver_destroy": (ctypes.c_int, [c_vp]),

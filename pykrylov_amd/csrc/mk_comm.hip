@@ -380,6 +380,20 @@ int mk_exchange_wait(const mk_csr *A, hipStream_t stream) {
     return MK_OK;
 }
 
+extern "C" int mk_comm_allreduce_host(double *vals, int64_t count) {
+    MK_REQUIRE_INIT();
+    MK_ARG(vals != nullptr && count >= 0 && count <= MK_MAXP);
+    if (!mk_comm_active() || count == 0) return MK_OK;
+    MkContext &c = mk_ctx();
+    double *buf = c.d_scratch + 2 * MK_MAXP;                 // (the first two rows serve mk_dot / mk_nrm2)
+    MK_HIP(hipMemcpyAsync(buf, vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, c.stream));
+    int rc = mk_comm_allreduce_sum(buf, count, c.stream);
+    if (rc != MK_OK) return rc;
+    MK_HIP(hipMemcpyAsync(vals, buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipStreamSynchronize(c.stream));
+    return MK_OK;
+}
+
 extern "C" int mk_csr_overlap_info(const mk_csr *A, int64_t *n_interior_tiles, int64_t *n_boundary_tiles) {
     MK_ARG(A != nullptr);
     if (n_interior_tiles) *n_interior_tiles = A->ex.d_tiles ? A->ex.n_int : 0;

@@ -248,6 +248,7 @@ def partition_host_csr(world, indptr, indices, data, n, mode="halo"):
     from .linop import CsrOperator
     p = plan_host_csr(world, indptr, indices, data, n, mode)
     op = CsrOperator(p["indptr"], p["indices"], p["data"], (p["n_local"], p["n_local"] + p["n_halo"]))
+    op.row_range, op.global_size = tuple(p["ranges"][world.rank]), int(n)
     return attach_exchange(op, p["mode"], p["n_local"], p["n_halo"], p["send_count"], p["recv_count"],
                            p["send_idx"]), p["ranges"]
 
@@ -271,9 +272,11 @@ def partition_poisson3d(world, nx, ny, nz, mode="halo"):
         n_halo = cnt * world.nranks
         _lib.check(lib.mk_csr_localize(h, 1, c0, c1, n_halo, ctypes.byref(lo), ctypes.byref(hi)))
         op = CsrOperator.from_handle(h.value)
+        op.row_range, op.global_size = (c0, c1), n
         return attach_exchange(op, 1, n_local, n_halo), ranges
     _lib.check(lib.mk_csr_localize(h, 0, c0, c1, 0, ctypes.byref(lo), ctypes.byref(hi)))
     op = CsrOperator.from_handle(h.value)
+    op.row_range, op.global_size = (c0, c1), n
     windows = world.allgather_object((c0, c1, lo.value, hi.value))
     needs = [banded_needs(*w) for w in windows]
     send_count, recv_count, send_idx = halo_plan(world.rank, ranges, needs)

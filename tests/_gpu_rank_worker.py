@@ -125,6 +125,27 @@ def main():
                                      x_err=float(np.linalg.norm(x - refs["x"]) / np.linalg.norm(refs["x"])))
         op.free()
 
+    # ---- check=True on a partitioned operator: the symmetry test is collective (global random vector sliced per
+    # rank, exchange before each product, rank-summed inner products) and all ranks reach the same verdict
+    from pykrylov_amd.tools import check_symmetric
+    op, ranges = dist.partition_host_csr(world, C.indptr, C.indices, C.data, nc, mode="halo")
+    c0, c1 = ranges[rank]
+    assert check_symmetric(op) is True
+    s = Minres(op)
+    s.solve(rhs_c[c0:c1], show=False, check=True, etol=0.0, rtol=1e-10)
+    x = gather_x(world, s.x)
+    out["minres_check/halo"] = dict(nMatvec=int(s.itn), ref=int(refm["itn"]),
+                                    hist_err=rel_hist_err(s.residHistory, refm["residHistory"]),
+                                    x_err=float(np.linalg.norm(x - refm["x"]) / np.linalg.norm(refm["x"])))
+    op.free()
+    op, ranges = dist.partition_host_csr(world, B.indptr, B.indices, B.data, nb, mode="halo")   # nonsymmetric
+    c0, c1 = ranges[rank]
+    assert check_symmetric(op) is False
+    s = Minres(op)
+    s.solve(rhs_b[c0:c1], show=False, check=True)
+    assert s.istop == 7 and s.itn == 0, (s.istop, s.itn)                  # minres.py:186-190
+    op.free()
+
     _lib.load().mk_comm_destroy()
     if rank == 0:
         print("RESULT " + json.dumps(out))
