@@ -591,6 +591,10 @@ class CsrOperator(LinearOperator):
         return LinearOperator._combine(self, other, f)
 
     def _device_matvec(self, x):
+        if getattr(self, 'local_size', None) is not None:
+            raise NotImplementedError('a row-partitioned CsrOperator multiplies inside the device solvers only '
+                                      '(its input needs the halo exchange); use the solver classes or '
+                                      'pykrylov_amd.tools.check_symmetric')
         if x.dtype != np.float64:
             if _kind(x.dtype) not in _INT_KINDS + _REAL_KINDS:
                 raise TypeError('CsrOperator is fp64-only on the device; got %s' % x.dtype)

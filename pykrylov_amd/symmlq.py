@@ -59,6 +59,9 @@ class Symmlq(KrylovMethod):
                        has_shift=int(shift is not None), shift=float(shift or 0.0)) as run:
             run.setup()
             lib = run.lib
+            if check and getattr(op, 'local_size', None) is not None:
+                raise NotImplementedError('Symmlq: check=True is not available on a row-partitioned operator '
+                                          '(use pykrylov_amd.tools.check_symmetric, which is collective)')
             if check:
                 # symmlq.py:163-171: s = <y,y>, t = <v, A y> with v, y of the first Lanczos step;
                 # the extra product is not counted
