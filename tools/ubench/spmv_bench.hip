@@ -36,6 +36,11 @@ __device__ inline double block_sum(double v, double* s4) {
 // VAR 0: current library kernel (8B/4B loads).  VAR 1: 16B value / 8B index loads (2 nnz per lane).
 // VAR 2: VAR 1 + nontemporal matrix loads.  VAR 3: VAR 0 without the x gather (x = 1).  VAR 4: VAR 0, products
 // summed per lane without LDS (wrong rows; timing only).  XCD: 1 = XCD-contiguous tile order.
+// VAR 5/6: indices and values staged in LDS (4/8-byte loads), x gathered in the row phase.  VAR 7: VAR 0 with the
+// gather folded into an 8 KB table (always an L1 hit; timing only) and VAR 8: folded into the tile's own z-plane --
+// the two experiments that show the gather's cost is the instruction, not the miss.  VAR 9: VAR 5 with 16-byte
+// value / 8-byte index loads.  VAR 10: 16-byte index loads, 4 nonzeros per lane (what the library kernel now does).
+// VAR 11: VAR 10 + row-phase gather with the tile's own 256 x entries in LDS.
 template <int VAR, int XCD>
 __global__ __launch_bounds__(BLOCK) void spmv(const int* __restrict__ ip, const int* __restrict__ ix, const double* __restrict__ dv,
                                               const double* __restrict__ x, double* __restrict__ y, long nrows, long ntiles, double* part) {
