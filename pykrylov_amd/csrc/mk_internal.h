@@ -140,8 +140,20 @@ __device__ __forceinline__ double mk_block_sum(double v, double *s4) {
 // slots t, t+256, ... in order, then mk_block_sum.  Every workgroup of the consumer kernel
 // does this redundantly and obtains bit-identical totals, so no extra kernel or fence is needed.
 __device__ __forceinline__ double mk_total(const double *part, int np, double *s4) {
+    // all (<= MK_MAXP / MK_BLOCK = 8) loads of a lane are issued together: the partials were written by other XCDs
+    // and come from the Infinity Cache, ~1 us per round trip -- one round trip instead of up to eight.  Slots past
+    // np contribute +0.0, which leaves the running sum unchanged bit for bit.
+    constexpr int K = MK_MAXP / MK_BLOCK;
+    double t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = (int)threadIdx.x + k * MK_BLOCK;
+        t[k] = part[i < np ? i : 0];
+        t[k] = (i < np) ? t[k] : 0.0;
+    }
     double v = 0.0;
-    for (int i = threadIdx.x; i < np; i += MK_BLOCK) v += part[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v += t[k];
     return mk_block_sum(v, s4);
 }
 
