@@ -30,18 +30,27 @@ __device__ __forceinline__ double window_test(const double *bi, double *bo, bool
                                               double nrg2, double etol, int *istop) {
     const int slot = (int)(itn % window);
     double ratio = __builtin_nan("");
+    double dw[MAXWIN];                         // the whole window in one batch of loads (not one round trip each)
+#pragma unroll
+    for (int k = 0; k < MAXWIN; ++k) dw[k] = bi[B_DERR + k];
     if (itn > window) {
         double ss = 0.0;
-        for (int k = 0; k < window; ++k) {
-            const double e = (k == slot) ? val : bi[B_DERR + k];
-            ss += e * e;
+#pragma unroll
+        for (int k = 0; k < MAXWIN; ++k) {
+            if (k < window) {
+                const double e = (k == slot) ? val : dw[k];
+                ss += e * e;
+            }
         }
         const double trnc = __dsqrt_rn(ss), nrg = __dsqrt_rn(nrg2);
         ratio = trnc / nrg;
         if (trnc < etol * nrg) *istop = 8;
     }
-    if (lead)
-        for (int k = 0; k < window; ++k) bo[B_DERR + k] = (k == slot) ? val : bi[B_DERR + k];
+    if (lead) {
+#pragma unroll
+        for (int k = 0; k < MAXWIN; ++k)
+            if (k < window) bo[B_DERR + k] = (k == slot) ? val : dw[k];
+    }
     return ratio;
 }
 

@@ -175,11 +175,17 @@ struct OpK3 {
         const double xnrg2 = bi[B_XNRG2] + phi * phi;
         double derr_ratio = __builtin_nan("");
         const int slot = (int)(itn % window);
+        double dw[MAXWIN];                     // the whole window in one batch of loads (not one round trip each)
+#pragma unroll
+        for (int k = 0; k < MAXWIN; ++k) dw[k] = bi[B_DERR + k];
         if (itn > window) {
             double ss = 0.0;
-            for (int k = 0; k < window; ++k) {
-                const double e = (k == slot) ? phi : bi[B_DERR + k];
-                ss += e * e;
+#pragma unroll
+            for (int k = 0; k < MAXWIN; ++k) {
+                if (k < window) {
+                    const double e = (k == slot) ? phi : dw[k];
+                    ss += e * e;
+                }
             }
             const double trnc = __dsqrt_rn(ss);
             const double xnrg = __dsqrt_rn(xnrg2);
@@ -225,7 +231,9 @@ struct OpK3 {
             bo[B_GMIN] = gmin;
             bo[B_XNRG2] = xnrg2;
             bo[B_ISTOP] = (double)istop;
-            for (int k = 0; k < window; ++k) bo[B_DERR + k] = (k == slot) ? phi : bi[B_DERR + k];
+#pragma unroll
+            for (int k = 0; k < MAXWIN; ++k)
+                if (k < window) bo[B_DERR + k] = (k == slot) ? phi : dw[k];
             scal[S_RNORM] = rnorm;
             scal[S_ARNORM] = Arnorm;
             scal[S_ANORM] = Anorm;
