@@ -105,7 +105,27 @@ typedef struct mk_rowop {
 } mk_rowop;
 int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops, mk_csr **out);
 
+/* Storage format the products of A stream from HBM, chosen per matrix and built on the device at the first product
+ * (an acceleration structure beside the CSR arrays; results are bit-identical in every format):
+ *   0  plain CSR: 4-byte columns + 8-byte values, x gathered through L1/L2;
+ *   1  windowed tiles: per 256-row tile the referenced columns are covered by contiguous windows of x that the kernel
+ *      stages in LDS with coalesced loads; per nonzero a uint16 LDS slot replaces the column (2 + 8 bytes);
+ *   2  format 1 + value dictionary: matrices with <= 256 distinct values store one byte per value (2 + 1 bytes).
+ * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 2).  A request the matrix does not qualify for
+ * degrades silently (2 -> 1 -> 0): tiles with scattered columns always take the gather path of format 0.
+ * mk_csr_format_info reports what is in use: the format, the number of windowed tiles, the LDS chunks (128
+ * doubles each) a workgroup reserves, the dictionary size and the bytes of matrix data (everything except x and y)
+ * one product streams. */
+int mk_csr_set_format(mk_csr *A, int fmt);
+int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_windowed, int32_t *lds_chunks,
+                       int32_t *dict_size, int64_t *matrix_bytes_per_product);
+/* Launch geometry of A's product kernels (what fixes the summation order of the dots fused into them): the grid,
+ * and the tile order (0 round robin; 1 each XCD sweeps a contiguous eighth; 2 XCD-contiguous blocks per step). */
+int mk_csr_launch_info(const mk_csr *A, int32_t *grid, int32_t *tile_map);
+
 /* y = A x   (K1; `self.op * p`, pykrylov/cg/cg.py:115 and every other solver).
+ * x_dev must be 16-byte aligned and readable up to an even number of entries (one entry of slack when ncols is odd;
+ * every buffer from mk_malloc has it).
  * Per row the products are added left to right with one rounding per multiply and per
  * add, so the result is bit-identical to a scalar CSR loop. */
 int mk_spmv(const mk_csr *A, const double *x_dev, double *y_dev);

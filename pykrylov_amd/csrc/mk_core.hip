@@ -103,7 +103,7 @@ extern "C" int mk_sync(void) {
 extern "C" int mk_malloc(void **dptr, size_t bytes) {
     MK_REQUIRE_INIT();
     MK_ARG(dptr != nullptr);
-    MK_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    MK_HIP(hipMalloc(dptr, (bytes ? bytes : 16) + 16));     // slack: kernels read vectors in 16-byte pairs
     return MK_OK;
 }
 
@@ -212,6 +212,8 @@ extern "C" int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops
     }
     mk_csr *B = new mk_csr(*A);
     B->alias = true;
+    B->base = A->base ? A->base : A;
+    B->plan = MkPlan();
     for (int k = 0; k < nops; ++k) B->ops[B->nops++] = ops[k];
     *out = B;
     return MK_OK;
@@ -224,6 +226,7 @@ extern "C" int mk_csr_destroy(mk_csr *A) {
         return MK_OK;
     }
     if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+    mk_csr_plan_reset(A);
     hipFree(A->d_indptr);
     hipFree(A->d_indices);
     hipFree(A->d_data);

@@ -25,7 +25,8 @@ struct MkCsrView {
     const double *data;
     int64_t nrows;
     int64_t ntiles;
-    int xcd_chunks;          // 1: each XCD sweeps its own contiguous eighth of the tiles (cache-resident problems)
+    int map;                 // tile order: 0 round robin; 1 each XCD sweeps its own contiguous eighth of the tiles
+                             // (cache-resident problems); 2 every step of the grid is split into eight XCD-contiguous blocks
     int nops;                // row program of a composed operator (mk_csr_compose); 0 for a plain matrix
     mk_rowop ops[MK_ROWPROG_MAX];
     // a launch may cover a subset of the tiles (overlap of the halo exchange, mk_comm.hip): `tiles` lists them
@@ -35,6 +36,15 @@ struct MkCsrView {
     int64_t ntl;
     int poff;
     int part;
+    // windowed tile format (mk_format.hip); fmt 0: none of this is read
+    int fmt;                 // 0 plain CSR (gathers), 1 windows + uint16 LDS slots, 2 windows + slots + value dictionary
+    int wchunks;             // LDS chunks (128 doubles each) reserved for the x windows of a tile
+    int ndict;
+    const uint16_t *slots;   // per nonzero: position of its x entry in the tile's LDS window buffer
+    const int32_t *wg;       // per tile and wave: global start of the wave's (<= 4) window chunks; bit 0 of [0]: tile eligible
+    const uint32_t *wn;      // per tile and wave: half lengths of those chunks, one byte each
+    const uint8_t *codes;    // per nonzero: index of its value in `dict` (fmt 2)
+    const double *dict;
 };
 
 // Working sets that fit the 256 MiB Infinity Cache profit from XCD-local tile ranges (every x line is then
@@ -43,6 +53,11 @@ struct MkCsrView {
 static inline int mk_xcd_chunks(const mk_csr *A) {
     const int64_t bytes = 12 * A->nnz + 4 * (A->nrows + 1) + 8 * (A->x_len() + A->nrows) * 3;
     return bytes <= (int64_t)200 * 1024 * 1024 ? 1 : 0;
+}
+static inline int mk_tile_map(const mk_csr *A) {
+    static const char *env = getenv("MK_SPMV_MAP");
+    if (env) return atoi(env);
+    return mk_xcd_chunks(A) ? 1 : 0;
 }
 
 // SpMV grid: twice as many (smaller-share) workgroups pay off only while the problem is cache resident
@@ -56,10 +71,33 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
     return g;
 }
 
+const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
+
 static inline MkCsrView mk_view(const mk_csr *A) {
-    MkCsrView v{A->d_indptr, A->d_indices, A->d_data, A->nrows, A->ntiles, mk_xcd_chunks(A), A->nops, {},
-                nullptr, A->ntiles, 0, 0};
+    MkCsrView v{};
+    v.indptr = A->d_indptr;
+    v.indices = A->d_indices;
+    v.data = A->d_data;
+    v.nrows = A->nrows;
+    v.ntiles = A->ntiles;
+    v.map = mk_tile_map(A);
+    v.nops = A->nops;
     for (int k = 0; k < A->nops; ++k) v.ops[k] = A->ops[k];
+    v.tiles = nullptr;
+    v.ntl = A->ntiles;
+    v.poff = 0;
+    v.part = 0;
+    const MkPlan *P = mk_csr_plan(A);
+    v.fmt = P ? P->fmt : 0;
+    if (v.fmt) {
+        v.wchunks = P->wchunks;
+        v.ndict = P->ndict;
+        v.slots = P->d_slots;
+        v.wg = P->d_wg;
+        v.wn = P->d_wn;
+        v.codes = P->d_codes;
+        v.dict = P->d_dict;
+    }
     return v;
 }
 
@@ -70,7 +108,7 @@ static inline MkCsrView mk_view_part(const mk_csr *A, int part, int poff2) {
     v.ntl = (part == 2) ? A->ex.n_bnd : A->ex.n_int;
     v.poff = (part == 2) ? poff2 : 0;
     v.part = part;
-    v.xcd_chunks = 0;
+    v.map = 0;
     return v;
 }
 
@@ -112,14 +150,23 @@ __device__ __forceinline__ double mk_rowprog(const MkCsrView &A, double t, const
 }
 
 // ---------------------------------------------------------------------------------------
-// CSR-stream SpMV.  A workgroup owns 256 consecutive rows per tile.  Pass 1: all lanes walk
-// the tile's nonzeros in storage order, four per lane -- `indices` with one and `data` with two
-// 16-byte loads per lane, fully coalesced (the chunk starts at a multiple of four nonzeros so that
-// the accesses are naturally aligned; at most three entries of the previous tile are read and ignored); x is
-// gathered through L1/L2; the PRODUCTS go to LDS.  Pass 2: lane t owns row t and adds its LDS
-// segment left to right, so the per-row rounding sequence is that of a scalar CSR loop
-// (bit-identical to the oracle).  Rows longer than the LDS tile are handled by looping over
-// chunks with the running sum kept in a register.
+// CSR-stream SpMV.  A workgroup owns 256 consecutive rows per tile and forms every row sum LEFT TO RIGHT, the
+// rounding sequence of a scalar CSR loop (bit-identical to the oracle), in two passes: pass 1 walks the tile's
+// nonzeros in storage order with wide coalesced loads and leaves the PRODUCTS in LDS, pass 2 (lane t = row t) adds
+// its LDS segment in order.  Two ways of getting at x:
+//
+//  * windowed tiles (fmt 1, 2; built once per matrix by mk_format.hip).  The tile's column set is covered by a few
+//    contiguous windows of x, cut into chunks of 128 doubles; the chunks are staged in LDS with one coalesced
+//    16-byte load per lane each (chunk c by wave c % 4; everything about a chunk is wave uniform and comes from
+//    scalar loads) and pass 1 multiplies against ds_read_b64 at a per-nonzero uint16 slot.  No gather goes
+//    through the texture-address path, which is what saturates first in a CSR product on this chip, and
+//    a nonzero costs 2 (slot) + 8 (value) bytes of HBM traffic instead of 4 + 8; with a value dictionary (fmt 2,
+//    matrices with <= 256 distinct values) 2 + 1.  The whole input of the NEXT tile (matrix stream and windows)
+//    is issued into registers as soon as this tile's registers have been consumed, so it lands while the row
+//    sums are formed; two barriers per tile.
+//  * gathers (fmt 0 and every tile the builder could not cover: scattered columns, > 2048 nonzeros): four
+//    nonzeros per lane and step -- one 16-byte index load, two 16-byte value loads, four gathers through L1/L2.
+//    Rows longer than the LDS tile are handled by looping over chunks with the running sum in a register.
 //
 // Epi interface:   double xin(double xj)            value actually multiplied (e.g. s*y[j])
 //                  void   row(int64_t r, double s, double *acc)   consume the row result
@@ -131,30 +178,120 @@ struct MkHasPre : std::false_type {};
 template <class Epi>
 struct MkHasPre<Epi, std::void_t<decltype(std::declval<Epi &>().pre((int64_t)0))>> : std::true_type {};
 
-template <bool PROG, class Epi, int NACC>
-__device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
-                                              double *prod, double (&acc)[NACC]) {
+typedef unsigned mk_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned mk_u4 __attribute__((ext_vector_type(4)));
+
+// position of chunk-relative product idx in the transposed staging buffer of the windowed path: lane l writes its
+// i-th product to [i][l] (consecutive lanes, consecutive addresses: conflict-free ds_write_b64)
+__device__ __forceinline__ int mk_phys(int idx) { return (idx & 7) * MK_BLOCK + (idx >> 3); }
+
+struct MkTileMeta {
+    int p_lo, p_hi, my_lo;
+};
+
+// one tile through the gather path; `sum` is returned for row r0 + tid.  Starts and ends with the LDS free.
+template <class Epi>
+__device__ __forceinline__ double mk_tile_gather(const MkCsrView &A, const double *__restrict__ x, Epi &epi, double *prod,
+                                                 int *sptr, const MkTileMeta &cur) {
     constexpr int QUADS = MK_SPMV_TILE / (4 * MK_BLOCK);   // 2 groups of 4 nonzeros per lane per chunk
     const int tid = threadIdx.x;
-    // XCD-aware tile order (optional).  Workgroup b is dispatched to XCD b % 8 (observed,
-    // MI355X_MICROARCH.md) and each XCD has its own 4 MiB L2.  Placement only affects speed.
-    const int G = gridDim.x;
-    const int nxcd = (A.xcd_chunks && G % 8 == 0) ? 8 : 1;
-    const int per_xcd = G / nxcd;
-    const int64_t chunk = (A.ntl + nxcd - 1) / nxcd;
-    const int64_t chunk0 = (int64_t)(blockIdx.x % nxcd) * chunk;
-    const int64_t chunk_end = (chunk0 + chunk < A.ntl) ? chunk0 + chunk : A.ntl;
+    const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
+    int my_hi = p_hi;
+    double sum = 0.0;
+    for (int base = p_lo & ~3; base < p_hi; base += MK_SPMV_TILE) {
+        const int cnt = (p_hi - base < MK_SPMV_TILE) ? p_hi - base : MK_SPMV_TILE;
+        // ---- pass 1: coalesced stream of the chunk, products into LDS.  Straight-line code: loads are clamped
+        // instead of predicated and every lane stores its (possibly unused) products, so that the compiler keeps
+        // all loads of the chunk in flight together.
+        mk_i4 col[QUADS];
+        mk_d2 val[QUADS][2];
+#pragma unroll
+        for (int k = 0; k < QUADS; ++k) {
+            int j = 4 * (k * MK_BLOCK + tid);
+            j = (j < cnt) ? j : ((cnt - 1) & ~3);
+            col[k] = *reinterpret_cast<const mk_i4 *>(A.indices + base + j);
+            val[k][0] = *reinterpret_cast<const mk_d2 *>(A.data + base + j);
+            val[k][1] = *reinterpret_cast<const mk_d2 *>(A.data + base + j + 2);
+            // slots past the chunk: keep the gathers in range
+            col[k].y = (j + 1 < cnt) ? col[k].y : col[k].x;
+            col[k].z = (j + 2 < cnt) ? col[k].z : col[k].x;
+            col[k].w = (j + 3 < cnt) ? col[k].w : col[k].x;
+        }
+        mk_d2 xv[QUADS][2];
+#pragma unroll
+        for (int k = 0; k < QUADS; ++k) {
+            xv[k][0].x = x[col[k].x];
+            xv[k][0].y = x[col[k].y];
+            xv[k][1].x = x[col[k].z];
+            xv[k][1].y = x[col[k].w];
+        }
+#pragma unroll
+        for (int k = 0; k < QUADS; ++k) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                mk_d2 pr;
+                pr.x = val[k][h].x * epi.xin(xv[k][h].x);
+                pr.y = val[k][h].y * epi.xin(xv[k][h].y);
+                *reinterpret_cast<mk_d2 *>(prod + 4 * (k * MK_BLOCK + tid) + 2 * h) = pr;
+            }
+        }
+        if (base == (p_lo & ~3)) {                       // first chunk of the tile: publish the row starts
+            sptr[tid] = my_lo;
+            if (tid == 0) sptr[MK_BLOCK] = p_hi;
+        }
+        __syncthreads();
+        if (base == (p_lo & ~3)) my_hi = sptr[tid + 1];
+        // ---- pass 2: one lane per row, left-to-right sum of its segment (clamped reads + selects)
+        const int lo = ((my_lo > base) ? my_lo : base) - base;
+        const int hi = ((my_hi < base + cnt) ? my_hi : base + cnt) - base;
+        const int len = hi - lo;
+        double t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = lo + k;
+            t[k] = prod[(idx < MK_SPMV_TILE && idx >= 0) ? idx : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double s2 = sum + t[k];
+            sum = (k < len) ? s2 : sum;
+        }
+        for (int k = 8; k < len; ++k) sum += prod[lo + k];
+        __syncthreads();
+    }
+    return sum;
+}
 
-    // Row pointers of a tile; fetched one tile ahead so that their latency is not on the critical path.
-    // (one load per lane: a row's end is its neighbour's start and travels through LDS, see below)
-    struct Meta {
-        int p_lo, p_hi, my_lo;
-    };
+template <int FMT, bool PROG, class Epi, int NACC>
+__device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
+                                              double *prod, double *xw, double (&acc)[NACC]) {
+    const int tid = threadIdx.x;
+    // Tile order.  Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md) and each XCD has its own
+    // 4 MiB L2; the order only affects speed (and which rows a workgroup's partial sums cover).
+    const int G = gridDim.x;
+    const bool x8 = (G % 8 == 0);
+    int64_t pos, stride, end;
+    if (A.map == 1 && x8) {                                  // XCD b % 8 sweeps its own contiguous eighth
+        const int64_t chunk = (A.ntl + 7) / 8, c0 = (int64_t)(blockIdx.x % 8) * chunk;
+        pos = c0 + blockIdx.x / 8;
+        stride = G / 8;
+        end = (c0 + chunk < A.ntl) ? c0 + chunk : A.ntl;
+    } else if (A.map == 2 && x8) {                           // every step of the grid: eight XCD-contiguous blocks
+        pos = (int64_t)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
+        stride = G;
+        end = A.ntl;
+    } else {
+        pos = blockIdx.x;
+        stride = G;
+        end = A.ntl;
+    }
     __shared__ int sptr[MK_BLOCK + 1];
-    auto load_meta = [&](int64_t pos, Meta &m) {            // pos: position in the tile list of this launch
+    // Row pointers of a tile (one load per lane: a row's end is its neighbour's start and travels through LDS);
+    // fetched ahead so that their latency is not on the critical path.
+    auto load_meta = [&](int64_t p, MkTileMeta &m) {         // p: position in the tile list of this launch
         m.p_lo = m.p_hi = m.my_lo = 0;
-        if (pos < chunk_end) {
-            const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
+        if (p < end) {
+            const int64_t tile = A.tiles ? (int64_t)A.tiles[p] : p;
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
             const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
             const int64_t r = r0 + tid;
@@ -163,95 +300,154 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             m.my_lo = A.indptr[(r < rend) ? r : rend];      // rows past the end start (and end) at p_hi
         }
     };
-    int64_t pos = chunk0 + blockIdx.x / nxcd;
-    Meta cur, nxt;
-    load_meta(pos, cur);
-    for (; pos < chunk_end; pos += per_xcd) {
-        const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
-        const int64_t r0 = tile * MK_ROWS_PER_TILE;
-        const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
-        const int64_t r = r0 + tid;
-        if constexpr (MkHasPre<Epi>::value) {
-            if (r < rend) epi.pre(r);
+    if constexpr (FMT == 0) {
+        MkTileMeta cur, nxt;
+        load_meta(pos, cur);
+        for (; pos < end; pos += stride) {
+            const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
+            const int64_t r0 = tile * MK_ROWS_PER_TILE;
+            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
+            const int64_t r = r0 + tid;
+            if constexpr (MkHasPre<Epi>::value) {
+                if (r < rend) epi.pre(r);
+            }
+            load_meta(pos + stride, nxt);                    // next tile's row pointers go in flight now
+            double sum = mk_tile_gather(A, x, epi, prod, sptr, cur);
+            if constexpr (PROG) {                            // composed operators only (separate instantiation)
+                if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
+            }
+            if (r < rend) epi.row(r, sum, acc);
+            cur = nxt;
         }
-        const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
-        int my_hi = p_hi;
-        double sum = 0.0;
-        bool first = true;
-        for (int base = p_lo & ~3; base < p_hi; base += MK_SPMV_TILE) {
-            const int cnt = (p_hi - base < MK_SPMV_TILE) ? p_hi - base : MK_SPMV_TILE;
-            // ---- pass 1: coalesced stream of the chunk, products into LDS.  Four nonzeros per lane and step: ONE
-            // 16-byte index load, two 16-byte value loads, four gathers -- the texture-address unit, not HBM, is
-            // the busiest resource of this kernel (~30 clocks per wave-level memory instruction whatever its
-            // width; tools/ubench/l1_bench.hip), so the instruction count is what is minimised.  Straight-line
-            // code: loads are clamped instead of predicated and every lane stores its (possibly unused)
-            // products, so that the compiler keeps all loads of the chunk in flight together.
-            mk_i4 col[QUADS];
-            mk_d2 val[QUADS][2];
+    } else {
+        const int lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        struct WRegs {
+            mk_u4 s;
+            mk_d2 val[4];
+            mk_u2 code;
+            mk_d2 w[4];
+            unsigned nvw;
+            bool valid;
+        };
+        // everything a windowed tile needs from memory, into registers (no use of the values here)
+        auto issue = [&](int64_t p, const MkTileMeta &m, WRegs &R) {
+            R.valid = false;
+            R.nvw = 0;
+            if (p >= end) return;
+            const int64_t tile = A.tiles ? (int64_t)A.tiles[p] : p;
+            const mk_i4 g = *reinterpret_cast<const mk_i4 *>(A.wg + (tile * 4 + wv) * 4);
+            if (!(g.x & 1)) return;                          // the builder could not cover this tile: gather path
+            R.valid = true;
+            R.nvw = A.wn[tile * 4 + wv];
+            const int gs[4] = {g.x & ~1, g.y, g.z, g.w};
 #pragma unroll
-            for (int k = 0; k < QUADS; ++k) {
-                int j = 4 * (k * MK_BLOCK + tid);
-                j = (j < cnt) ? j : ((cnt - 1) & ~3);
-                col[k] = *reinterpret_cast<const mk_i4 *>(A.indices + base + j);
-                val[k][0] = *reinterpret_cast<const mk_d2 *>(A.data + base + j);
-                val[k][1] = *reinterpret_cast<const mk_d2 *>(A.data + base + j + 2);
-                // slots past the chunk: keep the gathers in range
-                col[k].y = (j + 1 < cnt) ? col[k].y : col[k].x;
-                col[k].z = (j + 2 < cnt) ? col[k].z : col[k].x;
-                col[k].w = (j + 3 < cnt) ? col[k].w : col[k].x;
-            }
-            if (first) {
-                load_meta(pos + per_xcd, nxt);              // next tile's row pointers go in flight now
-                first = false;
-            }
-            mk_d2 xv[QUADS][2];
-#pragma unroll
-            for (int k = 0; k < QUADS; ++k) {
-                xv[k][0].x = x[col[k].x];
-                xv[k][0].y = x[col[k].y];
-                xv[k][1].x = x[col[k].z];
-                xv[k][1].y = x[col[k].w];
-            }
-#pragma unroll
-            for (int k = 0; k < QUADS; ++k) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    mk_d2 pr;
-                    pr.x = val[k][h].x * epi.xin(xv[k][h].x);
-                    pr.y = val[k][h].y * epi.xin(xv[k][h].y);
-                    *reinterpret_cast<mk_d2 *>(prod + 4 * (k * MK_BLOCK + tid) + 2 * h) = pr;
+            for (int i = 0; i < 4; ++i) {
+                const int hc = (int)((R.nvw >> (8 * i)) & 0xffu);
+                if (hc > 0) {
+                    const int l2 = (lane < hc) ? lane : hc - 1;
+                    R.w[i] = *reinterpret_cast<const mk_d2 *>(x + gs[i] + 2 * l2);
                 }
             }
-            if (base == (p_lo & ~3)) {                       // first chunk of the tile: publish the row starts
+            const int base = m.p_lo & ~7, cnt = m.p_hi - base;           // 0 < cnt <= MK_SPMV_TILE (builder)
+            int j = 8 * tid;
+            j = (j < cnt) ? j : ((cnt - 1) & ~7);
+            R.s = *reinterpret_cast<const mk_u4 *>(A.slots + base + j);
+            if constexpr (FMT == 2) {
+                R.code = *reinterpret_cast<const mk_u2 *>(A.codes + base + j);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) R.val[h] = *reinterpret_cast<const mk_d2 *>(A.data + base + j + 2 * h);
+            }
+        };
+        __shared__ double sdict[FMT == 2 ? 256 : 1];
+        if constexpr (FMT == 2) sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // read after a barrier below
+        MkTileMeta cur, nxt, nx2;
+        WRegs R;
+        load_meta(pos, cur);
+        load_meta(pos + stride, nxt);
+        issue(pos, cur, R);
+        bool lds_busy = false;                               // products of a windowed tile may still be read by slower waves
+        for (; pos < end; pos += stride) {
+            const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
+            const int64_t r0 = tile * MK_ROWS_PER_TILE;
+            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
+            const int64_t r = r0 + tid;
+            if constexpr (MkHasPre<Epi>::value) {
+                if (r < rend) epi.pre(r);
+            }
+            double sum = 0.0;
+            if (R.valid) {
+                const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
+                const int base = p_lo & ~7;
+                // windows -> LDS (the epilogue's on-the-fly scaling of x is applied here, once per entry)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hc = (int)((R.nvw >> (8 * i)) & 0xffu);
+                    if (hc > 0) {
+                        mk_d2 v;
+                        v.x = epi.xin(R.w[i].x);
+                        v.y = epi.xin(R.w[i].y);
+                        *reinterpret_cast<mk_d2 *>(xw + (wv + 4 * i) * 128 + 2 * lane) = v;
+                    }
+                }
                 sptr[tid] = my_lo;
                 if (tid == 0) sptr[MK_BLOCK] = p_hi;
-            }
-            __syncthreads();
-            if (base == (p_lo & ~3)) my_hi = sptr[tid + 1];
-            // ---- pass 2: one lane per row, left-to-right sum of its segment (clamped reads + selects)
-            const int lo = ((my_lo > base) ? my_lo : base) - base;
-            const int hi = ((my_hi < base + cnt) ? my_hi : base + cnt) - base;
-            const int len = hi - lo;
-            double t[8];
+                __syncthreads();
+                const int my_hi = sptr[tid + 1];
+                // ---- pass 1: products of this lane's 8 nonzeros against the LDS windows
+                const unsigned sw[4] = {R.s.x, R.s.y, R.s.z, R.s.w};
+                double pr[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int idx = lo + k;
-                t[k] = prod[(idx < MK_SPMV_TILE && idx >= 0) ? idx : 0];
-            }
+                for (int h = 0; h < 4; ++h) {
+                    const double x0 = xw[sw[h] & 0xffffu], x1 = xw[sw[h] >> 16];
+                    double v0, v1;
+                    if constexpr (FMT == 2) {
+                        const unsigned cw = (h < 2) ? R.code.x : R.code.y;
+                        v0 = sdict[(cw >> (16 * (h & 1))) & 0xffu];
+                        v1 = sdict[(cw >> (16 * (h & 1) + 8)) & 0xffu];
+                    } else {
+                        v0 = R.val[h].x;
+                        v1 = R.val[h].y;
+                    }
+                    pr[2 * h] = v0 * x0;
+                    pr[2 * h + 1] = v1 * x1;
+                }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double s2 = sum + t[k];
-                sum = (k < len) ? s2 : sum;
+                for (int i = 0; i < 8; ++i) prod[i * MK_BLOCK + tid] = pr[i];
+                // the registers are free: the next tile's input goes in flight and lands during pass 2
+                load_meta(pos + 2 * stride, nx2);
+                issue(pos + stride, nxt, R);
+                __syncthreads();
+                // ---- pass 2: one lane per row, left-to-right sum of its segment
+                const int lo = my_lo - base, len = my_hi - my_lo;
+                double t[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int idx = lo + k;
+                    t[k] = prod[mk_phys((idx < MK_SPMV_TILE && idx >= 0) ? idx : 0)];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double s2 = sum + t[k];
+                    sum = (k < len) ? s2 : sum;
+                }
+                for (int k = 8; k < len; ++k) sum += prod[mk_phys(lo + k)];
+                lds_busy = true;
+            } else {
+                if (lds_busy) __syncthreads();               // slower waves may still read the previous tile's products
+                load_meta(pos + 2 * stride, nx2);
+                sum = mk_tile_gather(A, x, epi, prod, sptr, cur);
+                issue(pos + stride, nxt, R);
+                lds_busy = false;
             }
-            for (int k = 8; k < len; ++k) sum += prod[lo + k];
-            __syncthreads();
+            if constexpr (PROG) {
+                if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
+            }
+            if (r < rend) epi.row(r, sum, acc);
+            cur = nxt;
+            nxt = nx2;
         }
-        if (first) load_meta(pos + per_xcd, nxt);           // empty tile: still advance the prefetch
-        if constexpr (PROG) {                                // composed operators only (separate instantiation)
-            if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
-        }
-        if (r < rend) epi.row(r, sum, acc);
-        cur = nxt;
     }
 }
 
@@ -262,10 +458,12 @@ struct MkNoGate {
     __device__ bool open(double *, bool, bool *) { return true; }
 };
 
-template <class Epi, class Gate, bool PROG>
-__global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+template <class Epi, class Gate, bool PROG, int FMT>
+__global__ __launch_bounds__(MK_BLOCK, FMT == 0 ? 8 : (FMT == 1 ? 4 : 5)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
-    __shared__ double prod[MK_SPMV_TILE];
+    extern __shared__ __attribute__((aligned(16))) double mk_smem[];     // products [MK_SPMV_TILE], then the windows
+    double *prod = mk_smem;
+    double *xw = mk_smem + MK_SPMV_TILE;
     __shared__ double s4[4];
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -281,7 +479,7 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const do
     double acc[Epi::NACC > 0 ? Epi::NACC : 1];
 #pragma unroll
     for (int d = 0; d < (Epi::NACC > 0 ? Epi::NACC : 1); ++d) acc[d] = 0.0;
-    mk_spmv_tiles<PROG>(A, x, epi, prod, acc);
+    mk_spmv_tiles<FMT, PROG>(A, x, epi, prod, xw, acc);
 #pragma unroll
     for (int d = 0; d < Epi::NACC; ++d) {
         const double tot = mk_block_sum(acc[d], s4);
@@ -290,16 +488,28 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_spmv_kernel(MkCsrView A, const do
     if (A.part != 1) halt.template clear_tail<Epi::NACC, Epi::SLOT0>(partials, A.poff + (int)gridDim.x);
 }
 
-// Launch the instantiation that matches the operator: plain matrices never pay for the row program.
+// Launch the instantiation that matches the operator: plain matrices never pay for the row program, matrices
+// without windowed tiles never pay for the window code.
+template <class Epi, class Gate, bool PROG>
+static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t st, const double *x, const Epi &epi,
+                                      const Gate &gate, MkHalt halt, double *partials) {
+    const size_t lds = sizeof(double) * (size_t)(MK_SPMV_TILE + (v.fmt ? 128 * v.wchunks : 0));
+    if (v.fmt == 2)
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 2>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                           halt, partials);
+    else if (v.fmt == 1)
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 1>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                           halt, partials);
+    else
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 0>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                           halt, partials);
+}
+
 template <class Epi, class Gate>
 static inline void mk_spmv_launch_view(const MkCsrView &v, int grid, hipStream_t st, const double *x, const Epi &epi,
                                        const Gate &gate, MkHalt halt, double *partials) {
-    if (v.nops > 0)
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, true>), dim3(grid), dim3(MK_BLOCK), 0, st, v, x, epi, gate, halt,
-                           partials);
-    else
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, false>), dim3(grid), dim3(MK_BLOCK), 0, st, v, x, epi, gate, halt,
-                           partials);
+    if (v.nops > 0) mk_spmv_launch_fmt<Epi, Gate, true>(v, grid, st, x, epi, gate, halt, partials);
+    else mk_spmv_launch_fmt<Epi, Gate, false>(v, grid, st, x, epi, gate, halt, partials);
 }
 
 template <class Epi, class Gate>

@@ -1,0 +1,363 @@
+// mk_format.hip -- the windowed tile format of a CSR matrix (built on first use, owned by the matrix).
+//
+// The reference has no sparse format at all (the operator wraps a user callable, linop/linop.py:114,289); CSR is
+// this library's own layout and the format below is an acceleration structure BESIDE the CSR arrays, in the spirit
+// of north_star's "LDS staging of x-vector tiles": the SpMV kernel (mk_device.h) reads it instead of `indices`
+// (and, with a value dictionary, instead of `data`) for every tile the builder could cover.
+//
+//  * cover:  per 256-row tile the sorted set of referenced column PAIRS is cut into windows wherever two
+//    neighbours are more than G pairs apart (G = 4, 16, ... until the cover fits); a window is stored as chunks
+//    of 128 doubles, chunk c of a tile belonging to wave c % 4.  A tile is eligible when it has 1..2048 nonzeros
+//    (counted from the 8-aligned start of its stream) and its cover needs <= 16 chunks.  Per nonzero the builder
+//    stores the uint16 position of its x entry in the tile's LDS window buffer.
+//  * value dictionary: when the whole matrix holds <= 256 distinct values (bit patterns), `data` is replaced
+//    by one byte per nonzero that indexes the sorted dictionary -- constant-coefficient stencils, graph Laplacians,
+//    incidence matrices.  Lossless: the product multiplies exactly the same doubles.
+//
+// Everything is integer work on the device; the row sums are still formed left to right from the same products,
+// so the results do not change by a bit whichever format a tile is in.
+#include "mk_device.h"
+
+namespace {
+
+constexpr int COVER_CAP = MK_SPMV_TILE;                      // nonzeros of an eligible tile
+constexpr unsigned long long DICT_EMPTY = 0x7ff8dead00c0ffeeULL;
+constexpr int DICT_SLOTS = 512;
+
+__device__ inline void bitonic_sort_i32(int *a, int n2) {
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += MK_BLOCK) {
+                const int q = i ^ j;
+                if (q > i) {
+                    const int u = a[i], v = a[q];
+                    const bool up = ((i & k) == 0);
+                    if ((u > v) == up) {
+                        a[i] = v;
+                        a[q] = u;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// stats: [0] max chunks of a tile, [1] eligible tiles
+__global__ __launch_bounds__(MK_BLOCK) void cover_kernel(const int32_t *__restrict__ ip, const int32_t *__restrict__ ix,
+                                                         int64_t nrows, int64_t ntiles, int64_t xlen,
+                                                         int32_t *__restrict__ wg, uint32_t *__restrict__ wn,
+                                                         uint16_t *__restrict__ sl, int *__restrict__ stats) {
+    constexpr int CMAX = MK_WCHUNKS_MAX;
+    __shared__ int key[COVER_CAP];
+    __shared__ int heads[CMAX + 1];
+    __shared__ int wst[CMAX], wof[CMAX];
+    __shared__ int nh, s_ok, s_nw;
+    const int tid = threadIdx.x;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * MK_ROWS_PER_TILE;
+        const int64_t rend = (r0 + MK_ROWS_PER_TILE < nrows) ? r0 + MK_ROWS_PER_TILE : nrows;
+        const int p_lo = ip[r0], p_hi = ip[rend], cnt = p_hi - p_lo;
+        __syncthreads();                                     // previous tile's shared state is no longer read
+        if (tid < CMAX) wg[tile * CMAX + tid] = 0;
+        if (tid < 4) wn[tile * 4 + tid] = 0;
+        if (cnt <= 0 || p_hi - (p_lo & ~7) > MK_SPMV_TILE) continue;
+        int n2 = 2;
+        while (n2 < cnt) n2 <<= 1;
+        for (int i = tid; i < n2; i += MK_BLOCK) key[i] = (i < cnt) ? (ix[p_lo + i] >> 1) : 0x7fffffff;
+        __syncthreads();
+        bitonic_sort_i32(key, n2);
+        bool done = false;
+        for (int G = 4; G <= 16384 && !done; G <<= 2) {
+            if (tid == 0) nh = 0;
+            __syncthreads();
+            for (int i = tid; i < cnt; i += MK_BLOCK)
+                if (i == 0 || key[i] - key[i - 1] > G) {
+                    const int q = atomicAdd(&nh, 1);
+                    if (q < CMAX) heads[q] = i;
+                }
+            __syncthreads();
+            if (tid == 0) {
+                bool ok = (nh <= CMAX);
+                const int nw = nh;
+                if (ok) {
+                    for (int a = 1; a < nw; ++a) {           // the (<= 16) window heads in ascending order
+                        const int v = heads[a];
+                        int b = a - 1;
+                        while (b >= 0 && heads[b] > v) {
+                            heads[b + 1] = heads[b];
+                            --b;
+                        }
+                        heads[b + 1] = v;
+                    }
+                    heads[nw] = cnt;
+                    int C = 0;
+                    for (int k = 0; k < nw; ++k) {
+                        const int st = key[heads[k]] * 2, en = (key[heads[k + 1] - 1] + 1) * 2;
+                        wst[k] = st;
+                        wof[k] = C * MK_WCHUNK;
+                        C += (en - st + MK_WCHUNK - 1) / MK_WCHUNK;
+                        if ((int64_t)en > xlen) ok = false; // the pair load of the last column would leave x
+                    }
+                    ok = ok && C <= CMAX;                    // (a wider gap may still merge many tiny windows)
+                    if (ok) {
+                        unsigned lens[4] = {0, 0, 0, 0};
+                        for (int k = 0; k < nw; ++k) {
+                            const int en = (key[heads[k + 1] - 1] + 1) * 2;
+                            for (int c = wof[k] / MK_WCHUNK, g = wst[k]; g < en; ++c, g += MK_WCHUNK) {
+                                const int wv = c & 3, i = c >> 2;
+                                const int half = ((en - g < MK_WCHUNK) ? en - g : MK_WCHUNK) / 2;
+                                wg[tile * CMAX + wv * 4 + i] = g;
+                                lens[wv] |= (unsigned)half << (8 * i);
+                            }
+                        }
+                        for (int w = 0; w < 4; ++w) {
+                            wn[tile * 4 + w] = lens[w];
+                            wg[tile * CMAX + w * 4] |= 1;    // bit 0 of every wave's first start: tile is eligible
+                        }
+                        atomicMax(&stats[0], C);
+                        atomicAdd(&stats[1], 1);
+                    }
+                }
+                s_ok = ok ? 1 : 0;
+                s_nw = nw;
+            }
+            __syncthreads();
+            done = (s_ok != 0);
+            __syncthreads();
+        }
+        if (done) {
+            const int nw = s_nw;
+            for (int j = tid; j < cnt; j += MK_BLOCK) {
+                const int col = ix[p_lo + j];
+                int k = 0;
+                for (int q = 1; q < nw; ++q) k += (wst[q] <= col) ? 1 : 0;
+                sl[p_lo + j] = (uint16_t)(wof[k] + col - wst[k]);
+            }
+        }
+    }
+}
+
+__device__ inline unsigned dict_hash(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 29;
+    return (unsigned)k & (DICT_SLOTS - 1);
+}
+
+// state: [0] distinct values so far, [1] gave up (more than 256, or the sentinel pattern occurs in the data)
+__global__ __launch_bounds__(MK_BLOCK) void dict_collect(int64_t nnz, const double *__restrict__ data,
+                                                         unsigned long long *table, int *state) {
+    unsigned long long seen0 = DICT_EMPTY, seen1 = DICT_EMPTY;     // the two values this lane confirmed last
+    for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * MK_BLOCK) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(data[j]);
+        if (key == seen0 || key == seen1) continue;
+        if (key == DICT_EMPTY || __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            state[1] = 1;
+            return;
+        }
+        unsigned h = dict_hash(key);
+        for (int probe = 0; probe < DICT_SLOTS; ++probe) {
+            unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == DICT_EMPTY) {
+                cur = atomicCAS(&table[h], DICT_EMPTY, key);
+                if (cur == DICT_EMPTY) {
+                    if (atomicAdd(&state[0], 1) + 1 > 256) state[1] = 1;
+                    cur = key;
+                }
+            }
+            if (cur == key) break;
+            h = (h + 1) & (DICT_SLOTS - 1);
+        }
+        seen1 = seen0;
+        seen0 = key;
+    }
+}
+
+// one workgroup: the distinct values in ascending order of their bit patterns -> dict[0 .. count)
+__global__ __launch_bounds__(MK_BLOCK) void dict_finalize(const unsigned long long *table, const int *state, double *dict) {
+    __shared__ unsigned long long k[DICT_SLOTS];
+    for (int i = threadIdx.x; i < DICT_SLOTS; i += MK_BLOCK) k[i] = (table[i] == DICT_EMPTY) ? ~0ULL : table[i];
+    __syncthreads();
+    for (int kk = 2; kk <= DICT_SLOTS; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < DICT_SLOTS; i += MK_BLOCK) {
+                const int q = i ^ j;
+                if (q > i) {
+                    const unsigned long long u = k[i], v = k[q];
+                    const bool up = ((i & kk) == 0);
+                    if ((u > v) == up) {
+                        k[i] = v;
+                        k[q] = u;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const int count = state[0];
+    if (threadIdx.x < 256) dict[threadIdx.x] = (threadIdx.x < count) ? __longlong_as_double((long long)k[threadIdx.x]) : 0.0;
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void dict_encode(int64_t nnz, const double *__restrict__ data,
+                                                        const double *__restrict__ dict, int count,
+                                                        uint8_t *__restrict__ codes) {
+    __shared__ unsigned long long k[256];
+    k[threadIdx.x] = (threadIdx.x < count) ? (unsigned long long)__double_as_longlong(dict[threadIdx.x]) : ~0ULL;
+    __syncthreads();
+    for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * MK_BLOCK) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(data[j]);
+        int lo = 0;                                          // largest index with k[lo] <= key (the key is present)
+#pragma unroll
+        for (int step = 128; step >= 1; step >>= 1)
+            if (lo + step < 256 && k[lo + step] <= key) lo += step;
+        codes[j] = (uint8_t)lo;
+    }
+}
+
+void plan_free(MkPlan &P) {
+    hipFree(P.d_slots);
+    hipFree(P.d_wg);
+    hipFree(P.d_wn);
+    hipFree(P.d_codes);
+    hipFree(P.d_dict);
+    P = MkPlan();
+}
+
+int default_format() {
+    static int f = [] {
+        const char *e = getenv("MK_SPMV_FORMAT");
+        int v = e ? atoi(e) : 2;
+        return v < 0 ? 0 : (v > 2 ? 2 : v);
+    }();
+    return f;
+}
+
+// build the plan of an owning (non-alias) matrix; on any failure the matrix stays on the plain CSR path
+int plan_build(const mk_csr *A) {
+    MkPlan &P = A->plan;
+    P.built = true;
+    P.fmt = 0;
+    const int want = A->want_fmt >= 0 ? A->want_fmt : default_format();
+    if (want == 0 || A->nnz == 0 || A->ntiles == 0 || !mk_ctx().ready) return MK_OK;
+    hipStream_t st = mk_ctx().stream;
+    const size_t pad = (size_t)A->nnz + MK_CSR_PAD;
+    int *d_stats = nullptr;
+    unsigned long long *d_table = nullptr;
+    auto fail = [&](const char *what) {
+        hipFree(d_stats);
+        hipFree(d_table);
+        plan_free(P);
+        P.built = true;
+        return mk_fail(MK_ERR_HIP, "windowed format: %s failed (the matrix stays on the CSR path)", what);
+    };
+    if (hipMalloc((void **)&P.d_slots, sizeof(uint16_t) * pad) != hipSuccess ||
+        hipMalloc((void **)&P.d_wg, sizeof(int32_t) * MK_WCHUNKS_MAX * (size_t)A->ntiles) != hipSuccess ||
+        hipMalloc((void **)&P.d_wn, sizeof(uint32_t) * 4 * (size_t)A->ntiles) != hipSuccess ||
+        hipMalloc((void **)&d_stats, 4 * sizeof(int)) != hipSuccess)
+        return fail("hipMalloc");
+    if (hipMemsetAsync(P.d_slots, 0, sizeof(uint16_t) * pad, st) != hipSuccess ||
+        hipMemsetAsync(d_stats, 0, 4 * sizeof(int), st) != hipSuccess)
+        return fail("hipMemset");
+    int grid = (int)(A->ntiles < 4096 ? A->ntiles : 4096);
+    hipLaunchKernelGGL(cover_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, A->d_indptr, A->d_indices, A->nrows, A->ntiles,
+                       A->x_len(), P.d_wg, P.d_wn, P.d_slots, d_stats);
+    int h_stats[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail("cover kernel");
+    hipFree(d_stats);
+    d_stats = nullptr;
+    P.wchunks = h_stats[0];
+    P.covered = h_stats[1];
+    if (2 * P.covered < A->ntiles) {                         // mostly scattered columns: not worth the second code path
+        plan_free(P);
+        P.built = true;
+        return MK_OK;
+    }
+    P.fmt = 1;
+    if (want < 2) return MK_OK;
+    // ---- value dictionary
+    int h_state[2] = {0, 0};
+    if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS + 2 * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&P.d_dict, sizeof(double) * 256) != hipSuccess)
+        return fail("hipMalloc");
+    int *d_state = reinterpret_cast<int *>(d_table + DICT_SLOTS);
+    std::vector<unsigned long long> empty(DICT_SLOTS, DICT_EMPTY);
+    if (hipMemcpyAsync(d_table, empty.data(), sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(d_state, 0, 2 * sizeof(int), st) != hipSuccess)
+        return fail("dictionary setup");
+    grid = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
+    grid = grid > 4096 ? 4096 : grid;
+    hipLaunchKernelGGL(dict_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, d_table, d_state);
+    if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail("dictionary kernel");
+    if (h_state[1] || h_state[0] > 256 || h_state[0] < 1) {  // too many distinct values: windows with raw values
+        hipFree(d_table);
+        hipFree(P.d_dict);
+        P.d_dict = nullptr;
+        return MK_OK;
+    }
+    if (hipMalloc((void **)&P.d_codes, pad) != hipSuccess) return fail("hipMalloc");
+    hipMemsetAsync(P.d_codes, 0, pad, st);
+    hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, P.d_dict);
+    hipLaunchKernelGGL(dict_encode, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, P.d_dict, h_state[0], P.d_codes);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail("dictionary encode");
+    hipFree(d_table);
+    P.ndict = h_state[0];
+    P.fmt = 2;
+    return MK_OK;
+}
+
+}  // namespace
+
+const MkPlan *mk_csr_plan(const mk_csr *A) {
+    const mk_csr *owner = A->base ? A->base : A;
+    if (!owner->plan.built) plan_build(owner);
+    return &owner->plan;
+}
+
+void mk_csr_plan_reset(const mk_csr *A) {
+    plan_free(A->plan);
+}
+
+extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 2);
+    if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_format: set the format on the matrix a composed operator was built from");
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    plan_free(A->plan);
+    A->want_fmt = fmt;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_windowed, int32_t *lds_chunks,
+                                  int32_t *dict_size, int64_t *matrix_bytes_per_product) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr);
+    const MkPlan *P = mk_csr_plan(A);
+    if (fmt) *fmt = P->fmt;
+    if (tiles_windowed) *tiles_windowed = P->fmt ? P->covered : 0;
+    if (lds_chunks) *lds_chunks = P->fmt ? P->wchunks : 0;
+    if (dict_size) *dict_size = P->ndict;
+    if (matrix_bytes_per_product) {
+        // bytes of matrix data one product streams from HBM (x and y not included): per nonzero 4 + 8 (CSR),
+        // 2 + 8 (windows) or 2 + 1 (windows + dictionary), plus row pointers and the window descriptors
+        int64_t b = 4 * (A->nrows + 1);
+        if (P->fmt == 0) b += 12 * A->nnz;
+        else {
+            // nonzeros of windowed tiles are not kept; the mixed case is bounded by the covered share
+            const double share = A->ntiles ? (double)P->covered / (double)A->ntiles : 0.0;
+            const double per = (P->fmt == 2) ? 3.0 : 10.0;
+            b += (int64_t)(A->nnz * (share * per + (1.0 - share) * 12.0)) + 80 * A->ntiles;
+        }
+        *matrix_bytes_per_product = b;
+    }
+    return MK_OK;
+}
+
+extern "C" int mk_csr_launch_info(const mk_csr *A, int32_t *grid, int32_t *tile_map) {
+    MK_ARG(A != nullptr);
+    if (grid) *grid = mk_grid_spmv_for(A);
+    if (tile_map) *tile_map = mk_tile_map(A);
+    return MK_OK;
+}

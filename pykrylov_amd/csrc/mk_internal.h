@@ -64,7 +64,7 @@ int mk_fail(int code, const char *fmt, ...);
 // --------------------------------------------------------------------------------------
 // exchange plan (multi-GPU); empty for a single-device matrix
 // --------------------------------------------------------------------------------------
-constexpr int MK_CSR_PAD = 4;      // padding entries behind indices / data (aligned 4-entry reads of the SpMV kernel)
+constexpr int MK_CSR_PAD = 8;      // padding entries behind indices / data / slots / codes (aligned 8-entry reads of the SpMV kernel)
 
 struct MkExchange {
     int mode = -1;                 // -1 none, 0 halo send/recv, 1 allgather
@@ -84,6 +84,22 @@ struct MkExchange {
     mutable bool in_flight = false; // ... and its messages are on comm_stream (wait for ev_comm)
 };
 
+// Windowed tile format of a matrix (mk_format.hip), built on first use of the matrix in a product.
+constexpr int MK_WCHUNK = 128;     // doubles per window chunk (one wave-level 16-byte load)
+constexpr int MK_WCHUNKS_MAX = 16; // chunks per tile (4 per wave): 16 KiB of LDS windows at most
+struct MkPlan {
+    bool built = false;
+    int fmt = 0;                   // 0 plain CSR, 1 windows + uint16 slots, 2 windows + slots + value dictionary
+    int wchunks = 0;               // max chunks of a tile
+    int ndict = 0;
+    int64_t covered = 0;           // tiles on the windowed path
+    uint16_t *d_slots = nullptr;
+    int32_t *d_wg = nullptr;
+    uint32_t *d_wn = nullptr;
+    uint8_t *d_codes = nullptr;
+    double *d_dict = nullptr;
+};
+
 struct mk_csr {
     int64_t nrows = 0, ncols = 0, nnz = 0;
     int32_t *d_indptr = nullptr;
@@ -91,7 +107,10 @@ struct mk_csr {
     double *d_data = nullptr;
     int64_t ntiles = 0;            // ceil(nrows / MK_ROWS_PER_TILE)
     MkExchange ex;
-    bool alias = false;            // composed operator: the arrays belong to another mk_csr
+    bool alias = false;            // composed operator: the arrays belong to another mk_csr ...
+    const mk_csr *base = nullptr;  // ... this one (which also owns the windowed format)
+    mutable MkPlan plan;
+    int want_fmt = -1;             // mk_csr_set_format: -1 = library default (MK_SPMV_FORMAT or 2)
     int32_t nops = 0;              // row program (mk_csr_compose)
     mk_rowop ops[MK_ROWPROG_MAX] = {};
     // length of the vector an SpMV reads (ncols, or n_local + n_halo with a halo plan)
@@ -99,6 +118,7 @@ struct mk_csr {
 };
 
 int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out);
+void mk_csr_plan_reset(const mk_csr *A);    // drop the windowed format (it is rebuilt on the next product)
 
 // grid sizes -------------------------------------------------------------------------
 // Persistent-style grids: at most `cap` workgroups which stride over the work.  The caps are tuning
