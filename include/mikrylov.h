@@ -183,6 +183,13 @@ int mk_exchange(const mk_csr *A, double *x_ext_dev);
 /* Sum `count` (<= 2048) host doubles over all ranks, in place; a no-op without a communicator.  For the few
  * reductions the host side of a partitioned run needs (e.g. tools.check_symmetric, utils.py:63-85). */
 int mk_comm_allreduce_host(double *vals_host, int64_t count);
+/* Timing aids (collective: every rank calls them with the same arguments in the same order).  Average duration
+ * in microseconds of `reps` back-to-back in-stream exchanges of A's plan (halo: pack + grouped send/recv; all-gather)
+ * resp. all-reduces of `count` (<= 2048) doubles, bracketed by one HIP event pair on the library stream. */
+int mk_comm_time_exchange(const mk_csr *A, double *x_ext_dev, int64_t reps, double *avg_us);
+int mk_comm_time_allreduce(int64_t count, int64_t reps, double *avg_us);
+/* Duration of the last overlapped halo message group on the second stream (0: none yet). */
+int mk_csr_comm_last_us(const mk_csr *A, double *us);
 /* Halo mode overlaps the messages with the product: tiles (256 rows) whose rows reference only owned columns are
  * multiplied while the neighbours' entries travel on a second stream, the remaining tiles afterwards.  Reports the
  * split (0, 0: no overlap plan -- single rank, all-gather mode, or every tile touches the halo). */

@@ -95,6 +95,9 @@ PROTOTYPES = {
     "mk_exchange": (ctypes.c_int, [c_vp, c_vp]),
     "mk_comm_allreduce_host": (ctypes.c_int, [P(c_f64), c_i64]),
     "mk_csr_overlap_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64)]),
+    "mk_comm_time_exchange": (ctypes.c_int, [c_vp, c_vp, c_i64, P(c_f64)]),
+    "mk_comm_time_allreduce": (ctypes.c_int, [c_i64, c_i64, P(c_f64)]),
+    "mk_csr_comm_last_us": (ctypes.c_int, [c_vp, P(c_f64)]),
     "mk_solver_create": (ctypes.c_int, [c_vp, P(MkParams), P(c_vp)]),
     "mk_solver_destroy": (ctypes.c_int, [c_vp]),
     "mk_solver_set_transpose": (ctypes.c_int, [c_vp, c_vp]),

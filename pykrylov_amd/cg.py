@@ -41,7 +41,7 @@ class CG(KrylovMethod):
         """
         op = self._device_operator()
         pdiag = self._device_precon(self.precon)
-        n = rhs.shape[0]
+        n = getattr(op, 'global_size', None) or rhs.shape[0]    # (row-partitioned operator: the global size)
         store_resids = kwargs.get('store_resids', False)
         store_iterates = kwargs.get('store_iterates', False)
 

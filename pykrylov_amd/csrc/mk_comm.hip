@@ -137,7 +137,8 @@ int build_overlap_plan(mk_csr *A) {
     ex.n_bnd = A->ntiles - n_int;
     MK_HIP(hipStreamCreateWithFlags(&ex.comm_stream, hipStreamNonBlocking));
     MK_HIP(hipEventCreateWithFlags(&ex.ev_pack, hipEventDisableTiming));
-    MK_HIP(hipEventCreateWithFlags(&ex.ev_comm, hipEventDisableTiming));
+    MK_HIP(hipEventCreate(&ex.ev_comm0));                    // (timed pair: duration of the last message group,
+    MK_HIP(hipEventCreate(&ex.ev_comm));                     //  mk_csr_comm_last_us)
     return MK_OK;
 }
 
@@ -359,6 +360,7 @@ int mk_exchange_begin(const mk_csr *A, double *x_ext) {
     // touches until mk_exchange_wait; the previous exchange's messages were waited for before the buffer is reused
     MK_HIP(hipEventRecord(ex.ev_pack, st));
     MK_HIP(hipStreamWaitEvent(ex.comm_stream, ex.ev_pack, 0));
+    MK_HIP(hipEventRecord(ex.ev_comm0, ex.comm_stream));
     MK_NCCL(g_rccl.GroupStart());
     for (int r = 0; r < g_nranks; ++r) {
         if (ex.send_count[r] > 0)
@@ -371,6 +373,7 @@ int mk_exchange_begin(const mk_csr *A, double *x_ext) {
     MK_NCCL(g_rccl.GroupEnd());
     MK_HIP(hipEventRecord(ex.ev_comm, ex.comm_stream));
     ex.pending = ex.in_flight = true;
+    ex.timed = true;
     return MK_OK;
 }
 
@@ -466,5 +469,69 @@ extern "C" int mk_exchange(const mk_csr *A, double *x_ext) {
                                 st));
     }
     MK_NCCL(g_rccl.GroupEnd());
+    return MK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- timing helpers
+// Collective: every rank must call these with the same arguments, in the same order.
+extern "C" int mk_comm_time_exchange(const mk_csr *A, double *x_ext, int64_t reps, double *avg_us) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A && x_ext && reps > 0 && avg_us);
+    hipStream_t st = mk_ctx().stream;
+    hipEvent_t e0, e1;
+    MK_HIP(hipEventCreate(&e0));
+    MK_HIP(hipEventCreate(&e1));
+    int rc = mk_exchange(A, x_ext);                          // untimed first round (connections, buffers)
+    if (rc != MK_OK) return rc;
+    MK_HIP(hipEventRecord(e0, st));
+    for (int64_t k = 0; k < reps; ++k)
+        if ((rc = mk_exchange(A, x_ext)) != MK_OK) return rc;
+    MK_HIP(hipEventRecord(e1, st));
+    MK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = 1e3 * (double)ms / (double)reps;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return MK_OK;
+}
+
+extern "C" int mk_comm_time_allreduce(int64_t count, int64_t reps, double *avg_us) {
+    MK_REQUIRE_INIT();
+    MK_ARG(count > 0 && count <= MK_MAXP && reps > 0 && avg_us);
+    if (!mk_comm_active()) {
+        *avg_us = 0.0;
+        return MK_OK;
+    }
+    MkContext &c = mk_ctx();
+    double *buf = c.d_scratch + 2 * MK_MAXP;
+    MK_HIP(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)count, c.stream));
+    hipEvent_t e0, e1;
+    MK_HIP(hipEventCreate(&e0));
+    MK_HIP(hipEventCreate(&e1));
+    int rc = mk_comm_allreduce_sum(buf, count, c.stream);
+    if (rc != MK_OK) return rc;
+    MK_HIP(hipEventRecord(e0, c.stream));
+    for (int64_t k = 0; k < reps; ++k)
+        if ((rc = mk_comm_allreduce_sum(buf, count, c.stream)) != MK_OK) return rc;
+    MK_HIP(hipEventRecord(e1, c.stream));
+    MK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = 1e3 * (double)ms / (double)reps;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return MK_OK;
+}
+
+// duration of the last overlapped halo message group on the second stream (0 if there was none); call after a sync
+extern "C" int mk_csr_comm_last_us(const mk_csr *A, double *us) {
+    MK_ARG(A && us);
+    *us = 0.0;
+    const MkExchange &ex = A->ex;
+    if (!ex.timed || !ex.ev_comm0 || !ex.ev_comm) return MK_OK;
+    if (hipEventSynchronize(ex.ev_comm) != hipSuccess) return MK_OK;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ex.ev_comm0, ex.ev_comm) == hipSuccess) *us = 1e3 * (double)ms;
     return MK_OK;
 }

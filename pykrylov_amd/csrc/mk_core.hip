@@ -236,6 +236,7 @@ extern "C" int mk_csr_destroy(mk_csr *A) {
     if (A->ex.comm_stream) hipStreamDestroy(A->ex.comm_stream);
     if (A->ex.ev_pack) hipEventDestroy(A->ex.ev_pack);
     if (A->ex.ev_comm) hipEventDestroy(A->ex.ev_comm);
+    if (A->ex.ev_comm0) hipEventDestroy(A->ex.ev_comm0);
     delete A;
     return MK_OK;
 }

@@ -60,18 +60,33 @@ static inline int mk_tile_map(const mk_csr *A) {
     return mk_xcd_chunks(A) ? 1 : 0;
 }
 
-// SpMV grid: twice as many (smaller-share) workgroups pay off only while the problem is cache resident
+const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
+
+// SpMV grid = the workgroups that are resident at once (persistent tiles; a second round only adds a tail).
+// CSR path: 4 per CU at <= 64 registers, twice as many smaller shares while the problem is cache resident.
+// Windowed path: 4 per CU (raw values, ~100 registers) or 5 per CU (dictionary) -- measured on 512^3 and 2-D
+// n = 1e6: 1024 / 1280 workgroups beat every other count by 5-25 % (tools/sweep_fmt.sh).
 static inline int mk_grid_spmv_for(const mk_csr *A) {
     int g = mk_grid_spmv(A->ntiles);
-    if (!getenv("MK_GRID_SPMV") && mk_xcd_chunks(A)) {
-        const int64_t cap = 2 * (int64_t)mk_cap_spmv() > MK_MAXP ? MK_MAXP : 2 * mk_cap_spmv();
-        g = (int)(A->ntiles > cap ? cap : (A->ntiles < 1 ? 1 : A->ntiles));
-        if (g >= 8) g -= g % 8;
-    }
+    if (getenv("MK_GRID_SPMV")) return g;
+    const MkPlan *P = mk_csr_plan(A);
+    int64_t cap = mk_cap_spmv();
+    if (P && P->fmt == 2) cap = 1280;
+    else if (P && P->fmt == 1) cap = 1024;
+    else if (mk_xcd_chunks(A)) cap = 2 * cap > MK_MAXP ? MK_MAXP : 2 * cap;
+    g = (int)(A->ntiles > cap ? cap : (A->ntiles < 1 ? 1 : A->ntiles));
+    if (g >= 8) g -= g % 8;
     return g;
 }
 
-const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
+// grid of one of the two launches of an overlapped (halo) product over `ntl` of A's tiles
+static inline int mk_grid_spmv_part(const mk_csr *A, int64_t ntl) {
+    int cap = mk_grid_spmv_for(A);
+    if (cap > MK_MAXP / 2) cap = MK_MAXP / 2;
+    int g = (int)(ntl < 1 ? 1 : (ntl > cap ? cap : ntl));
+    if (g >= 8) g -= g % 8;
+    return g;
+}
 
 static inline MkCsrView mk_view(const mk_csr *A) {
     MkCsrView v{};

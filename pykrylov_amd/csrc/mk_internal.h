@@ -79,9 +79,10 @@ struct MkExchange {
     int32_t *d_tiles = nullptr;    // interior tile ids followed by boundary tile ids
     int64_t n_int = 0, n_bnd = 0;
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_comm0 = nullptr, ev_comm = nullptr;
     mutable bool pending = false;  // an exchange was started and the next product must run in two parts
     mutable bool in_flight = false; // ... and its messages are on comm_stream (wait for ev_comm)
+    mutable bool timed = false;     // ev_comm0 / ev_comm bracket a message group
 };
 
 // Windowed tile format of a matrix (mk_format.hip), built on first use of the matrix in a product.

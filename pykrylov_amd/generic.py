@@ -206,7 +206,7 @@ def solve_guess_matvec_max(solver, kind, rhs, kwargs, count_guess_product):
     (reference bicgstab.py:148-151, cgs.py:120-123, tfqmr.py:156-159).  These solvers keep no history."""
     op = solver._device_operator()
     pdiag = solver._device_precon(solver.precon)
-    n = rhs.shape[0]
+    n = getattr(op, 'global_size', None) or rhs.shape[0]        # same limit on every rank of a partitioned run
     guess = kwargs.get('guess', None)
     matvec_max = kwargs.get('matvec_max', 2 * n)
     with DeviceRun(op, kind, rhs, guess, precon_diag=pdiag, abstol=float(solver.abstol),

@@ -70,12 +70,13 @@ class Minres(KrylovMethod):
         """
         A = self._device_operator()
         n = b.shape[0]
+        n_glob = getattr(A, 'global_size', None) or n           # row-partitioned operator: same limit on every rank
         precon = kwargs.get('precon', None)                   # minres.py:121: a `solve` keyword, not a ctor one
         pdiag = self._device_precon(precon)
         shift = kwargs.get('shift', 0.0)
         show = kwargs.get('show', True)
         check = kwargs.get('check', True)
-        itnlim = kwargs.get('itnlim', 5 * n)
+        itnlim = kwargs.get('itnlim', 5 * n_glob)
         rtol = kwargs.get('rtol', 1.0e-12)
         etol = kwargs.get('etol', 1.0e-6)
         store_iterates = kwargs.get('store_iterates', False)

@@ -43,7 +43,8 @@ class Symmlq(KrylovMethod):
         op = self._device_operator()
         pdiag = self._device_precon(self.precon)      # ctor keyword (symmlq.py:60); diagonal operators only
         n = rhs.shape[0]
-        matvec_max = kwargs.get('matvec_max', 2 * n + 2)
+        n_glob = getattr(op, 'global_size', None) or n          # row-partitioned operator: same limit on every rank
+        matvec_max = kwargs.get('matvec_max', 2 * n_glob + 2)
         rtol = kwargs.get('rtol', 1.0e-9)
         check = kwargs.get('check', False)
         shift = kwargs.get('shift', None)

@@ -146,6 +146,19 @@ def main():
     assert s.istop == 7 and s.itn == 0, (s.istop, s.itn)                  # minres.py:186-190
     op.free()
 
+    # ---- default iteration limit on an UNEVEN split (n = 1001 over 2 or 3 ranks: local blocks differ): the limit is
+    # 2 * n_global on every rank (cg.py:79-80), so all ranks take the same number of passes and the collectives stay
+    # matched (with per-rank limits the ranks with the shorter block would stop enqueuing first and the job hangs)
+    D = csr_ref.poisson1d(1001)
+    rhs_d = D.matvec(np.sin(np.arange(1001.0)))
+    op, ranges = dist.partition_host_csr(world, D.indptr, D.indices, D.data, 1001, mode="halo")
+    c0, c1 = ranges[rank]
+    s = CG(op, abstol=0.0, reltol=1e-300)                   # unreachable tolerance: runs until the limit (or r == 0)
+    s.solve(rhs_d[c0:c1], check_curvature=False)
+    counts = world.allgather_object(int(s.nMatvec))
+    assert len(set(counts)) == 1 and 600 < counts[0] <= 2 * 1001, counts
+    op.free()
+
     _lib.load().mk_comm_destroy()
     if rank == 0:
         print("RESULT " + json.dumps(out))

@@ -45,17 +45,28 @@ def test_partitioned_solvers_on_one_gpu(nranks):
     assert out["cg3d/halo"]["halo"] in (576, 1152)              # one or two neighbour planes of 24 x 24
 
 
-def test_bench_two_rank_path_smoke():
-    """bench.py's N > 1 branch (per-rank matrix generation, barrier / max-over-ranks timing, JSON line) with two
-    ranks on GPU 0 over the host-staged transport: a smoke test of the code path the driver runs on 2-8 GPUs."""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_rank_path_smoke(launcher):
+    """bench.py's N > 1 branch (per-rank matrix generation, gloo bootstrap, barrier / max-over-ranks timing, both
+    exchange modes, comm timings, JSON line) with two ranks on GPU 0 over the host-staged transport: a smoke test of
+    the code path the driver runs on 2-8 GPUs.  `self`: the plain `python bench.py --gpus 2 ...` form spawns its
+    ranks itself; `torchrun`: the external-launcher form of the driver contract."""
     env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "12", "--warmup", "3", "--transport", "host", "--workload", "poisson3d-64",
-           "--spmv-launches", "3"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--transport", "host",
+            "--workload", "poisson3d-64", "--spmv-launches", "3"]
+    if launcher == "self":
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + args
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 12 and line["value"] > 0 and line["scaling"] == "strong"
     assert line["config"]["rows"] == 64 ** 3 and line["residual"]["last"] < line["residual"]["first"]
-    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["achieved"] > 0
+    assert line["roofline"]["bound"] == "hbm"
+    ex = line["exchange"]
+    assert set(ex) == {"halo", "allgather"} and ex["allgather"]["value"] > 0
+    assert len(ex["halo"]["comm"]["per_rank"]) == 2 and ex["halo"]["comm"]["per_rank"][1]["exchange_alone_us"] > 0

@@ -250,3 +250,40 @@ def test_solver_rejects_host_operator():
     op = LinearOperator(4, 4, matvec=lambda v: 2 * v, symmetric=True)
     with pytest.raises(TypeError):
         CG(op).solve(np.ones(4))
+
+
+def test_default_limits_use_the_global_size(monkeypatch):
+    """On a row-partitioned operator rhs is the local slice; the default iteration limits must come from the GLOBAL
+    size (cg.py:79-80 `2n`, minres.py:128 `5n`, symmlq.py:90 `2n+2`), identical on every rank, or ranks with
+    unequal blocks stop enqueuing collectives at different passes."""
+    import numpy as np
+    import pykrylov_amd as pk
+    from pykrylov_amd import generic, cg, minres, symmlq
+    from pykrylov_amd.linop import CsrOperator
+
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    class FakeRun(object):
+        def __init__(self, op, kind, rhs, guess=None, precon_diag=None, **params):
+            seen.update(params)
+            raise Stop()
+
+    for mod in (generic, cg, minres, symmlq):
+        monkeypatch.setattr(mod, "DeviceRun", FakeRun)
+    op = object.__new__(CsrOperator)
+    op.__dict__.update(global_size=1001, local_size=334, _nMatvec=0)
+    monkeypatch.setattr(CsrOperator, "shape", property(lambda self: (334, 336)), raising=False)
+    rhs = np.ones(334)
+    for cls, key, want in ((pk.CG, "matvec_max", 2002), (pk.BiCGSTAB, "matvec_max", 2002),
+                           (pk.CGS, "matvec_max", 2002), (pk.TFQMR, "matvec_max", 2002),
+                           (pk.Symmlq, "matvec_max", 2004), (pk.Minres, "itnlim", 5005)):
+        seen.clear()
+        s = cls(op)
+        try:
+            s.solve(rhs, show=False, check=False) if cls is pk.Minres else s.solve(rhs)
+        except Stop:
+            pass
+        assert seen.get(key) == want, (cls.__name__, seen)

@@ -551,6 +551,112 @@ __global__ __launch_bounds__(BLOCK) void spmv_w3(const int* __restrict__ ip, con
     if (tid == 0) part[blockIdx.x] = tot;
 }
 
+
+// version 4: v3 with TWO tiles in flight (register sets RA / RB, loop unrolled by two)
+template <int VC>
+__global__ __launch_bounds__(BLOCK) void spmv_w4(const int* __restrict__ ip, const uint16_t* __restrict__ sl, const double* __restrict__ dv,
+                                                 const uint8_t* __restrict__ vc, const double* __restrict__ dict, const int* __restrict__ wg,
+                                                 const unsigned* __restrict__ wn, const double* __restrict__ x, double* __restrict__ y,
+                                                 long nrows, long ntiles, int nchunk, double* part) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* prod = smem;                 // TILE
+    double* xw = smem + TILE;            // nchunk * 128
+    __shared__ double s4[4];
+    __shared__ int sptr[BLOCK + 1];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (VC) { sdict[tid] = dict[tid]; }
+    double acc = 0.0;
+    struct Meta { int p_lo, p_hi, my_lo; };
+    struct Regs { u4v s; d2v val[4]; u2v code; d2v w[4]; unsigned nvw; double xr; };
+    auto load_meta = [&](long tile, Meta& m) {
+        m.p_lo = m.p_hi = m.my_lo = 0;
+        if (tile < ntiles) {
+            const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+            m.p_lo = ip[r0]; m.p_hi = ip[rend]; m.my_lo = ip[(r < rend) ? r : rend];
+        }
+    };
+    auto issue = [&](long tile, const Meta& m, Regs& R) {
+        R.nvw = 0;
+        if (tile >= ntiles) return;
+        const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+        R.xr = (r < rend) ? x[r] : 0.0;
+        const i4v g = *(const i4v*)(wg + (tile * 4 + wv) * 4);
+        R.nvw = wn[tile * 4 + wv];
+        const int gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hc = (int)((R.nvw >> (8 * i)) & 0xffu);
+            if (hc > 0) { const int l2 = min(lane, hc - 1); R.w[i] = *(const d2v*)(x + gs[i] + 2 * l2); }
+        }
+        const int base = m.p_lo & ~7, cnt = m.p_hi - base;
+        int j = 8 * tid; j = (j < cnt) ? j : ((cnt - 1) & ~7);
+        j = j < 0 ? 0 : j;
+        R.s = *(const u4v*)(sl + base + j);
+        if (VC) R.code = *(const u2v*)(vc + base + j);
+        else {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) R.val[h] = *(const d2v*)(dv + base + j + 2 * h);
+        }
+    };
+    const long G = gridDim.x;
+    long tile = blockIdx.x;
+    Meta m0, m1, m2, m3;
+    Regs RA, RB;
+    load_meta(tile, m0); load_meta(tile + G, m1); load_meta(tile + 2 * G, m2);
+    issue(tile, m0, RA); issue(tile + G, m1, RB);
+    auto body = [&](long tile, const Meta& mc, Regs& R, const Meta& mnext2, long tnext2, Meta& mload, long tload) {
+        const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+        const int p_lo = mc.p_lo, p_hi = mc.p_hi, my_lo = mc.my_lo;
+        const int base = p_lo & ~7, cnt = p_hi - base;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hc = (int)((R.nvw >> (8 * i)) & 0xffu);
+            if (hc > 0) *(d2v*)(xw + (wv + 4 * i) * 128 + 2 * lane) = R.w[i];
+        }
+        sptr[tid] = my_lo;
+        if (tid == 0) sptr[BLOCK] = p_hi;
+        __syncthreads();
+        const int my_hi = sptr[tid + 1];
+        const unsigned sw[4] = {R.s.x, R.s.y, R.s.z, R.s.w};
+        double pr[8];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const double x0 = xw[sw[h] & 0xffffu], x1 = xw[sw[h] >> 16];
+            double v0, v1;
+            if (VC) {
+                const unsigned cw = (h < 2) ? R.code.x : R.code.y;
+                v0 = sdict[(cw >> (16 * (h & 1))) & 0xffu]; v1 = sdict[(cw >> (16 * (h & 1) + 8)) & 0xffu];
+            } else { v0 = R.val[h].x; v1 = R.val[h].y; }
+            pr[2 * h] = v0 * x0; pr[2 * h + 1] = v1 * x1;
+        }
+        const double xr = R.xr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) prod[i * BLOCK + tid] = pr[i];
+        load_meta(tload, mload);
+        issue(tnext2, mnext2, R);                 // two tiles ahead, into the register set just consumed
+        __syncthreads();
+        const int lo = max(my_lo, p_lo) - base, hi = min(my_hi, base + cnt) - base, len = hi - lo;
+        double t[8], sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int idx = lo + k; t[k] = prod[phys((idx < TILE && idx >= 0) ? idx : 0)]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const double s2 = sum + t[k]; sum = (k < len) ? s2 : sum; }
+        for (int k = 8; k < len; ++k) sum += prod[phys(lo + k)];
+        if (r < rend) { y[r] = sum; acc += xr * sum; }
+    };
+    for (; tile < ntiles; tile += 2 * G) {
+        body(tile, m0, RA, m2, tile + 2 * G, m3, tile + 3 * G);        // consumes RA, refills it with tile+2G (meta m2); loads meta m3
+        if (tile + G < ntiles) body(tile + G, m1, RB, m3, tile + 3 * G, m0, tile + 4 * G);   // consumes RB, refills with tile+3G (m3); loads m0 := meta(tile+4G)
+        else break;
+        // rotate: next iteration's current = tile+2G (in RA, meta m2), then tile+3G (RB, meta m3); m0 holds meta(tile+4G)
+        Meta t0 = m0; m0 = m2; m1 = m3; m2 = t0;
+    }
+    const double tot = block_sum(acc, s4);
+    if (tid == 0) part[blockIdx.x] = tot;
+}
+
 template <class F> float timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -601,6 +707,11 @@ int main(int argc, char** argv) {
         CK(hipMemset(y, 0, n * 8)); \
         float ms = timeit([&] { hipLaunchKernelGGL((spmv_w3<VC, MAP, NT>), dim3(g), dim3(BLOCK), lds, 0, ip, sl2, dv, vc, dict, wg, wn, x, y, n, ntiles, hs[0], part); }, reps); \
         printf("w3 vc=%d map=%d nt=%d grid=%4d lds=%zu : %9.1f us  %.2f TB/s  %s\n", VC, MAP, NT, g, lds, ms * 1e3, bytes / ms / 1e9, check(y)); }
-    RUN3(0, 0, 0) RUN3(0, 1, 0) RUN3(0, 0, 1) RUN3(0, 1, 1) RUN3(1, 0, 0) RUN3(1, 1, 0) RUN3(1, 1, 1)
+#define RUN4(VC) for (int g : {1024, 1280, 2048}) { const size_t lds = (TILE + hs[0] * 128) * 8; \
+        CK(hipMemset(y, 0, n * 8)); \
+        float ms = timeit([&] { hipLaunchKernelGGL((spmv_w4<VC>), dim3(g), dim3(BLOCK), lds, 0, ip, sl2, dv, vc, dict, wg, wn, x, y, n, ntiles, hs[0], part); }, reps); \
+        printf("w4 vc=%d grid=%4d lds=%zu : %9.1f us  %.2f TB/s  %s\n", VC, g, lds, ms * 1e3, bytes / ms / 1e9, check(y)); }
+    RUN4(0) RUN4(1)
+    RUN3(0, 0, 0) RUN3(1, 0, 0) RUN3(1, 1, 0)
     return 0;
 }
