@@ -78,54 +78,76 @@ def stream_dot(a, b):
 
 
 def grid_spmv(ntiles):
+    """Grid of the SpMV kernels for matrices with at most 1024 tiles (every format caps the grid at >= 1024
+    workgroups); beyond that the grid depends on the storage format -- ask the library (mk_csr_launch_info)."""
     g = min(max(1, ntiles), SPMV_CAP)
     if g >= 8:
         g -= g % 8
     return g
 
 
-def spmv_tile_order(ntiles):
-    """For every workgroup the list of tiles it processes, in order (XCD-aware mapping of
-    csrc/mk_device.h: XCD b % 8 owns a contiguous eighth of the tiles, dealt round-robin to its workgroups)."""
-    grid = grid_spmv(ntiles)
-    nxcd = 8 if grid % 8 == 0 else 1
-    per = grid // nxcd
-    chunk = (ntiles + nxcd - 1) // nxcd
+def spmv_tile_order(ntiles, grid=None, tile_map=1):
+    """For every workgroup the list of tiles it processes, in order (csrc/mk_device.h `mk_spmv_tiles`).
+    tile_map 0: round robin.  1: XCD b % 8 owns a contiguous eighth of the tiles, dealt round-robin to its
+    workgroups (cache-resident matrices).  2: every step of the grid is cut into eight XCD-contiguous blocks.
+    Maps 1 and 2 fall back to 0 when the grid is not a multiple of 8."""
+    if grid is None:
+        grid = grid_spmv(ntiles)
+    x8 = grid % 8 == 0
     order = []
     for b in range(grid):
-        c0 = (b % nxcd) * chunk
-        cend = min(c0 + chunk, ntiles)
-        order.append(range(c0 + b // nxcd, cend, per))
+        if tile_map == 1 and x8:
+            per = grid // 8
+            chunk = (ntiles + 7) // 8
+            c0 = (b % 8) * chunk
+            order.append(range(c0 + b // 8, min(c0 + chunk, ntiles), per))
+        elif tile_map == 2 and x8:
+            order.append(range((b % 8) * (grid // 8) + b // 8, ntiles, grid))
+        else:
+            order.append(range(b, ntiles, grid))
     return order
 
 
-def spmv_partials(w, y, ntiles):
+def spmv_partials(w, y, ntiles, grid=None, tile_map=1):
     """Per-workgroup partial sums of sum(w*y) when the dot is fused into the SpMV kernel: lane t of a
     workgroup owns row 256*tile + t of each of its tiles and adds w[r]*y[r] in tile order."""
     n = len(w)
     prod = np.zeros(ntiles * BLOCK)
     prod[:n] = np.asarray(w, dtype=np.float64) * np.asarray(y, dtype=np.float64)
     prod = prod.reshape(ntiles, BLOCK)
-    order = spmv_tile_order(ntiles)
+    order = spmv_tile_order(ntiles, grid, tile_map)
     acc = np.zeros((len(order), BLOCK))
-    for b, tiles in enumerate(order):
-        for tile in tiles:
-            acc[b] = acc[b] + prod[tile]
+    steps = max(len(t) for t in order) if order else 0
+    for k in range(steps):                                   # vectorised over workgroups: step k of every workgroup
+        idx = np.array([t[k] if k < len(t) else -1 for t in order])
+        live = idx >= 0
+        acc[live] = acc[live] + prod[idx[live]]
     return _block_sum(acc)
+
+
+def launch_geometry(op):
+    """(grid, tile_map) of the SpMV kernels of a device operator, from the library (TEST helper: lets the
+    emulation follow the real grid of large matrices, which depends on the storage format)."""
+    import ctypes
+    from pykrylov_amd import _lib
+    g, m = ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(_lib.init().mk_csr_launch_info(op.handle, ctypes.byref(g), ctypes.byref(m)))
+    return g.value, m.value
 
 
 class GpuDots(object):
     """`dot_impl` for krylov_ref.Reductions reproducing the device's summation order: call sites
     listed in `spmv_sites` are fused into an SpMV kernel (row-owner order), all others are streaming
-    kernels."""
+    kernels.  `geometry` = (grid, tile_map) of the operator's SpMV launches (default: small-matrix rule)."""
 
-    def __init__(self, n, spmv_sites):
+    def __init__(self, n, spmv_sites, geometry=None):
         self.ntiles = (n + BLOCK - 1) // BLOCK
         self.spmv_sites = set(spmv_sites)
+        self.grid, self.tile_map = geometry if geometry else (None, 1)
 
     def __call__(self, a, b, site):
         if site in self.spmv_sites:
-            return total(spmv_partials(a, b, self.ntiles))
+            return total(spmv_partials(a, b, self.ntiles, self.grid, self.tile_map))
         return stream_dot(a, b)
 
 
