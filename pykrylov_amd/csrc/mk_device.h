@@ -196,9 +196,14 @@ struct MkHasPre<Epi, std::void_t<decltype(std::declval<Epi &>().pre((int64_t)0))
 typedef unsigned mk_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned mk_u4 __attribute__((ext_vector_type(4)));
 
-// position of chunk-relative product idx in the transposed staging buffer of the windowed path: lane l writes its
-// i-th product to [i][l] (consecutive lanes, consecutive addresses: conflict-free ds_write_b64)
-__device__ __forceinline__ int mk_phys(int idx) { return (idx & 7) * MK_BLOCK + (idx >> 3); }
+// Staging buffer of the windowed path: product idx (relative to the 8-aligned start of the tile's stream) lives at
+// [idx & 7][idx >> 3] of an 8 x 257 array -- lane l writes its i-th product to [i][l] (consecutive lanes, consecutive
+// addresses: conflict-free ds_write_b64); column 256 holds zeros, so that pass 2 can mask a read by redirecting its
+// ADDRESS there (one 32-bit select) instead of selecting 64-bit values: adding +0.0 never changes a running sum that
+// started at +0.0 (it can never be -0.0).
+constexpr int MK_PROD_LD = MK_BLOCK + 1;
+constexpr int MK_PROD_LDS = 8 * MK_PROD_LD;          // doubles reserved for products (>= MK_SPMV_TILE of the gather path)
+__device__ __forceinline__ int mk_phys(int idx) { return (idx & 7) * MK_PROD_LD + (idx >> 3); }
 
 struct MkTileMeta {
     int p_lo, p_hi, my_lo;
@@ -383,6 +388,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         load_meta(pos + stride, nxt);
         issue(pos, cur, R);
         bool lds_busy = false;                               // products of a windowed tile may still be read by slower waves
+        bool zero_ok = false;                                // the zero column of the staging buffer is in place
         for (; pos < end; pos += stride) {
             const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
@@ -429,24 +435,29 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                     pr[2 * h + 1] = v1 * x1;
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) prod[i * MK_BLOCK + tid] = pr[i];
+                for (int i = 0; i < 8; ++i) prod[i * MK_PROD_LD + tid] = pr[i];
+                if (!zero_ok) {                              // (a gather tile overwrote the zero column)
+                    if (tid < 8) prod[tid * MK_PROD_LD + MK_BLOCK] = 0.0;
+                    zero_ok = true;
+                }
                 // the registers are free: the next tile's input goes in flight and lands during pass 2
                 load_meta(pos + 2 * stride, nx2);
                 issue(pos + stride, nxt, R);
                 __syncthreads();
-                // ---- pass 2: one lane per row, left-to-right sum of its segment
+                // ---- pass 2: one lane per row, left-to-right sum of its segment.  Entry lo + k sits at
+                // [(a + k) & 7][b + carry]: one of two precomputed bases plus a compile-time offset.
                 const int lo = my_lo - base, len = my_hi - my_lo;
+                const int a = lo & 7;
+                const int adA = a * MK_PROD_LD + (lo >> 3), adB = adA - (8 * MK_PROD_LD - 1);
                 double t[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int idx = lo + k;
-                    t[k] = prod[mk_phys((idx < MK_SPMV_TILE && idx >= 0) ? idx : 0)];
+                    int ad = (a + k >= 8) ? adB : adA;
+                    ad = (k < len) ? ad : MK_BLOCK;          // past the row: the zero column
+                    t[k] = prod[ad + k * MK_PROD_LD];
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double s2 = sum + t[k];
-                    sum = (k < len) ? s2 : sum;
-                }
+                for (int k = 0; k < 8; ++k) sum += t[k];
                 for (int k = 8; k < len; ++k) sum += prod[mk_phys(lo + k)];
                 lds_busy = true;
             } else {
@@ -455,6 +466,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                 sum = mk_tile_gather(A, x, epi, prod, sptr, cur);
                 issue(pos + stride, nxt, R);
                 lds_busy = false;
+                zero_ok = false;
             }
             if constexpr (PROG) {
                 if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
@@ -476,9 +488,9 @@ struct MkNoGate {
 template <class Epi, class Gate, bool PROG, int FMT>
 __global__ __launch_bounds__(MK_BLOCK, FMT == 0 ? 8 : (FMT == 1 ? 4 : 5)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) double mk_smem[];     // products [MK_SPMV_TILE], then the windows
+    extern __shared__ __attribute__((aligned(16))) double mk_smem[];     // products [MK_PROD_LDS], then the windows
     double *prod = mk_smem;
-    double *xw = mk_smem + MK_SPMV_TILE;
+    double *xw = mk_smem + MK_PROD_LDS;
     __shared__ double s4[4];
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(MK_BLOCK, FMT == 0 ? 8 : (FMT == 1 ? 4 : 5)) void m
 template <class Epi, class Gate, bool PROG>
 static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t st, const double *x, const Epi &epi,
                                       const Gate &gate, MkHalt halt, double *partials) {
-    const size_t lds = sizeof(double) * (size_t)(MK_SPMV_TILE + (v.fmt ? 128 * v.wchunks : 0));
+    const size_t lds = sizeof(double) * (size_t)(MK_PROD_LDS + (v.fmt ? 128 * v.wchunks : 0));
     if (v.fmt == 2)
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 2>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                            halt, partials);
