@@ -188,6 +188,13 @@ def format_info(lib, op):
             "matrix_bytes_per_product": mbytes.value, "grid": grid.value, "tile_order": tmap.value}
 
 
+def colblocks(lib, op):
+    from pykrylov_amd import _lib
+    k = ctypes.c_int32()
+    _lib.check(lib.mk_csr_colblocks(op.handle, ctypes.byref(k)))
+    return k.value
+
+
 def other_configs(lib, passes=400, warm=20):
     """BASELINE configs[2] and configs[3] on one GPU (`--all-configs`): loop passes per second with the
     tolerances at zero so that exactly `passes` passes run, plus the iteration roofline with the
@@ -206,8 +213,9 @@ def other_configs(lib, passes=400, warm=20):
         _lib.check(lib.mk_sync())
         dt = time.perf_counter() - t0
         assert done == passes, (done, passes)
-        avg = ctypes.c_double()
-        _lib.check(lib.mk_solver_time_spmv(run.handle, 200, ctypes.byref(avg)))
+        avg = ctypes.c_double(float("nan"))
+        if kind == _lib.MK_BICGSTAB:                         # (the other solvers' product kernels: see profiles/)
+            _lib.check(lib.mk_solver_time_spmv(run.handle, 200, ctypes.byref(avg)))
         run.close()
         return dt, avg.value
 
@@ -225,8 +233,10 @@ def other_configs(lib, passes=400, warm=20):
     out["bicgstab-rand1m@1"] = {"value": passes / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / passes,
                                 "rows": n, "nnz": int(op.nnz), "matvecs_per_iteration": 2,
                                 "format": format_info(lib, op),
-                                "spmv": {"avg_launch_us": spmv_us, "achieved_GBs": b_spmv / spmv_us / 1e3,
-                                         "frac": b_spmv / spmv_us / 1e3 / HBM_PEAK_GBS},
+                                "column_blocks": colblocks(lib, op),
+                                "spmv": {"avg_product_us": spmv_us, "achieved_GBs": b_spmv / spmv_us / 1e3,
+                                         "frac": b_spmv / spmv_us / 1e3 / HBM_PEAK_GBS,
+                                         "note": "one product = all column-block launches of the first product's kernel"},
                                 "iteration_roofline": {"algorithmic_bytes_per_iter": b_iter,
                                                        "frac_of_hbm": b_iter * passes / dt / 1e9 / HBM_PEAK_GBS}}
     op.free()
@@ -244,8 +254,6 @@ def other_configs(lib, passes=400, warm=20):
     b_iter = b_spmv + 176 * n                                              # SURVEY.md 8d (kwarg shift)
     out["minres-shifted2d-2000@1"] = {"value": passes / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / passes,
                                       "rows": n, "nnz": int(op.nnz), "shift": 1.5, "format": format_info(lib, op),
-                                      "spmv": {"avg_launch_us": spmv_us,
-                                               "note": "SpMV kernel with the fused Lanczos epilogue (B_spmv + 32 n bytes)"},
                                       "iteration_roofline": {"algorithmic_bytes_per_iter": b_iter,
                                                              "frac_of_hbm": b_iter * passes / dt / 1e9 / HBM_PEAK_GBS}}
     op.free()

@@ -119,6 +119,14 @@ int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops, mk_csr **
 int mk_csr_set_format(mk_csr *A, int fmt);
 int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_windowed, int32_t *lds_chunks,
                        int32_t *dict_size, int64_t *matrix_bytes_per_product);
+/* Column blocks (off by default; block_kb > 0 turns them on for A, 0 off, -1 = environment MK_COLBLOCK_KB): a
+ * plain-CSR matrix (format 0) whose x vector is longer than two blocks is additionally stored as K <= 8 column blocks of
+ * block_kb KiB of x each; its products run block after block with the running row sums carried from one launch to the
+ * next, which is the same left-to-right sum (same bits), each block gathering from a slice of x that fits an XCD's L2.
+ * Measured slower than the single launch on 5-nonzero rows: an option, not the default.
+ * mk_csr_colblocks reports K (0: not blocked). */
+int mk_csr_set_colblocks(mk_csr *A, int32_t block_kb);
+int mk_csr_colblocks(const mk_csr *A, int32_t *nblocks);
 /* Launch geometry of A's product kernels (what fixes the summation order of the dots fused into them): the grid,
  * and the tile order (0 round robin; 1 each XCD sweeps a contiguous eighth; 2 XCD-contiguous blocks per step). */
 int mk_csr_launch_info(const mk_csr *A, int32_t *grid, int32_t *tile_map);

@@ -78,6 +78,8 @@ PROTOTYPES = {
     "mk_csr_set_format": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "mk_csr_format_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i64), P(c_i32), P(c_i32), P(c_i64)]),
     "mk_csr_launch_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
+    "mk_csr_colblocks": (ctypes.c_int, [c_vp, P(c_i32)]),
+    "mk_csr_set_colblocks": (ctypes.c_int, [c_vp, c_i32]),
     "mk_spmv": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mk_dot": (ctypes.c_int, [c_i64, c_vp, c_vp, P(c_f64)]),
     "mk_nrm2": (ctypes.c_int, [c_i64, c_vp, P(c_f64)]),

@@ -297,6 +297,11 @@ struct BicgstabSolver : mk_solver {
         return MK_OK;
     }
 
+    int enqueue_spmv_only() override {                     // (timing aid: the first product's kernel without its gate)
+        mk_launch_spmv(this, d_prec ? d_q : d_p, BEpi{d_r0, d_v}, false);
+        return MK_OK;
+    }
+
     int enqueue_pass() override {
         const int par = (int)(it & 1);
         double *qin = d_prec ? d_q : d_p, *zin = d_prec ? d_z : d_s;           // what the two products read

@@ -491,6 +491,8 @@ __global__ __launch_bounds__(MK_BLOCK) void tr_sort_segments(int64_t ncols, cons
     }
 }
 
+constexpr int32_t MK_TR_DEVICE_MAX_COLUMN = 2048;     // longest column the device path sorts (one lane, insertion sort)
+
 extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
     MK_REQUIRE_INIT();
     MK_ARG(A && out);
@@ -507,8 +509,37 @@ extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
     std::vector<int32_t> h((size_t)A->ncols + 1);
     MK_HIP(hipMemcpyAsync(h.data(), B->d_indptr, pbytes, hipMemcpyDeviceToHost, st));
     MK_HIP(hipStreamSynchronize(st));
-    for (int64_t c = 0; c < A->ncols; ++c) h[c + 1] += h[c];
+    int32_t longest = 0;
+    for (int64_t c = 0; c < A->ncols; ++c) {
+        longest = h[c + 1] > longest ? h[c + 1] : longest;
+        h[c + 1] += h[c];
+    }
     MK_HIP(hipMemcpyAsync(B->d_indptr, h.data(), pbytes, hipMemcpyHostToDevice, st));
+    if (longest > MK_TR_DEVICE_MAX_COLUMN) {
+        // A column this long (dense columns of least-squares / LP matrices) would make the per-segment insertion
+        // sort below quadratic on ONE lane.  Such matrices are transposed by a stable counting sort on the host:
+        // rows are visited in ascending order, so every transposed row comes out sorted by original row.
+        std::vector<int32_t> ip((size_t)A->nrows + 1), ix((size_t)A->nnz), tix((size_t)A->nnz);
+        std::vector<double> dv((size_t)A->nnz), tdv((size_t)A->nnz);
+        MK_HIP(hipMemcpyAsync(ip.data(), A->d_indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipMemcpyAsync(ix.data(), A->d_indices, sizeof(int32_t) * ix.size(), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipMemcpyAsync(dv.data(), A->d_data, sizeof(double) * dv.size(), hipMemcpyDeviceToHost, st));
+        MK_HIP(hipStreamSynchronize(st));
+        std::vector<int32_t> cur(h.begin(), h.end() - 1);
+        for (int64_t r = 0; r < A->nrows; ++r)
+            for (int32_t j = ip[r]; j < ip[r + 1]; ++j) {
+                const int32_t dst = cur[ix[j]]++;
+                tix[dst] = (int32_t)r;
+                tdv[dst] = dv[j];
+            }
+        MK_HIP(hipMemcpyAsync(B->d_indices, tix.data(), sizeof(int32_t) * tix.size(), hipMemcpyHostToDevice, st));
+        MK_HIP(hipMemcpyAsync(B->d_data, tdv.data(), sizeof(double) * tdv.size(), hipMemcpyHostToDevice, st));
+        MK_HIP(hipStreamSynchronize(st));
+        B->nops = A->nops;
+        for (int k = 0; k < A->nops; ++k) B->ops[k] = A->ops[k];
+        *out = B;
+        return MK_OK;
+    }
     int32_t *cursor = nullptr;
     MK_HIP(hipMalloc((void **)&cursor, pbytes));
     MK_HIP(hipMemcpyAsync(cursor, h.data(), pbytes, hipMemcpyHostToDevice, st));

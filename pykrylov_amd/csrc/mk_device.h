@@ -45,6 +45,8 @@ struct MkCsrView {
     const uint32_t *wn;      // per tile and wave: half lengths of those chunks, one byte each
     const uint8_t *codes;    // per nonzero: index of its value in `dict` (fmt 2)
     const double *dict;
+    // column-blocked products (fmt 0): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
+    const double *sum_in;
 };
 
 // Working sets that fit the 256 MiB Infinity Cache profit from XCD-local tile ranges (every x line is then
@@ -212,12 +214,12 @@ struct MkTileMeta {
 // one tile through the gather path; `sum` is returned for row r0 + tid.  Starts and ends with the LDS free.
 template <class Epi>
 __device__ __forceinline__ double mk_tile_gather(const MkCsrView &A, const double *__restrict__ x, Epi &epi, double *prod,
-                                                 int *sptr, const MkTileMeta &cur) {
+                                                 int *sptr, const MkTileMeta &cur, double sum0 = 0.0) {
     constexpr int QUADS = MK_SPMV_TILE / (4 * MK_BLOCK);   // 2 groups of 4 nonzeros per lane per chunk
     const int tid = threadIdx.x;
     const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
     int my_hi = p_hi;
-    double sum = 0.0;
+    double sum = sum0;
     for (int base = p_lo & ~3; base < p_hi; base += MK_SPMV_TILE) {
         const int cnt = (p_hi - base < MK_SPMV_TILE) ? p_hi - base : MK_SPMV_TILE;
         // ---- pass 1: coalesced stream of the chunk, products into LDS.  Straight-line code: loads are clamped
@@ -332,7 +334,8 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                 if (r < rend) epi.pre(r);
             }
             load_meta(pos + stride, nxt);                    // next tile's row pointers go in flight now
-            double sum = mk_tile_gather(A, x, epi, prod, sptr, cur);
+            const double sum0 = (A.sum_in && r < rend) ? A.sum_in[r] : 0.0;   // (column-blocked product: carried sums)
+            double sum = mk_tile_gather(A, x, epi, prod, sptr, cur, sum0);
             if constexpr (PROG) {                            // composed operators only (separate instantiation)
                 if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
             }
@@ -539,10 +542,53 @@ static inline void mk_spmv_launch_view(const MkCsrView &v, int grid, hipStream_t
     else mk_spmv_launch_fmt<Epi, Gate, false>(v, grid, st, x, epi, gate, halt, partials);
 }
 
+// Column-blocked product (mk_format.hip): the matrix is stored as K column blocks, each a CSR matrix over all rows.
+// Block k's launch continues every row sum where block k-1 left it (columns are sorted, so this IS the left-to-right
+// sum over the whole row: same bits), gathering only from its own slice of x -- which fits the XCD's L2, whereas a
+// random gather over an x larger than the L2 pulls a 128-byte line through the fabric per 8 useful bytes.  All
+// launches but the last store the running sums; the last one runs the real epilogue (and the row program).
+template <class Epi>
+struct MkPartialOf {
+    static constexpr int NACC = 0, SLOT0 = 0;
+    Epi e;
+    double *ysum;
+    __device__ void prologue(double *s4) { e.prologue(s4); }
+    __device__ double xin(double v) const { return e.xin(v); }
+    __device__ void row(int64_t r, double s, double *) { ysum[r] = s; }
+};
+
+// `next` yields the MkHalt of each launch (one per kernel: the halting protocol alternates the flag word)
+template <class Epi, class Gate, class HaltSrc>
+static inline void mk_spmv_launch_blocks(const mk_csr *A, int grid, hipStream_t st, const double *x, const Epi &epi,
+                                         const Gate &gate, HaltSrc &&next, double *partials) {
+    const MkPlan *P = mk_csr_plan(A);
+    const size_t K = (P && A->ex.mode < 0) ? P->cblocks.size() : 0;
+    if (K < 2) {
+        mk_spmv_launch_view(mk_view(A), grid, st, x, epi, gate, next(), partials);
+        return;
+    }
+    for (size_t k = 0; k < K; ++k) {
+        MkCsrView v = mk_view(A);
+        const mk_csr *B = P->cblocks[k];
+        v.indptr = B->d_indptr;
+        v.indices = B->d_indices;
+        v.data = B->d_data;
+        v.sum_in = k ? P->d_cbsum : nullptr;
+        v.part = k ? 2 : 1;                                  // the gate's side effects happen in the first launch only
+        if (k + 1 < K) {
+            v.nops = 0;
+            mk_spmv_launch_view(v, grid, st, x, MkPartialOf<Epi>{epi, P->d_cbsum}, gate, next(), partials);
+        } else {
+            mk_spmv_launch_view(v, grid, st, x, epi, gate, next(), partials);
+        }
+    }
+}
+
 template <class Epi, class Gate>
 static inline void mk_spmv_launch(const mk_csr *A, int grid, hipStream_t st, const double *x, const Epi &epi,
                                   const Gate &gate, MkHalt halt, double *partials) {
-    mk_spmv_launch_view(mk_view(A), grid, st, x, epi, gate, halt, partials);
+    // (one halt word for all launches: only for callers whose flags never change)
+    mk_spmv_launch_blocks(A, grid, st, x, epi, gate, [&] { return halt; }, partials);
 }
 
 // ---------------------------------------------------------------------------------------

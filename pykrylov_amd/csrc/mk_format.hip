@@ -213,7 +213,55 @@ __global__ __launch_bounds__(MK_BLOCK) void dict_encode(int64_t nnz, const doubl
     }
 }
 
+// ------------------------------------------------------------------------------------------------ column blocks
+constexpr int CB_MAX = 8;
+struct CbPtrs {
+    int32_t *indptr[CB_MAX];
+    int32_t *indices[CB_MAX];
+    double *data[CB_MAX];
+};
+
+// per row: how many of its entries fall into each column block -> cnt[b * (nrows + 1) + r + 1]
+__global__ __launch_bounds__(MK_BLOCK) void cb_count(int64_t nrows, const int32_t *__restrict__ ip,
+                                                     const int32_t *__restrict__ ix, int bw, int K, int32_t *cnt) {
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        int c[CB_MAX];
+#pragma unroll
+        for (int b = 0; b < CB_MAX; ++b) c[b] = 0;
+        for (int32_t j = ip[r]; j < ip[r + 1]; ++j) {
+            const int b = ix[j] / bw;
+#pragma unroll
+            for (int q = 0; q < CB_MAX; ++q) c[q] += (q == b) ? 1 : 0;
+        }
+#pragma unroll
+        for (int b = 0; b < CB_MAX; ++b)
+            if (b < K) cnt[(int64_t)b * (nrows + 1) + r + 1] = c[b];
+    }
+}
+
+// per row: copy its entries (sorted by column, hence grouped by block) to the blocks' arrays
+__global__ __launch_bounds__(MK_BLOCK) void cb_scatter(int64_t nrows, const int32_t *__restrict__ ip,
+                                                       const int32_t *__restrict__ ix, const double *__restrict__ dv,
+                                                       int bw, CbPtrs P) {
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        int cur = -1, dst = 0;
+        for (int32_t j = ip[r]; j < ip[r + 1]; ++j) {
+            const int col = ix[j], b = col / bw;
+            if (b != cur) {
+                cur = b;
+                dst = P.indptr[b][r];
+            }
+            P.indices[b][dst] = col;
+            P.data[b][dst] = dv[j];
+            ++dst;
+        }
+    }
+}
+
 void plan_free(MkPlan &P) {
+    for (mk_csr *B : P.cblocks) mk_csr_destroy(B);
+    P.cblocks.clear();
+    hipFree(P.d_cbsum);
     hipFree(P.d_slots);
     hipFree(P.d_wg);
     hipFree(P.d_wn);
@@ -231,13 +279,86 @@ int default_format() {
     return f;
 }
 
+// Column-block size in bytes of x (0: off, the default -- see cblocks_build)
+int64_t colblock_bytes(const mk_csr *A) {
+    static int64_t env = [] {
+        const char *e = getenv("MK_COLBLOCK_KB");
+        return e ? atoll(e) * 1024 : (int64_t)0;
+    }();
+    const int64_t b = A->want_cb_kb >= 0 ? (int64_t)A->want_cb_kb * 1024 : env;
+    return b < 0 ? 0 : b;
+}
+
+// Column blocks for a plain-CSR matrix (scattered columns) whose x is more than two blocks long.  OFF by default:
+// measured on BASELINE configs[2] (random n = 1e6, 5 nnz/row; x = 8 MB against 4 MiB of L2 per XCD) a product costs
+// 53 us unblocked, 60 us in 4 blocks of 2 MB and 100 us in 8 blocks of 1 MB -- every extra launch re-reads the row
+// pointers, carries the running sums through memory (24 B per row) and pays its own ramp-up, which together cost
+// more than the 128-byte lines the blocked gathers no longer pull through the fabric.  Kept (mk_csr_set_colblocks,
+// MK_COLBLOCK_KB) because the mechanism -- carried row sums, gate / epilogue split over launches -- is exact and
+// the trade-off is different for wider rows.
+int cblocks_build(const mk_csr *A) {
+    MkPlan &P = A->plan;
+    const int64_t blk = colblock_bytes(A);
+    if (blk <= 0 || A->ex.mode >= 0 || A->nnz == 0) return MK_OK;
+    const int64_t xbytes = 8 * A->x_len();
+    if (xbytes <= 2 * blk) return MK_OK;
+    int K = (int)((xbytes + blk - 1) / blk);
+    if (K > CB_MAX) K = CB_MAX;
+    int64_t bw = (A->x_len() + K - 1) / K;
+    bw = (bw + 255) / 256 * 256;
+    K = (int)((A->x_len() + bw - 1) / bw);
+    if (K < 2) return MK_OK;
+    hipStream_t st = mk_ctx().stream;
+    const int64_t n1 = A->nrows + 1;
+    int32_t *d_cnt = nullptr;
+    MK_HIP(hipMalloc((void **)&d_cnt, sizeof(int32_t) * (size_t)(K * n1)));
+    MK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t)(K * n1), st));
+    int grid = (int)((A->nrows + MK_BLOCK - 1) / MK_BLOCK);
+    grid = grid < 1 ? 1 : (grid > 16384 ? 16384 : grid);
+    hipLaunchKernelGGL(cb_count, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, (int)bw, K, d_cnt);
+    std::vector<int32_t> h((size_t)(K * n1));
+    MK_HIP(hipMemcpyAsync(h.data(), d_cnt, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    hipFree(d_cnt);
+    CbPtrs ptrs{};
+    for (int b = 0; b < K; ++b) {
+        int32_t *row = h.data() + (size_t)b * n1;
+        for (int64_t r = 0; r < A->nrows; ++r) row[r + 1] += row[r];        // exclusive scan on the host (one-off)
+        mk_csr *B = nullptr;
+        int rc = mk_csr_alloc(A->nrows, A->ncols, row[A->nrows], &B);
+        if (rc != MK_OK) return rc;
+        B->plan.built = true;                                // a block is always a plain CSR stream
+        P.cblocks.push_back(B);
+        MK_HIP(hipMemcpyAsync(B->d_indptr, row, sizeof(int32_t) * (size_t)n1, hipMemcpyHostToDevice, st));
+        ptrs.indptr[b] = B->d_indptr;
+        ptrs.indices[b] = B->d_indices;
+        ptrs.data[b] = B->d_data;
+    }
+    hipLaunchKernelGGL(cb_scatter, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data,
+                       (int)bw, ptrs);
+    MK_HIP(hipMalloc((void **)&P.d_cbsum, sizeof(double) * (size_t)(A->nrows > 0 ? A->nrows : 1)));
+    MK_HIP(hipStreamSynchronize(st));
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+}
+
 // build the plan of an owning (non-alias) matrix; on any failure the matrix stays on the plain CSR path
 int plan_build(const mk_csr *A) {
     MkPlan &P = A->plan;
     P.built = true;
     P.fmt = 0;
     const int want = A->want_fmt >= 0 ? A->want_fmt : default_format();
-    if (want == 0 || A->nnz == 0 || A->ntiles == 0 || !mk_ctx().ready) return MK_OK;
+    if (A->nnz == 0 || A->ntiles == 0 || !mk_ctx().ready) return MK_OK;
+    auto plain = [&]() {                                     // plain CSR: column blocks if x is too long for an L2
+        if (cblocks_build(A) != MK_OK) {
+            for (mk_csr *B : P.cblocks) mk_csr_destroy(B);
+            P.cblocks.clear();
+            hipFree(P.d_cbsum);
+            P.d_cbsum = nullptr;
+        }
+        return MK_OK;
+    };
+    if (want == 0) return plain();
     hipStream_t st = mk_ctx().stream;
     const size_t pad = (size_t)A->nnz + MK_CSR_PAD;
     int *d_stats = nullptr;
@@ -271,7 +392,7 @@ int plan_build(const mk_csr *A) {
     if (2 * P.covered < A->ntiles) {                         // mostly scattered columns: not worth the second code path
         plan_free(P);
         P.built = true;
-        return MK_OK;
+        return plain();
     }
     P.fmt = 1;
     if (want < 2) return MK_OK;
@@ -359,5 +480,23 @@ extern "C" int mk_csr_launch_info(const mk_csr *A, int32_t *grid, int32_t *tile_
     MK_ARG(A != nullptr);
     if (grid) *grid = mk_grid_spmv_for(A);
     if (tile_map) *tile_map = mk_tile_map(A);
+    return MK_OK;
+}
+
+extern "C" int mk_csr_colblocks(const mk_csr *A, int32_t *nblocks) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr && nblocks != nullptr);
+    const MkPlan *P = mk_csr_plan(A);
+    *nblocks = (int32_t)P->cblocks.size();
+    return MK_OK;
+}
+
+extern "C" int mk_csr_set_colblocks(mk_csr *A, int32_t block_kb) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr && block_kb >= -1);
+    if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_colblocks: set it on the matrix a composed operator was built from");
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    plan_free(A->plan);
+    A->want_cb_kb = block_kb;
     return MK_OK;
 }

@@ -99,6 +99,10 @@ struct MkPlan {
     uint32_t *d_wn = nullptr;
     uint8_t *d_codes = nullptr;
     double *d_dict = nullptr;
+    // column blocks (plain-CSR matrices whose x does not fit an XCD's L2): A = [A_0 | A_1 | ...] by column range,
+    // each block a CSR matrix over all rows; a product runs block after block with the running row sums carried
+    std::vector<struct mk_csr *> cblocks;
+    double *d_cbsum = nullptr;     // nrows running sums
 };
 
 struct mk_csr {
@@ -112,6 +116,7 @@ struct mk_csr {
     const mk_csr *base = nullptr;  // ... this one (which also owns the windowed format)
     mutable MkPlan plan;
     int want_fmt = -1;             // mk_csr_set_format: -1 = library default (MK_SPMV_FORMAT or 2)
+    int want_cb_kb = -1;           // mk_csr_set_colblocks: -1 = library default (MK_COLBLOCK_KB or off)
     int32_t nops = 0;              // row program (mk_csr_compose)
     mk_rowop ops[MK_ROWPROG_MAX] = {};
     // length of the vector an SpMV reads (ncols, or n_local + n_halo with a halo plan)

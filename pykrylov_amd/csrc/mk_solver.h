@@ -203,7 +203,7 @@ static inline int mk_launch_stream(mk_solver *s, const Op &op, int64_t n) {
 template <class Epi, class Gate = MkNoGate>
 static inline int mk_launch_spmv_on(mk_solver *s, const mk_csr *M, const double *x, const Epi &epi,
                                     const Gate &gate = Gate()) {
-    mk_spmv_launch(M, mk_grid_spmv_for(M), s->stream, x, epi, gate, s->next_halt(), s->d_part);
+    mk_spmv_launch_blocks(M, mk_grid_spmv_for(M), s->stream, x, epi, gate, [&] { return s->next_halt(); }, s->d_part);
     return MK_OK;
 }
 
@@ -221,7 +221,7 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
         if (rc != MK_OK) return rc;
         mk_spmv_launch_view(mk_view_part(A, 2, g1), g2, s->stream, x, epi, gate, s->next_halt(), s->d_part);
     } else {
-        mk_spmv_launch(A, mk_grid_spmv_for(A), s->stream, x, epi, gate, s->next_halt(), s->d_part);
+        mk_spmv_launch_blocks(A, mk_grid_spmv_for(A), s->stream, x, epi, gate, [&] { return s->next_halt(); }, s->d_part);
     }
     if (timed) s->spmv_end();
     return MK_OK;

@@ -139,3 +139,106 @@ def test_transpose_and_composed_operators_use_the_format():
     shifted = op - 1.5 * IdentityOperator(A.shape[0])
     assert np.array_equal(shifted * x, A.matvec(x) - 1.5 * x)
     op.free()
+
+
+# ------------------------------------------------------------------------------------------------ column blocks
+def blocked(op, kb=2048):
+    """Turn column blocks on for this operator (they are off by default)."""
+    from pykrylov_amd import _lib
+    _lib.check(_lib.init().mk_csr_set_colblocks(op.handle, kb))
+    return op
+
+
+def colblocks(op):
+    from pykrylov_amd import _lib
+    k = ctypes.c_int32()
+    _lib.check(_lib.init().mk_csr_colblocks(op.handle, ctypes.byref(k)))
+    return k.value
+
+
+@pytest.fixture(scope="module")
+def big_random():
+    """Scattered columns and an x vector of 5.6 MB: does not fit an XCD's L2, so the product is column-blocked."""
+    return csr_ref.random_diagdom(700001, seed=4)
+
+
+def test_column_blocked_product_is_bit_exact(big_random):
+    from pykrylov_amd import CsrOperator, IdentityOperator
+    A = big_random
+    n = A.shape[0]
+    op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
+    assert fmt_info(op)["fmt"] == 0 and colblocks(op) == 0           # off by default
+    blocked(op)
+    assert fmt_info(op)["fmt"] == 0 and colblocks(op) == 3
+    rng = np.random.default_rng(8)
+    for x in (np.ones(n), rng.standard_normal(n), 1e180 * rng.standard_normal(n)):
+        assert np.array_equal(op * x, A.matvec(x))
+    # the row program of a composed operator runs once, on the finished sums
+    x = rng.standard_normal(n)
+    shifted = 2.0 * op - 0.5 * IdentityOperator(n)
+    assert np.array_equal(shifted * x, 2.0 * A.matvec(x) - 0.5 * x)
+    # transposed operator: its own blocks
+    assert np.array_equal(blocked(op.T) * x, A.rmatvec(x))
+    assert colblocks(op.T) == 3
+    op.free()
+
+
+@pytest.mark.parametrize("solver", ["bicgstab", "cgs", "tfqmr"])
+def test_column_blocked_solvers_bit_exact(big_random, solver):
+    """Fused epilogues and gates across the block launches: same bits as the oracle in the device's dot order."""
+    import pykrylov_amd
+    from pykrylov_amd import CsrOperator
+    from oracle import gpu_order, krylov_ref as kr
+    A = big_random
+    n = A.shape[0]
+    op = blocked(CsrOperator(A.indptr, A.indices, A.data, A.shape))
+    rhs = A.matvec(np.ones(n))
+    cls = {"bicgstab": pykrylov_amd.BiCGSTAB, "cgs": pykrylov_amd.CGS, "tfqmr": pykrylov_amd.TFQMR}[solver]
+    s = cls(op, reltol=1e-9)
+    s.solve(rhs, guess=np.linspace(0.5, 1.5, n))
+    geo = gpu_order.launch_geometry(op)
+    ref = getattr(kr, solver)(A, rhs, reltol=1e-9, guess=np.linspace(0.5, 1.5, n),
+                              red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES[solver], geo)))
+    assert s.nMatvec == ref["nMatvec"] and s.converged == ref["converged"]
+    assert s.residNorm == ref["residNorm"] and np.array_equal(s.x, ref["x"])
+    op.free()
+
+
+def test_column_blocked_minres_scaled_gather(big_random, monkeypatch):
+    """MINRES multiplies the gathered entries by 1/beta on the fly (epilogue `xin`): every block launch must do it."""
+    from pykrylov_amd import CsrOperator, Minres
+    from oracle import gpu_order, krylov_ref as kr
+    monkeypatch.setattr(kr, "_sq", lambda a: a * a)
+    R = big_random
+    n = R.shape[0]
+    rows = np.repeat(np.arange(n), np.diff(R.indptr))
+    S = csr_ref.from_coo(np.concatenate([rows, R.indices]), np.concatenate([R.indices, rows]),
+                         np.concatenate([R.data, R.data]), (n, n))                    # R + R^T: symmetric, scattered
+    op = blocked(CsrOperator(S.indptr, S.indices, S.data, S.shape, symmetric=True))
+    assert colblocks(op) == 3
+    rhs = S.matvec(np.ones(n))
+    s = Minres(op)
+    s.solve(rhs, show=False, check=False, etol=0.0, rtol=1e-12, itnlim=25)
+    ref = kr.minres(S, rhs, check=False, etol=0.0, rtol=1e-12, itnlim=25,
+                    red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["minres"], gpu_order.launch_geometry(op))))
+    assert (s.istop, s.itn) == (ref["istop"], ref["itn"])
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
+    op.free()
+
+
+def test_transpose_with_a_dense_column():
+    """a dense column used to put an O(len^2) insertion sort on one lane; such matrices are transposed by a
+    stable counting sort on the host.  Result: rows of A^T sorted by original row, bit-identical to the oracle."""
+    from pykrylov_amd import CsrOperator
+    rng = np.random.default_rng(2)
+    m, k = 30000, 400
+    rows = np.concatenate([np.arange(m), rng.integers(0, m, 60000)])
+    cols = np.concatenate([np.full(m, 7), rng.integers(0, k, 60000)])
+    A = csr_ref.from_coo(rows, cols, rng.standard_normal(len(rows)), (m, k))
+    op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
+    At = A.transpose()
+    tp, ti, td = op.T.to_csr_arrays()
+    assert np.array_equal(tp, At.indptr) and np.array_equal(ti, At.indices) and np.array_equal(td, At.data)
+    u = rng.standard_normal(m)
+    assert np.array_equal(op.T * u, A.rmatvec(u))
+    op.free()
