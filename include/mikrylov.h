@@ -105,6 +105,17 @@ typedef struct mk_rowop {
 } mk_rowop;
 int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops, mk_csr **out);
 
+/* Matrix-free operator: the products of the returned handle are computed by a HOST callback -- the reference's own
+ * operator protocol, `LinearOperator(nargin, nargout, matvec=callable)` (linop/linop.py:114,271-298), e.g. the gallery
+ * operators its CG test runs on (cg/tests/test_diagdom.py:38-40).  Everything else of a solver loop (dots, updates,
+ * scalar recurrences, stopping tests) still runs on the device: at each product site the loop's input vector is
+ * materialised on the device, copied to the host, `fn(user, transpose, x_host, y_host)` is called (x_host: ncols
+ * entries, or nrows when transpose != 0; return 0 on success), and the result feeds the same fused epilogue kernel
+ * a CSR product would have fed.  The callback is invoked exactly when the reference would have invoked `op * v`
+ * (never after the loop condition failed).  Single GPU only. */
+typedef int (*mk_matvec_fn)(void *user, int transpose, const double *x_host, double *y_host);
+int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn, void *user, int transpose, mk_csr **out);
+
 /* Storage format the products of A stream from HBM, chosen per matrix and built on the device at the first product
  * (an acceleration structure beside the CSR arrays; results are bit-identical in every format):
  *   0  plain CSR: 4-byte columns + 8-byte values, x gathered through L1/L2;

@@ -41,6 +41,8 @@ HOST_EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTE
                                     ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
                                     ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64))
 HOST_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+# matrix-free operator callback (mk_csr_create_callback): fn(user, transpose, x_host, y_host) -> 0 on success
+MATVEC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class MkResult(ctypes.Structure):
@@ -68,6 +70,7 @@ PROTOTYPES = {
     "mk_calib_stream": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int]),
     "mk_csr_create": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),
     "mk_csr_destroy": (ctypes.c_int, [c_vp]),
+    "mk_csr_create_callback": (ctypes.c_int, [c_i64, c_i64, MATVEC_FN, c_vp, ctypes.c_int, P(c_vp)]),
     "mk_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),
     "mk_csr_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "mk_csr_from_coo": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),

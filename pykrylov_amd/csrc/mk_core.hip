@@ -219,9 +219,65 @@ extern "C" int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops
     return MK_OK;
 }
 
+extern "C" int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn, void *user, int transpose,
+                                      mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(nrows >= 0 && ncols >= 0 && fn != nullptr && out != nullptr);
+    MK_ARG(nrows <= 2147483647LL && ncols <= 2147483647LL);
+    mk_csr *A = new mk_csr();
+    A->nrows = nrows;
+    A->ncols = ncols;
+    A->nnz = 0;
+    A->ntiles = (nrows + MK_ROWS_PER_TILE - 1) / MK_ROWS_PER_TILE;
+    A->host_fn = fn;
+    A->host_user = user;
+    A->host_transpose = transpose;
+    A->plan.built = true;
+    const size_t nin = (size_t)(ncols > 0 ? ncols : 1), nout = (size_t)(nrows > 0 ? nrows : 1);
+    if (hipHostMalloc((void **)&A->h_cb_in, sizeof(double) * nin, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&A->h_cb_out, sizeof(double) * nout, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&A->d_cb_in, sizeof(double) * nin + 16) != hipSuccess ||
+        hipMalloc((void **)&A->d_cb_out, sizeof(double) * nout + 16) != hipSuccess ||
+        hipMalloc((void **)&A->d_cb_go, sizeof(int)) != hipSuccess) {
+        mk_csr_destroy(A);
+        return mk_fail(MK_ERR_HIP, "mk_csr_create_callback: allocation failed for %lld x %lld", (long long)nrows,
+                       (long long)ncols);
+    }
+    *out = A;
+    return MK_OK;
+}
+
+// the host side of a matrix-free product: reads the gate's decision, and if the product is wanted copies the
+// materialised input to the host, calls the operator, and puts the result where the epilogue launch reads it
+int mk_host_product(const mk_csr *A, hipStream_t st) {
+    int go = 0;
+    MK_HIP(hipMemcpyAsync(&go, A->d_cb_go, sizeof(int), hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    if (!go) return MK_OK;                                   // loop condition failed (or halted): the reference would
+                                                             // not have called `op * v` either
+    if (A->ncols > 0)
+        MK_HIP(hipMemcpyAsync(A->h_cb_in, A->d_cb_in, sizeof(double) * (size_t)A->ncols, hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    if (A->host_fn(A->host_user, A->host_transpose, A->h_cb_in, A->h_cb_out) != 0)
+        return mk_fail(MK_ERR_STATE, "the host operator callback reported a failure");
+    if (A->nrows > 0)
+        MK_HIP(hipMemcpyAsync(A->d_cb_out, A->h_cb_out, sizeof(double) * (size_t)A->nrows, hipMemcpyHostToDevice, st));
+    return MK_OK;
+}
+
 extern "C" int mk_csr_destroy(mk_csr *A) {
     if (!A) return MK_OK;
     if (A->alias) {
+        delete A;
+        return MK_OK;
+    }
+    if (A->host_fn) {
+        if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+        if (A->h_cb_in) hipHostFree(A->h_cb_in);
+        if (A->h_cb_out) hipHostFree(A->h_cb_out);
+        hipFree(A->d_cb_in);
+        hipFree(A->d_cb_out);
+        hipFree(A->d_cb_go);
         delete A;
         return MK_OK;
     }
@@ -275,6 +331,11 @@ extern "C" int mk_spmv(const mk_csr *A, const double *x, double *y) {
     MkPlainEpi epi{y};
     mk_spmv_launch(A, mk_grid_spmv_for(A), mk_ctx().stream, x, epi, MkNoGate(), never_halt(), mk_ctx().d_scratch);
     MK_HIP(hipGetLastError());
+    if (mk_ctx().pending_rc != MK_OK) {
+        const int rc = mk_ctx().pending_rc;
+        mk_ctx().pending_rc = MK_OK;
+        return rc;
+    }
     return MK_OK;
 }
 

@@ -47,6 +47,13 @@ struct MkCsrView {
     const double *dict;
     // column-blocked products (fmt 0): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
     const double *sum_in;
+    // matrix-free operators (host callback): cb_mode 1 = materialise the product's input vector (`vin[j] = xin(x[j])`,
+    // `xlen` entries) and report the gate's decision in *cb_go; 2 = the row sums are the entries of `y_ext`
+    int cb_mode;
+    int64_t xlen;
+    double *vin;
+    const double *y_ext;
+    int *cb_go;
 };
 
 // Working sets that fit the 256 MiB Infinity Cache profit from XCD-local tile ranges (every x line is then
@@ -57,12 +64,14 @@ static inline int mk_xcd_chunks(const mk_csr *A) {
     return bytes <= (int64_t)200 * 1024 * 1024 ? 1 : 0;
 }
 static inline int mk_tile_map(const mk_csr *A) {
+    if (A->host_fn) return 0;
     static const char *env = getenv("MK_SPMV_MAP");
     if (env) return atoi(env);
     return mk_xcd_chunks(A) ? 1 : 0;
 }
 
 const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
+int mk_host_product(const mk_csr *A, hipStream_t st);   // mk_core.hip: D2H, host callback, H2D of a matrix-free operator
 
 // SpMV grid = the workgroups that are resident at once (persistent tiles; a second round only adds a tail).
 // CSR path: 4 per CU at <= 64 registers, twice as many smaller shares while the problem is cache resident.
@@ -70,7 +79,7 @@ const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the wi
 // n = 1e6: 1024 / 1280 workgroups beat every other count by 5-25 % (tools/sweep_fmt.sh).
 static inline int mk_grid_spmv_for(const mk_csr *A) {
     int g = mk_grid_spmv(A->ntiles);
-    if (getenv("MK_GRID_SPMV")) return g;
+    if (getenv("MK_GRID_SPMV") || A->host_fn) return g;
     const MkPlan *P = mk_csr_plan(A);
     int64_t cap = mk_cap_spmv();
     if (P && P->fmt == 2) cap = 1280;
@@ -504,12 +513,34 @@ __global__ __launch_bounds__(MK_BLOCK, FMT == 0 ? 8 : (FMT == 1 ? 4 : 5)) void m
     bool stop = false;
     const bool go = gate.open(s4, lead && A.part != 2, &stop);     // part 2 repeats the decision, not the writes
     if (lead) halt.out(stop);
+    if constexpr (FMT == 0 && !PROG) {
+        if (lead && A.cb_mode == 1) *A.cb_go = go ? 1 : 0;          // (zeroed by the host before the launch)
+    }
     if (!go) return;
     epi.prologue(s4);
     double acc[Epi::NACC > 0 ? Epi::NACC : 1];
 #pragma unroll
     for (int d = 0; d < (Epi::NACC > 0 ? Epi::NACC : 1); ++d) acc[d] = 0.0;
-    mk_spmv_tiles<FMT, PROG>(A, x, epi, prod, xw, acc);
+    if constexpr (FMT == 0 && !PROG) {
+        if (A.cb_mode == 1) {                                       // matrix-free operator: the callback's input
+            for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < A.xlen; j += (int64_t)gridDim.x * MK_BLOCK)
+                A.vin[j] = epi.xin(x[j]);
+            return;
+        }
+        if (A.cb_mode == 2) {                                       // ... and its result through the row epilogue
+            for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+                const int64_t r = tile * MK_ROWS_PER_TILE + threadIdx.x;
+                if (r < A.nrows) {
+                    if constexpr (MkHasPre<Epi>::value) epi.pre(r);
+                    epi.row(r, A.y_ext[r], acc);
+                }
+            }
+        } else {
+            mk_spmv_tiles<FMT, PROG>(A, x, epi, prod, xw, acc);
+        }
+    } else {
+        mk_spmv_tiles<FMT, PROG>(A, x, epi, prod, xw, acc);
+    }
 #pragma unroll
     for (int d = 0; d < Epi::NACC; ++d) {
         const double tot = mk_block_sum(acc[d], s4);
@@ -561,6 +592,26 @@ struct MkPartialOf {
 template <class Epi, class Gate, class HaltSrc>
 static inline void mk_spmv_launch_blocks(const mk_csr *A, int grid, hipStream_t st, const double *x, const Epi &epi,
                                          const Gate &gate, HaltSrc &&next, double *partials) {
+    if (A->host_fn) {
+        // Matrix-free operator.  Launch 1 evaluates the gate (with its side effects) and materialises the input
+        // vector; the host calls the operator if the gate let the product through; launch 2 repeats the gate's
+        // decision (no side effects) and feeds the result to the real epilogue.
+        MkCsrView v = mk_view(A);
+        v.cb_go = A->d_cb_go;
+        v.vin = A->d_cb_in;
+        v.y_ext = A->d_cb_out;
+        v.xlen = A->ncols;
+        v.cb_mode = 1;
+        v.part = 1;
+        hipMemsetAsync(A->d_cb_go, 0, sizeof(int), st);
+        mk_spmv_launch_view(v, grid, st, x, MkPartialOf<Epi>{epi, nullptr}, gate, next(), partials);
+        const int rc = mk_host_product(A, st);
+        if (rc != MK_OK && mk_ctx().pending_rc == MK_OK) mk_ctx().pending_rc = rc;
+        v.cb_mode = 2;
+        v.part = 2;
+        mk_spmv_launch_view(v, grid, st, x, epi, gate, next(), partials);
+        return;
+    }
     const MkPlan *P = mk_csr_plan(A);
     const size_t K = (P && A->ex.mode < 0) ? P->cblocks.size() : 0;
     if (K < 2) {

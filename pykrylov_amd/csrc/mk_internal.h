@@ -31,6 +31,7 @@ struct MkContext {
     hipStream_t stream = nullptr;
     int num_cu = 0;
     std::string last_error;
+    int pending_rc = 0;              // error raised inside an enqueue helper that cannot return it (host callbacks)
     // pinned staging for scalar read-backs
     double *h_scratch = nullptr;     // MK_MAXP * MK_NDOT doubles
     double *d_scratch = nullptr;
@@ -117,6 +118,13 @@ struct mk_csr {
     mutable MkPlan plan;
     int want_fmt = -1;             // mk_csr_set_format: -1 = library default (MK_SPMV_FORMAT or 2)
     int want_cb_kb = -1;           // mk_csr_set_colblocks: -1 = library default (MK_COLBLOCK_KB or off)
+    // matrix-free operator (mk_csr_create_callback): no arrays; products come from a host callback
+    mk_matvec_fn host_fn = nullptr;
+    void *host_user = nullptr;
+    int host_transpose = 0;
+    double *h_cb_in = nullptr, *h_cb_out = nullptr;    // pinned staging (x_len / nrows doubles)
+    double *d_cb_in = nullptr, *d_cb_out = nullptr;    // device: materialised input, product
+    int *d_cb_go = nullptr;                            // device flag: the gate let this product through
     int32_t nops = 0;              // row program (mk_csr_compose)
     mk_rowop ops[MK_ROWPROG_MAX] = {};
     // length of the vector an SpMV reads (ncols, or n_local + n_halo with a halo plan)

@@ -140,6 +140,11 @@ int mk_solver::iterate(int64_t max_iters, int64_t *done) {
             ++it;
         }
         MK_HIP(hipGetLastError());
+        if (mk_ctx().pending_rc != MK_OK) {                  // (a host operator callback failed)
+            const int prc = mk_ctx().pending_rc;
+            mk_ctx().pending_rc = MK_OK;
+            return prc;
+        }
         launched += todo;
         int rc = poll();
         if (rc != MK_OK) return rc;
@@ -242,6 +247,11 @@ extern "C" int mk_solver_setup(mk_solver *s, const double *rhs, const double *gu
     int rc = s->setup(rhs, guess);
     if (rc != MK_OK) return rc;
     MK_HIP(hipGetLastError());
+    if (mk_ctx().pending_rc != MK_OK) {
+        rc = mk_ctx().pending_rc;
+        mk_ctx().pending_rc = MK_OK;
+        return rc;
+    }
     s->is_setup = true;
     return s->poll();
 }

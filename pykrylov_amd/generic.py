@@ -3,9 +3,10 @@ plus the glue every device-resident solver of this package shares.
 
 A solver object keeps pykrylov's constructor keywords (`abstol`, `reltol`, `precon`,
 `logger`; unknown keywords are ignored as in generic.py:74-77) and result attributes.
-`solve()` hands the whole loop to `libmikrylov.so`: the operator must therefore be a
-:class:`pykrylov_amd.linop.CsrOperator` (matrix resident in HBM).  Anything else raises
-`TypeError` -- this package has no host implementation of the loops to fall back to.
+`solve()` hands the whole loop to `libmikrylov.so`.  With a :class:`pykrylov_amd.linop.CsrOperator` (matrix
+resident in HBM) the products run on the device too; any other operator of the reference's protocol
+(``op * vector``) is called back on the host at each product site while the rest of the loop stays on the device
+(:class:`pykrylov_amd.linop.HostOperatorShell`).  There is no host implementation of the loops in this package.
 """
 import ctypes
 import logging
@@ -59,12 +60,19 @@ class KrylovMethod(object):
 
     # ------------------------------------------------------------------ device glue
     def _device_operator(self):
-        from .linop import CsrOperator
-        if not isinstance(self.op, CsrOperator):
-            raise TypeError('%s runs its loop on the GPU and needs a pykrylov_amd.linop.CsrOperator; got %r. '
-                            'Build one with CsrOperator(indptr, indices, data, shape) or pykrylov_amd.gallery.'
-                            % (self.__class__.__name__, type(self.op).__name__))
-        return self.op
+        """The operator as the device loop sees it: a CsrOperator (matrix in HBM, products on the device) or, for
+        any other operator of the reference's protocol, a shell whose products call back into it on the host
+        (the loop itself -- dots, updates, recurrences, stopping tests -- stays on the device either way)."""
+        from .linop import CsrOperator, HostOperatorShell
+        if isinstance(self.op, CsrOperator):
+            return self.op
+        sh = getattr(self, '_host_shell', None)
+        if sh is None or sh.host_op is not self.op:
+            if not hasattr(self.op, 'shape') or not hasattr(self.op, '__mul__'):
+                raise TypeError('%s needs an operator with `.shape` and `op * vector`; got %r'
+                                % (self.__class__.__name__, type(self.op).__name__))
+            sh = self._host_shell = HostOperatorShell(self.op)
+        return sh
 
     def _no_precon(self, precon):
         if precon is not None:
@@ -134,14 +142,19 @@ class DeviceRun(object):
         self.result = _lib.MkResult()
         self._setup_done = False
 
+    def _check(self, rc):
+        if rc != 0 and hasattr(self.op, 'raise_pending'):
+            self.op.raise_pending()                           # what a matrix-free operator raised in its callback
+        _lib.check(rc)
+
     def setup(self):
-        _lib.check(self.lib.mk_solver_setup(self.handle, self.d_rhs.ptr,
-                                            None if self.d_guess is None else self.d_guess.ptr))
+        self._check(self.lib.mk_solver_setup(self.handle, self.d_rhs.ptr,
+                                             None if self.d_guess is None else self.d_guess.ptr))
         self._setup_done = True
 
     def iterate(self, max_iters):
         done = ctypes.c_int64(0)
-        _lib.check(self.lib.mk_solver_iterate(self.handle, int(max_iters), ctypes.byref(done)))
+        self._check(self.lib.mk_solver_iterate(self.handle, int(max_iters), ctypes.byref(done)))
         return done.value
 
     def finish(self):

@@ -632,6 +632,75 @@ class CsrOperator(LinearOperator):
         self.free()
 
 
+class HostOperatorShell(object):
+    """What the device solvers see of an operator that is NOT a CsrOperator: any object following the reference's
+    protocol, ``op * ndarray -> ndarray`` (linop.py:271-298, e.g. ``LinearOperator(n, n, matvec=callable)`` or the
+    gallery operators of cg/tests/test_diagdom.py:38-40).  The solver loop stays on the device; at every product site
+    libmikrylov copies the loop's input vector to the host and calls back into `op` (mk_csr_create_callback), exactly
+    when the reference would have evaluated ``op * v`` -- so ``op.nMatvec`` counts what it counts in the reference.
+    An exception raised by the operator aborts the solve and is re-raised to the caller."""
+
+    def __init__(self, op):
+        self.host_op = op
+        self.error = None
+        nargout, nargin = op.shape
+        self.shape = (int(nargout), int(nargin))
+        self.symmetric = bool(getattr(op, 'symmetric', False))
+        self.local_size = None
+        self._nMatvec = 0                                   # (the wrapped operator keeps the real count itself)
+        self._T = None
+        self._lib = _lib.init()
+        nrows, ncols = self.shape
+
+        def call(user, transpose, xp, yp):
+            try:
+                x = np.ctypeslib.as_array(ctypes.cast(xp, ctypes.POINTER(ctypes.c_double)), shape=(ncols,)).copy()
+                y = np.asarray(self.host_op * x)
+                if _is_complex(y.dtype):
+                    raise TypeError('operator returned complex data; the device solvers are fp64-only')
+                if y.shape != (nrows,):
+                    raise ValueError('operator returned shape %s, expected (%d,)' % (y.shape, nrows))
+                np.ctypeslib.as_array(ctypes.cast(yp, ctypes.POINTER(ctypes.c_double)), shape=(nrows,))[:] = y
+                return 0
+            except BaseException as exc:                    # noqa: B902  (must not propagate through the C frames)
+                self.error = exc
+                return 1
+        self._cb = _lib.MATVEC_FN(call)                     # keep the thunk alive
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.mk_csr_create_callback(nrows, ncols, self._cb, None, 0, ctypes.byref(h)))
+        self._handle = h.value
+
+    handle = property(lambda self: self._handle)
+    nnz = 0
+
+    @property
+    def T(self):
+        if self.symmetric:
+            return self
+        if self._T is None:
+            self._T = HostOperatorShell(self.host_op.T)
+            self._T._T = self
+        return self._T
+
+    def raise_pending(self):
+        "Re-raise what the wrapped operator raised inside a callback (called when a libmikrylov call failed)."
+        for sh in (self, self._T):
+            if sh is not None and sh.error is not None:
+                err, sh.error = sh.error, None
+                raise err
+
+    def free(self):
+        if getattr(self, '_handle', None):
+            try:
+                self._lib.mk_csr_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    def __del__(self):
+        self.free()
+
+
 class _ComposedCsrOperator(CsrOperator):
     """A CsrOperator with a row program (see CsrOperator._compose).  Products are counted on this operator and on
     the matrix it was built from, as the reference's composite closures do (linop.py:356-360 via `self(y)`)."""

@@ -81,7 +81,11 @@ class _LlsBase(KrylovMethod):
             if d_dm is not None or d_dn is not None:
                 _lib.check(lib.mk_solver_set_lls_precon(handle, None if d_dm is None else d_dm.ptr,
                                                         None if d_dn is None else d_dn.ptr))
-            _lib.check(lib.mk_solver_setup(handle, d_rhs.ptr, None))
+            def chk(rc):
+                if rc != 0 and hasattr(A, 'raise_pending'):
+                    A.raise_pending()                         # what a matrix-free operator raised in its callback
+                _lib.check(rc)
+            chk(lib.mk_solver_setup(handle, d_rhs.ptr, None))
             res = _lib.MkResult()
             _lib.check(lib.mk_solver_finish(handle, ctypes.byref(res)))
             nx = m if x_rows else n
@@ -94,7 +98,7 @@ class _LlsBase(KrylovMethod):
                 self.iterates.append(get_x())
             while not res.halted:
                 done = ctypes.c_int64()
-                _lib.check(lib.mk_solver_iterate(handle, 1 if store_iterates else (1 << 20), ctypes.byref(done)))
+                chk(lib.mk_solver_iterate(handle, 1 if store_iterates else (1 << 20), ctypes.byref(done)))
                 last_itn = int(res.itn)
                 _lib.check(lib.mk_solver_finish(handle, ctypes.byref(res)))
                 if store_iterates and int(res.itn) > last_itn:

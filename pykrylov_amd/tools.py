@@ -21,6 +21,7 @@ def check_symmetric(op, repeats=10):
     are counted in ``op.nMatvec`` as the reference does.
     """
     from .linop import CsrOperator
+    op = getattr(op, 'host_op', op)                           # (solver-side shell of a matrix-free operator)
     if getattr(op, 'local_size', None) is not None:
         return _check_symmetric_partitioned(op, repeats)
     m, n = op.shape

@@ -245,11 +245,18 @@ def test_operator_algebra():
     assert op.T is None and op.H is None
 
 
-def test_solver_rejects_host_operator():
-    from pykrylov_amd import CG, LinearOperator
-    op = LinearOperator(4, 4, matvec=lambda v: 2 * v, symmetric=True)
+def test_solver_rejects_non_operators_and_needs_a_gpu_for_host_operators():
+    """A matrix-free operator is accepted (its products are called back from the device loop, test_gpu_hostop.py),
+    but the loop itself has no host implementation: without a GPU the solve fails loudly.  Objects that are not
+    operators at all are a TypeError."""
+    from pykrylov_amd import CG, LinearOperator, _lib
     with pytest.raises(TypeError):
-        CG(op).solve(np.ones(4))
+        CG(object()).solve(np.ones(4))
+    op = LinearOperator(4, 4, matvec=lambda v: 2 * v, symmetric=True)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.MkError):
+            CG(op).solve(np.ones(4))
 
 
 def test_default_limits_use_the_global_size(monkeypatch):
