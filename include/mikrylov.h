@@ -279,6 +279,15 @@ int mk_solver_set_transpose(mk_solver *s, const mk_csr *At);
  * linop.DiagonalOperator(diag) (linop.py:473-516) multiplies by.  Borrowed: it must stay alive until the solver
  * is destroyed.  NULL removes it.  Call before mk_solver_setup.  MK_ERR_UNSUPPORTED for the lls kinds. */
 int mk_solver_set_precon_diag(mk_solver *s, const double *diag);
+/* General preconditioner: any operator the reference would apply as `precon * r` (generic/generic.py:76), evaluated
+ * by a HOST callback `fn(user, r_host, y_host)` (n entries each; return 0 on success).  The loop stays on the device: at
+ * each preconditioner site the vector is copied to the host, the callback runs, and the inner product that involves
+ * its result is formed on the device afterwards.  Not invoked once the loop has halted; in BiCGSTAB / CGS / TFQMR the
+ * application that precedes a product happens before that product's loop test, so the callback may run once more
+ * than in the reference (its last result is unused).  The six square solvers; MK_ERR_UNSUPPORTED for the lls kinds
+ * and on partitioned operators.  Replaces a diagonal set earlier.  Call before mk_solver_setup. */
+typedef int (*mk_precon_fn)(void *user, const double *r_host, double *y_host);
+int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void *user);
 /* The least-squares kinds take two preconditioners, applied by the reference as `u = M(Mu)` in the m-space and
  * `v = N(Nv)` in the n-space of the Golub-Kahan process (lls/lsqr.py:189-190,201-202,253-254,265-266 and the same
  * lines of lsmr.py, craig.py, craigmr.py): device arrays with the diagonals of M (nrows(A) entries) and N

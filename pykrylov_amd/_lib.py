@@ -43,6 +43,8 @@ HOST_EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTE
 HOST_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 # matrix-free operator callback (mk_csr_create_callback): fn(user, transpose, x_host, y_host) -> 0 on success
 MATVEC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+# general preconditioner callback (mk_solver_set_precon_callback): fn(user, r_host, y_host) -> 0 on success
+PRECON_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class MkResult(ctypes.Structure):
@@ -107,6 +109,7 @@ PROTOTYPES = {
     "mk_solver_destroy": (ctypes.c_int, [c_vp]),
     "mk_solver_set_transpose": (ctypes.c_int, [c_vp, c_vp]),
     "mk_solver_set_precon_diag": (ctypes.c_int, [c_vp, c_vp]),
+    "mk_solver_set_precon_callback": (ctypes.c_int, [c_vp, PRECON_FN, c_vp]),
     "mk_solver_set_lls_precon": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mk_solver_setup": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mk_solver_iterate": (ctypes.c_int, [c_vp, c_i64, P(c_i64)]),

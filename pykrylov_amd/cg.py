@@ -6,7 +6,7 @@ the GPU (``csrc/mk_cg.hip``: 3 fused kernels per iteration, no host round trip).
 import numpy as np
 
 from . import _lib
-from .generic import KrylovMethod, DeviceRun
+from .generic import KrylovMethod, DeviceRun, HostPrecon
 from .tools import check_symmetric
 
 __docformat__ = 'restructuredtext'
@@ -53,6 +53,11 @@ class CG(KrylovMethod):
         guess = kwargs.get('guess', None)
         matvec_max = kwargs.get('matvec_max', 2 * n)
 
+        def prec(r):                                                   # y = precon * r for `store_resids` (cg.py:96,133)
+            if pdiag is None:
+                return r
+            return pdiag.precon * r if isinstance(pdiag, HostPrecon) else pdiag * r
+
         with DeviceRun(op, _lib.MK_CG, rhs, guess, precon_diag=pdiag, abstol=float(self.abstol),
                        reltol=float(self.reltol),
                        matvec_max=int(matvec_max),
@@ -64,7 +69,7 @@ class CG(KrylovMethod):
                 if store_iterates:
                     self.iterates.append(run.x())
                 if store_resids:
-                    self.resids.append(run.vector(0) if pdiag is None else pdiag * run.vector(0))
+                    self.resids.append(prec(run.vector(0)))
                 while not res.halted:
                     run.iterate(1)
                     res = run.finish()
@@ -72,7 +77,7 @@ class CG(KrylovMethod):
                         if store_iterates:
                             self.iterates.append(run.x())
                         if store_resids:
-                            self.resids.append(run.vector(0) if pdiag is None else pdiag * run.vector(0))
+                            self.resids.append(prec(run.vector(0)))
             else:
                 res = run.run()
             x = run.x()

@@ -293,6 +293,7 @@ struct BicgstabSolver : mk_solver {
         mk_launch_stream(this, MkOpCopy{d_r0, d_r}, n);
         mk_launch_stream(this, MkOpCopy{d_r0, d_p}, n);
         if (d_prec) mk_launch_stream(this, MkOpMul{d_prec, d_r0, d_q}, n);     // q = precon * p   bicgstab.py:96-97
+        if (precon_fn && host_precon(d_r0, d_q) != MK_OK) return MK_ERR_STATE;
         MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)n, stream));
         return MK_OK;
     }
@@ -305,13 +306,15 @@ struct BicgstabSolver : mk_solver {
     int enqueue_pass() override {
         const int par = (int)(it & 1);
         double *qin = d_prec ? d_q : d_p, *zin = d_prec ? d_z : d_s;           // what the two products read
-        int rc = exchange(qin);
-        if (rc != MK_OK) return rc;
+        int rc;
+        if (precon_fn && it > 0 && (rc = host_precon(d_p, d_q)) != MK_OK) return rc;   // q = precon * p  bicgstab.py:96-97
+        if ((rc = exchange(qin)) != MK_OK) return rc;
         mk_launch_spmv(this, qin, BEpi{d_r0, d_v}, true,
                        GateB{d_part, np_stream, d_scal, d_status, it == 0 ? 1 : 0, prm.matvec_max, nmv0 + 2 * it});
         if ((rc = allreduce(SLOT_R0V, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_r, d_v, d_s, d_prec, d_z, 0.0}, n);
         if ((rc = allreduce(SLOT_SS, 1)) != MK_OK) return rc;
+        if (precon_fn && (rc = host_precon(d_s, d_z)) != MK_OK) return rc;     // z = precon * s       bicgstab.py:120-121
         if ((rc = exchange(zin)) != MK_OK) return rc;
         mk_launch_spmv(this, zin, DEpi{d_s, d_r0, d_t}, true,
                        GateD{d_part, np_stream, d_scal, d_status, prm.matvec_max, nmv0 + 2 * it + 1});

@@ -183,6 +183,7 @@ struct CgSolver : mk_solver {
         }
         if (d_prec) {
             mk_launch_stream(this, MkOpMul{d_prec, d_r, d_Ap}, n);          // y = precon * r    cg.py:91-92
+            if (precon_fn && host_precon(d_r, d_Ap) != MK_OK) return MK_ERR_STATE;
             mk_launch_stream(this, MkOpDot<1>{d_r, d_Ap}, n);               // ry = <r, y>       cg.py:99
         } else {
             mk_launch_stream(this, MkOpDot<1>{d_r, d_r}, n);                // ry = <r, r>       cg.py:99
@@ -208,6 +209,10 @@ struct CgSolver : mk_solver {
         if ((rc = allreduce(0, 1)) != MK_OK) return rc;
         mk_launch_stream(this, CgUpdateR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_Ap, d_r,
                                          d_prec, 0.0, false}, n);
+        if (precon_fn) {                                    // y = precon * r ; <r, y> re-formed   cg.py:137-138,146
+            if ((rc = host_precon(d_r, d_Ap)) != MK_OK) return rc;
+            mk_launch_stream(this, MkOpDot<1>{d_r, d_Ap}, n);
+        }
         if ((rc = allreduce(1, 1)) != MK_OK) return rc;
         mk_launch_stream(this, CgUpdateXP{d_part, np_stream, d_scal, d_status, d_hist, par, prm.matvec_max, d_r, d_p,
                                           d_x, 0.0, 0.0}, n);

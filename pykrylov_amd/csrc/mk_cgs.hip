@@ -46,6 +46,7 @@ struct OpC {
     double *q, *z, *x;
     const double *dg;                                                         // preconditioner diagonal or null
     double alpha;
+    int defer_x;              // host preconditioner: z is replaced after this kernel, x += alpha z follows (OpXZ)
     __device__ bool prologue(double *s4, bool lead) {
         const double sigma = mk_total(part + SLOT_SIGMA * MK_MAXP, np, s4);   // cgs.py:84
         alpha = scal[S_RHO0 + par] / sigma;                                   // cgs.py:85
@@ -57,7 +58,7 @@ struct OpC {
         qv = uv - alpha * vv;                                                 // cgs.py:86
         zv = uv + qv;                                                         // cgs.py:91
         if (dg) zv = dv * zv;                                                 // cgs.py:88-89
-        xv = xv + alpha * zv;                                                 // cgs.py:94
+        if (!defer_x) xv = xv + alpha * zv;                                   // cgs.py:94
     }
     __device__ void pair(int64_t i, double *) {
         const double2 uv = mk_ld2(u, i), vv = mk_ld2(v, i);
@@ -76,6 +77,27 @@ struct OpC {
         z[i] = zv;
         x[i] = xv;
     }
+};
+
+struct OpXZ {    // x += alpha z with the device's alpha (host preconditioner: z = precon * (u + q) came from the host)
+    static constexpr int NACC = 0, SLOT0 = 0;
+    const double *scal;
+    const double *z;
+    double *x;
+    double alpha;
+    __device__ bool prologue(double *, bool) {
+        alpha = scal[S_ALPHA];
+        return false;
+    }
+    __device__ bool skip() const { return false; }
+    __device__ void pair(int64_t i, double *) {
+        const double2 zv = mk_ld2(z, i);
+        double2 xv = mk_ld2(x, i);
+        xv.x = xv.x + alpha * zv.x;                                           // cgs.py:94
+        xv.y = xv.y + alpha * zv.y;
+        mk_st2(x, i, xv);
+    }
+    __device__ void one(int64_t i, double *) { x[i] = x[i] + alpha * z[i]; }
 };
 
 struct DEpi {    // Az = A z ; r -= alpha Az ; <r,r>, <r0,r>
@@ -206,17 +228,23 @@ struct CgsSolver : mk_solver {
         mk_launch_stream(this, MkOpCopy{d_r0, d_u}, n);                        // u = r0           cgs.py:73
         mk_launch_stream(this, MkOpCopy{d_r0, d_p}, n);                        // p = r0.copy()    cgs.py:74
         if (d_prec) mk_launch_stream(this, MkOpMul{d_prec, d_r0, d_y}, n);     // y = precon * p   cgs.py:79-80
+        if (precon_fn && (rc = host_precon(d_p, d_y)) != MK_OK) return rc;
         return MK_OK;
     }
 
     int enqueue_pass() override {
         const int par = (int)(it & 1);
         double *yin = d_prec ? d_y : d_p;
-        int rc = exchange(yin);
-        if (rc != MK_OK) return rc;
+        int rc;
+        if (precon_fn && it > 0 && (rc = host_precon(d_p, d_y)) != MK_OK) return rc;   // y = precon * p   cgs.py:79-80
+        if ((rc = exchange(yin)) != MK_OK) return rc;
         mk_launch_spmv(this, yin, BEpi{d_r0, d_v}, true, CountGate{d_status, 2 * it});
         if ((rc = allreduce(SLOT_SIGMA, 1)) != MK_OK) return rc;
-        mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_u, d_v, d_q, d_z, d_x, d_prec, 0.0}, n);
+        mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_u, d_v, d_q, d_z, d_x, d_prec, 0.0, precon_fn ? 1 : 0}, n);
+        if (precon_fn) {                                    // z = precon * (u + q) ; x += alpha z     cgs.py:88-94
+            if ((rc = host_precon(d_z, d_z)) != MK_OK) return rc;
+            mk_launch_stream(this, OpXZ{d_scal, d_z, d_x, 0.0}, n);
+        }
         if ((rc = exchange(d_z)) != MK_OK) return rc;
         mk_launch_spmv(this, d_z, DEpi{d_scal, d_r0, d_r, 0.0}, true, CountGate{d_status, 2 * it + 1});
         if ((rc = allreduce(SLOT_RR, 2)) != MK_OK) return rc;

@@ -326,6 +326,7 @@ struct MinresSolver : mk_solver {
         if (d_prec) {
             if (!d_y && (rc0 = alloc_vec(&d_y, nx))) return rc0;
             mk_launch_stream(this, MkOpMul{d_prec, d_r[0], d_y}, n);           // y = precon * b    minres.py:162-163
+            if (precon_fn && host_precon(d_r[0], d_y) != MK_OK) return MK_ERR_STATE;
             mk_launch_stream(this, MkOpDot<SLOT_YY>{d_r[0], d_y}, n);          // beta1 = <b, y>    minres.py:166
         } else {
             mk_launch_stream(this, MkOpDot<SLOT_YY>{d_r[0], d_r[1]}, n);       // beta1 = <b, y>    minres.py:166
@@ -352,6 +353,10 @@ struct MinresSolver : mk_solver {
                        GateK1{d_status, it, prm.itnlim});
         if ((rc = allreduce(SLOT_ALFA, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpK2{d_part, np_spmv, d_scal, blk, r2, d_t, r1, d_prec, d_y, 0.0}, n);
+        if (precon_fn) {                                    // y = precon * r2 ; <r2, y> re-formed   minres.py:249-251
+            if ((rc = host_precon(r1, d_y)) != MK_OK) return rc;          // (OpK2 wrote the new r2 into r1's storage)
+            mk_launch_stream(this, MkOpDot<SLOT_YY>{r1, d_y}, n);
+        }
         if ((rc = allreduce(SLOT_YY, 1)) != MK_OK) return rc;
         // reference: w1 = w2 ; w2 = w ; w = f(v, w1, w2).  With storage (a, b, c) = (old w1, old w2, old w):
         // new w1 = b, new w2 = c, new w is written into a.

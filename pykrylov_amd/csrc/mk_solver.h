@@ -32,6 +32,13 @@ struct mk_solver {
     const mk_csr *A = nullptr;
     const mk_csr *At = nullptr;     // transposed matrix (least-squares solvers only)
     const double *d_prec = nullptr; // diagonal of a Jacobi-type preconditioner M^-1 (borrowed, n entries) or null
+    // general preconditioner through a host callback (mk_solver_set_precon_callback): the kernels run with a
+    // diagonal of ones (`1.0 * v` is exact) and every preconditioned vector is replaced by the callback's result
+    // right after the kernel that produced it; inner products with it are re-formed by a separate dot kernel
+    mk_precon_fn precon_fn = nullptr;
+    void *precon_user = nullptr;
+    double *d_ones = nullptr, *h_pin = nullptr, *h_pout = nullptr;
+    int host_precon(const double *in_dev, double *out_dev, bool force = false);   // out = precon * in ; unless `force`, a no-op once the loop has halted
     mk_params prm{};
     int64_t n = 0;        // local rows = length of every solver vector
     int64_t nx = 0;       // length of vectors that feed an SpMV (n + halo)

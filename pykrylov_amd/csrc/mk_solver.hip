@@ -31,7 +31,26 @@ int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
     return MK_OK;
 }
 
+int mk_solver::host_precon(const double *in_dev, double *out_dev, bool force) {
+    if (!precon_fn) return MK_OK;
+    int h = 0;
+    MK_HIP(hipMemcpyAsync(&h, d_halt + (q & 1), sizeof(int), hipMemcpyDeviceToHost, stream));   // the next kernel's word
+    if (n > 0) MK_HIP(hipMemcpyAsync(h_pin, in_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    MK_HIP(hipStreamSynchronize(stream));
+    if (h && !force) return MK_OK;                           // the loop has ended: the reference applies nothing more
+    if (precon_fn(precon_user, h_pin, h_pout) != 0) {
+        const int rc = mk_fail(MK_ERR_STATE, "the host preconditioner callback reported a failure");
+        if (mk_ctx().pending_rc == MK_OK) mk_ctx().pending_rc = rc;
+        return rc;
+    }
+    if (n > 0) MK_HIP(hipMemcpyAsync(out_dev, h_pout, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
+    return MK_OK;
+}
+
 mk_solver::~mk_solver() {
+    hipFree(d_ones);
+    if (h_pin) hipHostFree(h_pin);
+    if (h_pout) hipHostFree(h_pout);
     if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
     for (double *v : vecs) hipFree(v);
     for (hipEvent_t e : spmv_ev) hipEventDestroy(e);
@@ -215,6 +234,34 @@ extern "C" int mk_solver_set_precon_diag(mk_solver *s, const double *diag) {
     if (diag && !s->takes_precon())
         return mk_fail(MK_ERR_UNSUPPORTED, "this solver kind has no device preconditioner hook");
     s->d_prec = diag;
+    return MK_OK;
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void mk_fill_kernel(double *v, int64_t n, double a) {
+    for (int64_t i = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MK_BLOCK) v[i] = a;
+}
+
+extern "C" int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void *user) {
+    MK_ARG(s);
+    if (!fn) {
+        s->precon_fn = nullptr;
+        s->d_prec = nullptr;
+        return MK_OK;
+    }
+    if (!s->takes_precon()) return mk_fail(MK_ERR_UNSUPPORTED, "this solver kind has no preconditioner hook");
+    if (s->A->ex.mode >= 0)
+        return mk_fail(MK_ERR_UNSUPPORTED, "host preconditioner callbacks are single-GPU (the vector would have to be gathered)");
+    const size_t len = (size_t)(s->n > 0 ? s->n : 1);
+    if (!s->d_ones) {
+        MK_HIP(hipMalloc((void **)&s->d_ones, sizeof(double) * len + 16));
+        MK_HIP(hipHostMalloc((void **)&s->h_pin, sizeof(double) * len, hipHostMallocDefault));
+        MK_HIP(hipHostMalloc((void **)&s->h_pout, sizeof(double) * len, hipHostMallocDefault));
+        hipLaunchKernelGGL(mk_fill_kernel, dim3(512), dim3(MK_BLOCK), 0, s->stream, s->d_ones, (int64_t)len, 1.0);
+        MK_HIP(hipGetLastError());
+    }
+    s->precon_fn = fn;
+    s->precon_user = user;
+    s->d_prec = s->d_ones;
     return MK_OK;
 }
 

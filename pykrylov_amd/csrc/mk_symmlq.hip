@@ -541,6 +541,7 @@ struct SymmlqSolver : mk_solver {
         if (d_prec && !d_y && (rc = alloc_vec(&d_y, nx))) return rc;
         double *y0 = d_prec ? d_y : d_r[1];
         if (d_prec) mk_launch_stream(this, MkOpMul{d_prec, d_r[0], d_y}, n);   // y = precon * r1   symmlq.py:131-132
+        if (precon_fn && (rc = host_precon(d_r[0], d_y)) != MK_OK) return rc;
         mk_launch_stream(this, MkOpDot<SLOT_A>{d_r[0], y0}, n);                // beta1             symmlq.py:134
         if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
         if ((rc = exchange(y0)) != MK_OK) return rc;
@@ -550,6 +551,10 @@ struct SymmlqSolver : mk_solver {
         mk_launch_stream(this, OpS3{d_part, np_spmv, d_scal, d_r[0], d_v, d_t, 0.0}, n);
         if ((rc = allreduce(SLOT_C, 2)) != MK_OK) return rc;
         mk_launch_stream(this, OpS4{d_part, np_stream, d_scal, d_t, d_v, d_r[1], d_prec, d_y, 0.0}, n);
+        if (precon_fn) {                                    // y = precon * r2 ; <r2, y> re-formed   symmlq.py:188-190
+            if ((rc = host_precon(d_r[1], d_y)) != MK_OK) return rc;
+            mk_launch_stream(this, MkOpDot<SLOT_A>{d_r[1], d_y}, n);
+        }
         if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
         hipLaunchKernelGGL(symmlq_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_stream, d_scal, d_status,
                            next_halt(), prm.rtol, prm.matvec_max);
@@ -567,6 +572,10 @@ struct SymmlqSolver : mk_solver {
                        CountGate{d_status, 1 + it});
         if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpK2{d_part, np_spmv, d_scal, blk, r2, d_t, r1, d_prec, d_y, 0.0}, n);
+        if (precon_fn) {                                    // y = precon * r2 ; <r2, y> re-formed   symmlq.py:308-310
+            if ((rc = host_precon(r1, d_y)) != MK_OK) return rc;          // (OpK2 wrote the new r2 into r1's storage)
+            mk_launch_stream(this, MkOpDot<SLOT_B>{r1, d_y}, n);
+        }
         if ((rc = allreduce(SLOT_B, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpK3{d_part, np_stream, d_scal, d_status, par, 2 + it, prm.matvec_max, prm.rtol, d_v,
                                     d_w, d_x, 0, 0, 0, 0, false}, n);
@@ -590,8 +599,13 @@ struct SymmlqSolver : mk_solver {
             }
             if (beta1 != 0) bstep = bstep / beta1;                            // symmlq.py:369
             const MkHalt nh{d_nohalt, 0, mk_comm_active() ? MK_MAXP : 0};
+            const double *bdir = d_b;
+            if (precon_fn) {                                 // the step is along precon * b   symmlq.py:372-373
+                if ((rc = host_precon(d_b, d_t, true)) != MK_OK) return rc;
+                bdir = d_t;                                  // (with the unit diagonal the kernel multiplies it by 1.0)
+            }
             hipLaunchKernelGGL(mk_stream_kernel<OpFinX>, dim3(mk_grid_stream(n)), dim3(MK_BLOCK), 0, stream,
-                               OpFinX{d_w, d_b, d_x, d_prec, zbar, bstep, cg_point}, n, nh, d_part);
+                               OpFinX{d_w, bdir, d_x, d_prec, zbar, bstep, cg_point}, n, nh, d_part);
             if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
             if ((rc = exchange(d_x)) != MK_OK) return rc;
             if ((rc = mk_exchange_wait(A, stream)) != MK_OK) return rc;      // one launch over all tiles below

@@ -316,6 +316,7 @@ struct TfqmrSolver : mk_solver {
         mk_launch_stream(this, MkOpCopy{d_r0, d_w}, n);                        // w = r0.copy()    tfqmr.py:71
         MK_HIP(hipMemsetAsync(d_d, 0, sizeof(double) * (size_t)n, stream));    // d = 0            tfqmr.py:72
         if (d_prec) mk_launch_stream(this, MkOpMul{d_prec, d_r0, d_z}, n);     // z = precon * y   tfqmr.py:77-78
+        if (precon_fn && host_precon(d_y, d_z) != MK_OK) return MK_ERR_STATE;
         if ((rc = exchange(zsrc())) != MK_OK) return rc;
         // u = A z ; v = u.copy() ; first sigma                               tfqmr.py:82-83
         mk_launch_spmv(this, zsrc(), EpiP6<true>{d_r0, d_u, d_v}, false, CountGate{d_status, 0});
@@ -332,11 +333,13 @@ struct TfqmrSolver : mk_solver {
         if ((rc = allreduce(SLOT_WW, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpP3{d_part, np_stream, d_scal, d_status, prm.matvec_max, nmv, k, d_d, d_v, d_x, d_y,
                                     d_prec, d_z, 0.0, 0.0, false}, n);
+        if (precon_fn && (rc = host_precon(d_y, d_z)) != MK_OK) return rc;     // z = precon * y       tfqmr.py:109-110
         if ((rc = exchange(zs)) != MK_OK) return rc;
         mk_launch_spmv(this, zs, EpiP4{d_scal, zs, d_r0, d_u, d_w, d_d, 0.0, 0.0}, true, CountGate{d_status, nmv});
         if ((rc = allreduce(SLOT_WW, 2)) != MK_OK) return rc;
         mk_launch_stream(this, OpP5{d_part, np_spmv, d_scal, d_status, par, prm.matvec_max, nmv + 1, k, d_d, d_w, d_u,
                                     d_x, d_y, d_v, d_prec, d_z, 0.0, 0.0, false}, n);
+        if (precon_fn && (rc = host_precon(d_y, d_z)) != MK_OK) return rc;     // z = precon * y       tfqmr.py:142-143
         if ((rc = exchange(zs)) != MK_OK) return rc;
         mk_launch_spmv(this, zs, EpiP6<false>{d_r0, d_u, d_v}, true, CountGate{d_status, nmv + 1});
         return allreduce(SLOT_SIGMA, 1);

@@ -80,23 +80,37 @@ class KrylovMethod(object):
                                       % self.__class__.__name__)
 
     def _device_precon(self, precon):
-        """The diagonal of a preconditioner the device loop can apply (``precon * r`` with a DiagonalOperator,
-        reference linop.py:473-516; the docs' `DiagonalPrec`, examples/bmark.py:14-23), or None.
+        """How the device loop applies ``precon * r`` (generic.py:76; cg.py:91-92, bicgstab.py:96-99, ...):
 
-        Anything else -- an arbitrary callable / operator -- cannot run inside the device-resident loop and is
-        refused loudly: there is no host fallback."""
+        * an operator that exposes its diagonal (``DiagonalOperator``, linop.py:473-516 -- the docs' Jacobi
+          `DiagonalPrec`, examples/bmark.py:14-23) is returned as an fp64 array and applied INSIDE the kernels;
+        * anything else with ``precon * vector`` is returned wrapped in :class:`HostPrecon`: the loop stays on the
+          device and calls it back on the host at each preconditioner site."""
         if precon is None:
             return None
         diag = getattr(precon, 'diag', None)
-        if diag is None or callable(diag):
-            raise NotImplementedError('%s: only diagonal preconditioners (an operator with a `.diag` array, e.g. '
-                                      'pykrylov_amd.linop.DiagonalOperator) run on the device path; got %r'
-                                      % (self.__class__.__name__, type(precon).__name__))
-        n = self.op.shape[0]
-        return as_f64_vector(diag, getattr(self.op, 'local_size', None) or n, 'precon.diag')
+        if diag is not None and not callable(diag):
+            n = self.op.shape[0]
+            return as_f64_vector(diag, getattr(self.op, 'local_size', None) or n, 'precon.diag')
+        if not hasattr(precon, '__mul__') and not callable(precon):
+            raise TypeError('%s: precon must support `precon * vector`; got %r'
+                            % (self.__class__.__name__, type(precon).__name__))
+        if getattr(self.op, 'local_size', None) is not None:
+            raise NotImplementedError('%s: on a row-partitioned operator only diagonal preconditioners are available'
+                                      % self.__class__.__name__)
+        return HostPrecon(precon)
 
     def _logging(self):
         return self.logger is not null_log and self.logger.isEnabledFor(logging.INFO)
+
+
+class HostPrecon(object):
+    """A general preconditioner for the device loop: ``precon * r`` evaluated on the host through a callback."""
+
+    def __init__(self, precon):
+        self.precon = precon
+        self.error = None
+        self.calls = 0
 
 
 def as_f64_vector(v, n, what):
@@ -133,6 +147,24 @@ class DeviceRun(object):
             setattr(p, k, v)
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.mk_solver_create(op.handle, ctypes.byref(p), ctypes.byref(self.handle)))
+        self.host_precon = None
+        if isinstance(precon_diag, HostPrecon):
+            hp, self.host_precon, precon_diag = precon_diag, precon_diag, None
+
+            def call(user, rp, yp):
+                try:
+                    r = np.ctypeslib.as_array(ctypes.cast(rp, ctypes.POINTER(ctypes.c_double)), shape=(n,)).copy()
+                    y = np.asarray(hp.precon * r if hasattr(hp.precon, '__mul__') else hp.precon(r))
+                    if y.shape != (n,):
+                        raise ValueError('precon * r has shape %s, expected (%d,)' % (y.shape, n))
+                    np.ctypeslib.as_array(ctypes.cast(yp, ctypes.POINTER(ctypes.c_double)), shape=(n,))[:] = y
+                    hp.calls += 1
+                    return 0
+                except BaseException as exc:                # noqa: B902  (must not propagate through the C frames)
+                    hp.error = exc
+                    return 1
+            self._precon_cb = _lib.PRECON_FN(call)          # keep the thunk alive
+            _lib.check(self.lib.mk_solver_set_precon_callback(self.handle, self._precon_cb, None))
         if precon_diag is not None:
             self.d_prec = precon_diag if isinstance(precon_diag, _lib.DeviceArray) else \
                 _lib.DeviceArray.from_numpy(as_f64_vector(precon_diag, n, 'precon.diag'))
@@ -145,6 +177,9 @@ class DeviceRun(object):
     def _check(self, rc):
         if rc != 0 and hasattr(self.op, 'raise_pending'):
             self.op.raise_pending()                           # what a matrix-free operator raised in its callback
+        if rc != 0 and self.host_precon is not None and self.host_precon.error is not None:
+            err, self.host_precon.error = self.host_precon.error, None
+            raise err
         _lib.check(rc)
 
     def setup(self):

@@ -162,8 +162,11 @@ def test_cg_zero_rhs_and_history_accumulates(golden):
         s.solve(np.ones(99))
     with pytest.raises(TypeError):
         s.solve(1j * np.ones(100))
-    with pytest.raises(NotImplementedError):
-        CG(op, precon=op).solve(np.ones(100))
+    # an operator as preconditioner (here A itself) goes through the host-callback path (test_gpu_hostop.py)
+    s3 = CG(op, precon=op)
+    s3.solve(np.ones(100), matvec_max=7)
+    ref3 = kr.cg(A, np.ones(100), matvec_max=7, precon=A.matvec)
+    assert s3.nMatvec == ref3["nMatvec"] and rel_hist_err(s3.residHistory, ref3["residHistory"]) <= TOL
 
 
 def test_cg_options_store_and_logging(golden, caplog):

@@ -176,3 +176,89 @@ def test_operator_exceptions_propagate():
     op = LinearOperator(50, 50, mv, symmetric=True)
     with pytest.raises(Boom):
         CG(op, reltol=0.0, abstol=0.0).solve(np.ones(50), matvec_max=40)
+
+
+# ------------------------------------------------------------------------------------------------ general preconditioners
+class TridiagPrecon(object):
+    """A non-diagonal SPD operator applied as `precon * r` (generic.py:76): P = tridiag(0.2, 1, 0.2) scaled by 1/d."""
+
+    def __init__(self, d):
+        self.d = np.asarray(d, dtype=np.float64)
+        self.calls = 0
+
+    def __call__(self, r):
+        self.calls += 1
+        w = r / self.d
+        y = w.copy()
+        y[1:] = y[1:] + 0.2 * w[:-1]
+        y[:-1] = y[:-1] + 0.2 * w[1:]
+        return y / self.d
+
+    def __mul__(self, r):
+        return self(r)
+
+
+@pytest.mark.parametrize("solver", ["cg", "bicgstab", "cgs", "tfqmr"])
+def test_host_preconditioner_matches_oracle(solver):
+    """Same callable on both sides, oracle dots in the device's order: the general-preconditioner path of the four
+    `precon * r` solvers reproduces the oracle bit for bit (CSR operator on the device, preconditioner on the host)."""
+    import pykrylov_amd
+    from pykrylov_amd import CsrOperator
+    if solver == "cg":
+        A = csr_ref.poisson2d(40)
+    else:
+        A = csr_ref.random_diagdom(2500, seed=12)
+    n = A.shape[0]
+    diag = np.array([A.data[A.indptr[i]:A.indptr[i + 1]][A.indices[A.indptr[i]:A.indptr[i + 1]] == i][0] for i in range(n)])
+    op = CsrOperator(A.indptr, A.indices, A.data, A.shape, symmetric=(solver == "cg"))
+    rhs = A.matvec(np.ones(n))
+    cls = {"cg": pykrylov_amd.CG, "bicgstab": pykrylov_amd.BiCGSTAB, "cgs": pykrylov_amd.CGS,
+           "tfqmr": pykrylov_amd.TFQMR}[solver]
+    for kw in (dict(matvec_max=60), dict(matvec_max=60, guess=np.linspace(0.9, 1.1, n))):
+        P = TridiagPrecon(np.sqrt(np.abs(diag)))
+        Pref = TridiagPrecon(np.sqrt(np.abs(diag)))
+        s = cls(op, reltol=1e-9, precon=P)
+        s.solve(rhs, **kw)
+        ref = getattr(kr, solver)(A, rhs, reltol=1e-9, precon=Pref,
+                                  red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES[solver])), **kw)
+        assert s.nMatvec == ref["nMatvec"] and s.converged == ref["converged"], (solver, kw.keys())
+        assert s.residNorm == ref["residNorm"] and np.array_equal(s.x, ref["x"])
+        # applied as often as in the reference, or once more where the application precedes the loop test
+        assert Pref.calls <= P.calls <= Pref.calls + 1
+
+
+def test_host_preconditioner_minres_symmlq(monkeypatch):
+    from pykrylov_amd import CsrOperator, Minres, Symmlq
+    monkeypatch.setattr(kr, "_sq", lambda a: a * a)
+    A = csr_ref.poisson2d(30)
+    n = A.shape[0]
+    op = CsrOperator(A.indptr, A.indices, A.data, A.shape, symmetric=True)
+    rhs = A.matvec(np.ones(n))
+    d = np.full(n, 2.0)
+    s = Minres(op)
+    s.solve(rhs, precon=TridiagPrecon(d), show=False, check=False, etol=0.0, rtol=1e-10)
+    ref = kr.minres(A, rhs, precon=TridiagPrecon(d), check=False, etol=0.0, rtol=1e-10,
+                    red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["minres"])))
+    assert (s.istop, s.itn) == (ref["istop"], ref["itn"])
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
+    q = Symmlq(op, precon=TridiagPrecon(d))
+    q.solve(rhs)
+    refq = kr.symmlq(A, rhs, precon=TridiagPrecon(d),
+                     red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["symmlq"])))
+    assert q.nMatvec == refq["nMatvec"] and np.array_equal(q.x, refq["x"])
+
+
+def test_host_operator_and_host_preconditioner_together():
+    """Both callbacks in one solve: the reference's fully matrix-free setting."""
+    from pykrylov_amd import CG, LinearOperator
+    A = csr_ref.poisson2d(25)
+    n = A.shape[0]
+    op = LinearOperator(n, n, lambda x: A.matvec(x), symmetric=True)
+    rhs = A.matvec(np.ones(n))
+    P, Pref = TridiagPrecon(np.full(n, 2.0)), TridiagPrecon(np.full(n, 2.0))
+    s = CG(op, precon=P)
+    s.solve(rhs, matvec_max=40)
+    ref = kr.cg(A, rhs, precon=Pref, matvec_max=40,
+                red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geometry(n))))
+    assert s.nMatvec == ref["nMatvec"] and np.array_equal(s.x, ref["x"])
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"])

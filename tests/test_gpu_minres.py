@@ -112,8 +112,8 @@ def test_minres_edge_cases(golden):
     s3 = Minres(op)
     s3.solve(d["m30_s0_c0_rhs"], show=False, check=False, store_iterates=True, etol=0.0, rtol=1e-6)
     assert len(s3.iterates) == s3.itn + 1 and np.array_equal(s3.iterates[-1], s3.x)
-    with pytest.raises(NotImplementedError):
-        s3.solve(d["m30_s0_c0_rhs"], precon=op, show=False)
+    s3.solve(d["m30_s0_c0_rhs"], precon=op, show=False, check=False, itnlim=5)     # operator preconditioner: host callback
+    assert s3.itn == 5
     with pytest.raises(Exception):
         s3.solve(d["m30_s0_c0_rhs"], window=99, show=False, check=False)
 

@@ -68,14 +68,22 @@ def test_cg_precon_store_resids_are_preconditioned(golden):
     assert np.array_equal(s.resids[0], dg * (-d["spd_rhs"]))
 
 
-def test_non_diagonal_precon_is_refused(golden):
-    from pykrylov_amd import CG, LinearOperator
+def test_operator_precon_equal_to_the_diagonal_one_gives_the_same_bits(golden):
+    """A LinearOperator preconditioner (no `.diag`) goes through the host-callback path (test_gpu_hostop.py); with
+    the same action as the DiagonalOperator it must reproduce the in-kernel diagonal path bit for bit."""
+    from pykrylov_amd import CG, DiagonalOperator, LinearOperator
     d = golden("precon_jacobi.npz")
     A = golden_csr(d, "spd_A_")
     n = A.shape[0]
-    with pytest.raises(NotImplementedError):
-        CG(op_from(A, symmetric=True), precon=LinearOperator(n, n, matvec=lambda v: v, symmetric=True)) \
-            .solve(d["spd_rhs"])
+    dg = d["spd_d"]
+    s1 = CG(op_from(A, symmetric=True), precon=DiagonalOperator(dg))
+    s1.solve(d["spd_rhs"], matvec_max=40)
+    s2 = CG(op_from(A, symmetric=True), precon=LinearOperator(n, n, matvec=lambda v: dg * v, symmetric=True))
+    s2.solve(d["spd_rhs"], matvec_max=40)
+    assert s1.nMatvec == s2.nMatvec and np.array_equal(s1.x, s2.x)
+    assert np.array_equal(s1.residHistory, s2.residHistory)
+    with pytest.raises(TypeError):
+        CG(op_from(A, symmetric=True), precon=object()).solve(d["spd_rhs"])
 
 
 # ------------------------------------------------------------------ BiCGSTAB / CGS / TFQMR

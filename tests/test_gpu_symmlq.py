@@ -85,5 +85,6 @@ def test_symmlq_edge_cases(golden):
     nonsym = golden_csr(golden("nonsym_jpwh991.npz"), "A_")
     with pytest.raises(NotImplementedError):
         Symmlq(op_from(nonsym)).solve(np.ones(991), check=True)
-    with pytest.raises(NotImplementedError):
-        Symmlq(op, precon=op).solve(rhs)
+    sp = Symmlq(op, precon=op)                              # operator preconditioner: host callback path
+    sp.solve(rhs, matvec_max=6)
+    assert sp.nMatvec >= 6
