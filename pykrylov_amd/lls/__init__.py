@@ -2,8 +2,10 @@
 
 `LSQRFramework`, `LSMRFramework`, `CRAIGFramework`, `CRAIGMRFramework` keep the reference's `solve`
 signatures and result attributes; the Golub-Kahan bidiagonalisation (one product with A and one with
-A' per iteration) and every scalar recurrence run on the GPU (``csrc/mk_lls.hip``).  The operator must
-be a :class:`pykrylov_amd.linop.CsrOperator`; its transpose is built on the device on first use.
-Preconditioners `M`, `N` are not available on the device path yet.
+A' per iteration) and every scalar recurrence run on the GPU (``csrc/mk_lls.hip``).  With a
+:class:`pykrylov_amd.linop.CsrOperator` both products run on the device (the transpose is built there on first
+use); any other operator with ``A * v`` and ``A.T * u`` is called back on the host at each product site
+(:class:`pykrylov_amd.linop.HostOperatorShell`).  Preconditioners `M`, `N` run on the device when they expose a
+diagonal (``DiagonalOperator``, linop.py:473-516; ``mk_solver_set_lls_precon``); other `M` / `N` are refused.
 """
 from .solvers import LSQRFramework, LSMRFramework, CRAIGFramework, CRAIGMRFramework   # noqa: F401

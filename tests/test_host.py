@@ -294,3 +294,37 @@ def test_default_limits_use_the_global_size(monkeypatch):
         except Stop:
             pass
         assert seen.get(key) == want, (cls.__name__, seen)
+
+
+def test_integration_md_stub_matches_the_header():
+    """INTEGRATION.md section 2b shows the ctypes structures a reference maintainer would paste: they must have the
+    fields and sizes of include/mikrylov.h (a stale stub is rejected by the `struct_size` check at run time)."""
+    import ctypes
+    import re
+    from pykrylov_amd import _lib
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(ROOT, "include", "mikrylov.h")).read()
+
+    def md_fields(cls):
+        body = md[md.index("class %s(ctypes.Structure)" % cls):]
+        body = body[body.index("_fields_"):body.index("]\n") + 1]
+        return re.findall(r'\("(\w+)",\s*ctypes\.(c_\w+)(?:\s*\*\s*(\d+))?\)', body)
+
+    def hdr_fields(name):
+        body = hdr[:hdr.index("} %s;" % name)]
+        body = body[body.rindex("typedef struct {"):]
+        return re.findall(r"^\s*(int32_t|int64_t|double)\s+([\w\s,\[\]]+);", body, re.M)
+
+    ctype = {"int32_t": "c_int32", "int64_t": "c_int64", "double": "c_double"}
+    for cls, cname, ref in (("MkParams", "mk_params", _lib.MkParams), ("MkResult", "mk_result", _lib.MkResult)):
+        want = []
+        for typ, names in hdr_fields(cname):
+            for nm in names.split(","):
+                nm = nm.strip()
+                m = re.match(r"(\w+)\[(\d+)\]", nm)
+                want.append((m.group(1), ctype[typ], m.group(2)) if m else (nm, ctype[typ], ""))
+        got = md_fields(cls)
+        assert got == want, (cls, got, want)
+        fields = [(n, getattr(ctypes, t) * int(k) if k else getattr(ctypes, t)) for n, t, k in got]
+        stub = type(cls, (ctypes.Structure,), {"_fields_": fields})
+        assert ctypes.sizeof(stub) == ctypes.sizeof(ref)
