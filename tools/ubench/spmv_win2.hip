@@ -657,6 +657,189 @@ __global__ __launch_bounds__(BLOCK) void spmv_w4(const int* __restrict__ ip, con
     if (tid == 0) part[blockIdx.x] = tot;
 }
 
+
+// ================================================================================================= version 5
+// Wave-independent tiles: wave w of a workgroup owns rows [64 w, 64 w + 64) of each 256-row tile, with its own
+// cover (windows of the 64 rows), its own LDS regions and NO workgroup barriers (LDS operations of one wave execute
+// in order).  Thread t still owns row 256 tile + t, so the fused-dot partial sums are unchanged.
+constexpr int CW = 6;                                    // window chunks per wave-tile
+struct __attribute__((aligned(64))) QDesc { int g[CW]; unsigned short off[CW]; unsigned char half[CW]; unsigned char ok; unsigned char pad[64 - 4 * CW - 2 * CW - CW - 1]; };
+
+__global__ __launch_bounds__(BLOCK) void cover5_kernel(const int* __restrict__ ip, const int* __restrict__ ix, long nrows, long nq,
+                                                       QDesc* __restrict__ qd, uint16_t* __restrict__ sl, int* __restrict__ stats) {
+    // one workgroup per 64-row quarter (simple; the builder runs once per matrix)
+    __shared__ int key[1024];
+    __shared__ int heads[CW + 1];
+    __shared__ int wst[CW], wof[CW];
+    __shared__ int nh, s_ok, s_nw;
+    const int tid = threadIdx.x;
+    for (long q = blockIdx.x; q < nq; q += gridDim.x) {
+        const long r0 = q * 64, rend = min(r0 + 64, nrows);
+        __syncthreads();
+        if (tid == 0) { QDesc d; memset(&d, 0, sizeof(d)); qd[q] = d; }
+        if (r0 >= nrows) continue;
+        const int p_lo = ip[r0], p_hi = ip[rend], cnt = p_hi - p_lo;
+        if (cnt <= 0 || p_hi - (p_lo & ~7) > 512) continue;
+        int n2 = 2; while (n2 < cnt) n2 <<= 1;
+        for (int i = tid; i < n2; i += BLOCK) key[i] = (i < cnt) ? (ix[p_lo + i] >> 1) : 0x7fffffff;
+        __syncthreads();
+        bitonic_sort(key, n2);
+        bool done = false;
+        for (int G = 4; G <= 16384 && !done; G <<= 2) {
+            if (tid == 0) nh = 0;
+            __syncthreads();
+            for (int i = tid; i < cnt; i += BLOCK)
+                if (i == 0 || key[i] - key[i - 1] > G) { const int k = atomicAdd(&nh, 1); if (k < CW) heads[k] = i; }
+            __syncthreads();
+            if (tid == 0) {
+                bool ok = nh <= CW; const int nw = nh;
+                if (ok) {
+                    for (int a = 1; a < nw; ++a) { const int v = heads[a]; int b = a - 1; while (b >= 0 && heads[b] > v) { heads[b + 1] = heads[b]; --b; } heads[b + 1] = v; }
+                    heads[nw] = cnt;
+                    int L = 0, C = 0;
+                    for (int k = 0; k < nw; ++k) {
+                        const int st = key[heads[k]] * 2, en = (key[heads[k + 1] - 1] + 1) * 2;
+                        wst[k] = st; wof[k] = L; L += en - st; C += (en - st + 127) / 128;
+                    }
+                    ok = C <= CW;
+                    if (ok) {
+                        QDesc d; memset(&d, 0, sizeof(d)); d.ok = 1;
+                        int c = 0;
+                        for (int k = 0; k < nw; ++k) {
+                            const int en = (key[heads[k + 1] - 1] + 1) * 2;
+                            for (int g = wst[k], o = wof[k]; g < en; g += 128, o += 128, ++c) { d.g[c] = g; d.off[c] = (unsigned short)o; d.half[c] = (unsigned char)(min(128, en - g) / 2); }
+                        }
+                        qd[q] = d;
+                        atomicMax(&stats[0], L); atomicAdd(&stats[1], 1);
+                    }
+                }
+                s_ok = ok ? 1 : 0; s_nw = nw;
+            }
+            __syncthreads();
+            done = s_ok != 0;
+            __syncthreads();
+        }
+        if (done) {
+            const int nw = s_nw;
+            for (int j = tid; j < cnt; j += BLOCK) {
+                const int col = ix[p_lo + j];
+                int k = 0;
+                for (int t = 1; t < nw; ++t) k += (wst[t] <= col) ? 1 : 0;
+                sl[p_lo + j] = (uint16_t)(wof[k] + col - wst[k]);
+            }
+        }
+    }
+}
+
+template <int VC>
+__global__ __launch_bounds__(BLOCK) void spmv_w5(const int* __restrict__ ip, const uint16_t* __restrict__ sl, const double* __restrict__ dv,
+                                                 const uint8_t* __restrict__ vc, const double* __restrict__ dict, const QDesc* __restrict__ qd,
+                                                 const double* __restrict__ x, double* __restrict__ y, long nrows, long ntiles, int wcap, double* part) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int PLD = 65, PSZ = 8 * PLD;               // per-wave product staging [8][65], column 64 = zeros
+    __shared__ double s4[4];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* prod = smem + wv * (PSZ + wcap);
+    double* xw = prod + PSZ;
+    if (VC) { sdict[tid] = dict[tid]; __syncthreads(); }
+    if (lane < 8) prod[lane * PLD + 64] = 0.0;
+    double acc = 0.0;
+    struct Meta { int p_lo, p_hi, my_lo; };
+    struct Regs { u4v s; d2v val[4]; u2v code; d2v w[CW]; unsigned hv0, hv1; unsigned short off[CW]; double xr; };
+    auto load_meta = [&](long tile, Meta& m) {
+        m.p_lo = m.p_hi = m.my_lo = 0;
+        if (tile < ntiles) {
+            const long r0 = tile * ROWS + wv * 64, rend = min(r0 + 64, nrows), r = r0 + lane;
+            if (r0 < nrows) { m.p_lo = ip[r0]; m.p_hi = ip[rend]; m.my_lo = ip[(r < rend) ? r : rend]; }
+        }
+    };
+    auto issue = [&](long tile, const Meta& m, Regs& R) {
+        R.hv0 = R.hv1 = 0;
+        if (tile >= ntiles) return;
+        const long r = tile * ROWS + tid;
+        R.xr = (r < nrows) ? x[r] : 0.0;
+        const QDesc* d = qd + (tile * 4 + wv);
+        unsigned h0 = 0, h1 = 0;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const int hc = d->half[c];
+            R.off[c] = d->off[c];
+            if (c < 4) h0 |= (unsigned)hc << (8 * c); else h1 |= (unsigned)hc << (8 * (c - 4));
+            if (hc > 0) { const int l2 = min(lane, hc - 1); R.w[c] = *(const d2v*)(x + d->g[c] + 2 * l2); }
+        }
+        R.hv0 = h0; R.hv1 = h1;
+        const int base = m.p_lo & ~7, cnt = m.p_hi - base;
+        int j = 8 * lane; j = (j < cnt) ? j : ((cnt - 1) & ~7);
+        j = j < 0 ? 0 : j;
+        R.s = *(const u4v*)(sl + base + j);
+        if (VC) R.code = *(const u2v*)(vc + base + j);
+        else {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) R.val[h] = *(const d2v*)(dv + base + j + 2 * h);
+        }
+    };
+    Meta m0, m1, m2;
+    Regs R;
+    long tile = blockIdx.x;
+    const long G = gridDim.x;
+    load_meta(tile, m0); load_meta(tile + G, m1);
+    issue(tile, m0, R);
+    for (; tile < ntiles; tile += G) {
+        const long r = tile * ROWS + tid;
+        const int p_lo = m0.p_lo, p_hi = m0.p_hi, my_lo = m0.my_lo;
+        const int base = p_lo & ~7;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const int hc = (int)(((c < 4 ? R.hv0 >> (8 * c) : R.hv1 >> (8 * (c - 4)))) & 0xffu);
+            if (hc > 0 && lane < hc) *(d2v*)(xw + R.off[c] + 2 * lane) = R.w[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int my_hi = __shfl_down(my_lo, 1, 64);
+        if (lane == 63) my_hi = p_hi;
+        const unsigned sw[4] = {R.s.x, R.s.y, R.s.z, R.s.w};
+        double pr[8];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const double x0 = xw[sw[h] & 0xffffu], x1 = xw[sw[h] >> 16];
+            double v0, v1;
+            if (VC) {
+                const unsigned cw = (h < 2) ? R.code.x : R.code.y;
+                v0 = sdict[(cw >> (16 * (h & 1))) & 0xffu]; v1 = sdict[(cw >> (16 * (h & 1) + 8)) & 0xffu];
+            } else { v0 = R.val[h].x; v1 = R.val[h].y; }
+            pr[2 * h] = v0 * x0; pr[2 * h + 1] = v1 * x1;
+        }
+        const double xr = R.xr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) prod[i * PLD + lane] = pr[i];
+        load_meta(tile + 2 * G, m2);
+        issue(tile + G, m1, R);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int lo = my_lo - base, len = my_hi - my_lo;
+        const int a = lo & 7;
+        const int adA = a * PLD + (lo >> 3), adB = adA - (8 * PLD - 1);
+        double t[8], sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int ad = (a + k >= 8) ? adB : adA;
+            ad = (k < len) ? ad : 64;
+            t[k] = prod[ad + k * PLD];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += t[k];
+        for (int k = 8; k < len; ++k) { const int idx = lo + k; sum += prod[(idx & 7) * PLD + (idx >> 3)]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (r < nrows) { y[r] = sum; acc += xr * sum; }
+        m0 = m1; m1 = m2;
+    }
+    const double tot = block_sum(acc, s4);
+    if (tid == 0) part[blockIdx.x] = tot;
+}
+
 template <class F> float timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -711,7 +894,19 @@ int main(int argc, char** argv) {
         CK(hipMemset(y, 0, n * 8)); \
         float ms = timeit([&] { hipLaunchKernelGGL((spmv_w4<VC>), dim3(g), dim3(BLOCK), lds, 0, ip, sl2, dv, vc, dict, wg, wn, x, y, n, ntiles, hs[0], part); }, reps); \
         printf("w4 vc=%d grid=%4d lds=%zu : %9.1f us  %.2f TB/s  %s\n", VC, g, lds, ms * 1e3, bytes / ms / 1e9, check(y)); }
-    RUN4(0) RUN4(1)
+    { QDesc* qd; uint16_t* sl5; const long nq = ntiles * 4;
+      CK(hipMalloc(&qd, nq * sizeof(QDesc))); CK(hipMalloc(&sl5, (nnz + 16) * 2)); CK(hipMemset(sl5, 0, (nnz + 16) * 2));
+      CK(hipMemset(stats, 0, 8));
+      float c5 = timeit([&] { hipLaunchKernelGGL(cover5_kernel, dim3(8192), dim3(BLOCK), 0, 0, ip, ix, n, nq, qd, sl5, stats); }, 1);
+      int h5[2]; CK(hipMemcpy(h5, stats, 8, hipMemcpyDeviceToHost));
+      const int wcap = (h5[0] + 1) & ~1;
+      printf("cover5 %.1f ms, max L=%d, covered quarters=%d/%ld (x2 runs)\n", c5, h5[0], h5[1], nq);
+#define RUN5(VC) for (int g : {1024, 1280, 1536, 2048}) { const size_t lds = 4 * (8 * 65 + wcap) * 8; \
+        CK(hipMemset(y, 0, n * 8)); \
+        float ms = timeit([&] { hipLaunchKernelGGL((spmv_w5<VC>), dim3(g), dim3(BLOCK), lds, 0, ip, sl5, dv, vc, dict, qd, x, y, n, ntiles, wcap, part); }, reps); \
+        printf("w5 vc=%d grid=%4d lds=%zu : %9.1f us  %.2f TB/s  %s\n", VC, g, lds, ms * 1e3, bytes / ms / 1e9, check(y)); }
+      RUN5(0) RUN5(1)
+    }
     RUN3(0, 0, 0) RUN3(1, 0, 0) RUN3(1, 1, 0)
     return 0;
 }
