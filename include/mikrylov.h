@@ -105,6 +105,16 @@ typedef struct mk_rowop {
 } mk_rowop;
 int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops, mk_csr **out);
 
+/* Sum, difference and product of two device matrices as ONE device operator (linop.py:375-398 `op + other`, :403-426
+ * `op - other`, :332-354 `op * other`): the reference evaluates them as `(A*x) + (B*x)`, `(A*x) - (B*x)` and `A*(B*x)`
+ * -- two complete products and one element-wise operation -- and so does the device: the first product's row sums go
+ * to a temporary, the second product's kernel combines them with its own row sums (or multiplies the temporary)
+ * and feeds the result to the fused epilogue of whatever solver kernel asked for the product.  Same bits as the
+ * reference's closures.  A and B are borrowed (they must outlive the result); they may carry a row program
+ * (mk_csr_compose) but must not be composites, matrix-free or partitioned.  sign = +1 / -1. */
+int mk_csr_create_sum(const mk_csr *A, const mk_csr *B, int sign, mk_csr **out);
+int mk_csr_create_product(const mk_csr *A, const mk_csr *B, mk_csr **out);
+
 /* Matrix-free operator: the products of the returned handle are computed by a HOST callback -- the reference's own
  * operator protocol, `LinearOperator(nargin, nargout, matvec=callable)` (linop/linop.py:114,271-298), e.g. the gallery
  * operators its CG test runs on (cg/tests/test_diagdom.py:38-40).  Everything else of a solver loop (dots, updates,

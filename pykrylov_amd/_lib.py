@@ -72,6 +72,8 @@ PROTOTYPES = {
     "mk_calib_stream": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int]),
     "mk_csr_create": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),
     "mk_csr_destroy": (ctypes.c_int, [c_vp]),
+    "mk_csr_create_sum": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, P(c_vp)]),
+    "mk_csr_create_product": (ctypes.c_int, [c_vp, c_vp, P(c_vp)]),
     "mk_csr_create_callback": (ctypes.c_int, [c_i64, c_i64, MATVEC_FN, c_vp, ctypes.c_int, P(c_vp)]),
     "mk_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),
     "mk_csr_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),

@@ -205,6 +205,8 @@ extern "C" int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops
         return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_compose: at most %d steps per operator", (int)MK_ROWPROG_MAX);
     if (A->ex.mode >= 0)
         return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_compose: compose before the operator is partitioned");
+    if (A->comp_kind || A->host_fn)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_compose: the operand has no matrix of its own (sum / product / matrix-free)");
     for (int k = 0; k < nops; ++k) {
         MK_ARG(ops[k].code >= MK_ROW_SCALE && ops[k].code <= MK_ROW_RSUB);
         if (ops[k].code != MK_ROW_SCALE && A->nrows != A->ncols)
@@ -217,6 +219,42 @@ extern "C" int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops
     for (int k = 0; k < nops; ++k) B->ops[B->nops++] = ops[k];
     *out = B;
     return MK_OK;
+}
+
+static int pair_create(const mk_csr *A, const mk_csr *B, int kind, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A && B && out);
+    if (!A->is_plain() || !B->is_plain())
+        return mk_fail(MK_ERR_UNSUPPORTED, "operands of a device sum / product must be plain device matrices "
+                                           "(not composites, matrix-free or partitioned operators)");
+    if (kind == 3) MK_ARG(A->ncols == B->nrows);
+    else MK_ARG(A->nrows == B->nrows && A->ncols == B->ncols);
+    mk_csr *C = new mk_csr();
+    C->nrows = A->nrows;
+    C->ncols = B->ncols;
+    C->nnz = A->nnz + B->nnz;
+    C->ntiles = (C->nrows + MK_ROWS_PER_TILE - 1) / MK_ROWS_PER_TILE;
+    C->comp_kind = kind;
+    C->comp_a = A;
+    C->comp_b = B;
+    C->plan.built = true;
+    const int64_t tlen = (kind == 3) ? B->nrows : A->nrows;
+    if (hipMalloc((void **)&C->d_comp_tmp, sizeof(double) * (size_t)(tlen > 0 ? tlen : 1) + 16) != hipSuccess) {
+        delete C;
+        return mk_fail(MK_ERR_HIP, "device sum / product: hipMalloc failed");
+    }
+    MK_HIP(hipMemsetAsync(C->d_comp_tmp, 0, sizeof(double) * (size_t)(tlen > 0 ? tlen : 1) + 16, mk_ctx().stream));
+    *out = C;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_create_sum(const mk_csr *A, const mk_csr *B, int sign, mk_csr **out) {
+    MK_ARG(sign == 1 || sign == -1);
+    return pair_create(A, B, sign > 0 ? 1 : 2, out);
+}
+
+extern "C" int mk_csr_create_product(const mk_csr *A, const mk_csr *B, mk_csr **out) {
+    return pair_create(A, B, 3, out);
 }
 
 extern "C" int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn, void *user, int transpose,
@@ -271,6 +309,12 @@ extern "C" int mk_csr_destroy(mk_csr *A) {
         delete A;
         return MK_OK;
     }
+    if (A->comp_kind) {
+        if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+        hipFree(A->d_comp_tmp);
+        delete A;
+        return MK_OK;
+    }
     if (A->host_fn) {
         if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
         if (A->h_cb_in) hipHostFree(A->h_cb_in);
@@ -308,6 +352,7 @@ extern "C" int mk_csr_shape(const mk_csr *A, int64_t *nrows, int64_t *ncols, int
 extern "C" int mk_csr_download(const mk_csr *A, int32_t *indptr, int32_t *indices, double *data) {
     MK_REQUIRE_INIT();
     MK_ARG(A != nullptr);
+    if (A->comp_kind || A->host_fn) return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_download: the operand has no matrix of its own");
     hipStream_t st = mk_ctx().stream;
     if (indptr)
         MK_HIP(hipMemcpyAsync(indptr, A->d_indptr, sizeof(int32_t) * (size_t)(A->nrows + 1), hipMemcpyDeviceToHost, st));
@@ -557,6 +602,8 @@ constexpr int32_t MK_TR_DEVICE_MAX_COLUMN = 2048;     // longest column the devi
 extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
     MK_REQUIRE_INIT();
     MK_ARG(A && out);
+    if (A->comp_kind || A->host_fn)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_transpose: the operand has no matrix of its own; transpose its parts");
     mk_csr *B = nullptr;
     int rc = mk_csr_alloc(A->ncols, A->nrows, A->nnz, &B);
     if (rc != MK_OK) return rc;

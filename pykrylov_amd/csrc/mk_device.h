@@ -64,6 +64,7 @@ static inline int mk_xcd_chunks(const mk_csr *A) {
     return bytes <= (int64_t)200 * 1024 * 1024 ? 1 : 0;
 }
 static inline int mk_tile_map(const mk_csr *A) {
+    if (A->comp_kind) return mk_tile_map(A->comp_kind == 3 ? A->comp_a : A->comp_b);
     if (A->host_fn) return 0;
     static const char *env = getenv("MK_SPMV_MAP");
     if (env) return atoi(env);
@@ -78,6 +79,7 @@ int mk_host_product(const mk_csr *A, hipStream_t st);   // mk_core.hip: D2H, hos
 // Windowed path: 4 per CU (raw values, ~100 registers) or 5 per CU (dictionary) -- measured on 512^3 and 2-D
 // n = 1e6: 1024 / 1280 workgroups beat every other count by 5-25 % (tools/sweep_fmt.sh).
 static inline int mk_grid_spmv_for(const mk_csr *A) {
+    if (A->comp_kind) return mk_grid_spmv_for(A->comp_kind == 3 ? A->comp_a : A->comp_b);   // the final launch's matrix
     int g = mk_grid_spmv(A->ntiles);
     if (getenv("MK_GRID_SPMV") || A->host_fn) return g;
     const MkPlan *P = mk_csr_plan(A);
@@ -588,10 +590,61 @@ struct MkPartialOf {
     __device__ void row(int64_t r, double s, double *) { ysum[r] = s; }
 };
 
+// Pair operators (mk_csr_create_sum / _product): the second launch's epilogue wrappers.  (The wrapped epilogue's
+// optional `pre` hook is forwarded through a base class so that MkHasPre sees it exactly when the epilogue has one.)
+template <class Epi, bool = MkHasPre<Epi>::value>
+struct MkWrapBase {
+    Epi e;
+};
+template <class Epi>
+struct MkWrapBase<Epi, true> {
+    Epi e;
+    __device__ void pre(int64_t r) { e.pre(r); }
+};
+template <class Epi, int SIGN>
+struct MkAddOf : MkWrapBase<Epi> {   // row sum = t1[r] + s  (or - s): `(A*x) + (B*x)`, linop.py:375-398, :403-426
+    static constexpr int NACC = Epi::NACC, SLOT0 = Epi::SLOT0;
+    const double *t1;
+    __device__ void prologue(double *s4) { this->e.prologue(s4); }
+    __device__ double xin(double v) const { return this->e.xin(v); }
+    __device__ void row(int64_t r, double s, double *acc) { this->e.row(r, SIGN > 0 ? t1[r] + s : t1[r] - s, acc); }
+};
+template <class Epi>
+struct MkNoXin : MkWrapBase<Epi> {   // the outer product of `A*(B*x)`: its input B*x was formed from xin(x) already
+    static constexpr int NACC = Epi::NACC, SLOT0 = Epi::SLOT0;
+    __device__ void prologue(double *s4) { this->e.prologue(s4); }
+    __device__ double xin(double v) const { return v; }
+    __device__ void row(int64_t r, double s, double *acc) { this->e.row(r, s, acc); }
+};
+
 // `next` yields the MkHalt of each launch (one per kernel: the halting protocol alternates the flag word)
 template <class Epi, class Gate, class HaltSrc>
 static inline void mk_spmv_launch_blocks(const mk_csr *A, int grid, hipStream_t st, const double *x, const Epi &epi,
                                          const Gate &gate, HaltSrc &&next, double *partials) {
+    if (A->comp_kind) {
+        // Two device matrices as one operator: first product into the temporary (gate with its side effects), second
+        // product with the combining wrapper around the real epilogue (gate's decision repeated).
+        const mk_csr *P = A->comp_a, *Q = A->comp_b;
+        if (A->comp_kind == 3) {
+            MkCsrView v1 = mk_view(Q);
+            v1.part = 1;
+            mk_spmv_launch_view(v1, mk_grid_spmv_for(Q), st, x, MkPartialOf<Epi>{epi, A->d_comp_tmp}, gate, next(), partials);
+            MkCsrView v2 = mk_view(P);
+            v2.part = 2;
+            mk_spmv_launch_view(v2, grid, st, A->d_comp_tmp, MkNoXin<Epi>{{epi}}, gate, next(), partials);
+        } else {
+            MkCsrView v1 = mk_view(P);
+            v1.part = 1;
+            mk_spmv_launch_view(v1, mk_grid_spmv_for(P), st, x, MkPartialOf<Epi>{epi, A->d_comp_tmp}, gate, next(), partials);
+            MkCsrView v2 = mk_view(Q);
+            v2.part = 2;
+            if (A->comp_kind == 1)
+                mk_spmv_launch_view(v2, grid, st, x, MkAddOf<Epi, 1>{{epi}, A->d_comp_tmp}, gate, next(), partials);
+            else
+                mk_spmv_launch_view(v2, grid, st, x, MkAddOf<Epi, -1>{{epi}, A->d_comp_tmp}, gate, next(), partials);
+        }
+        return;
+    }
     if (A->host_fn) {
         // Matrix-free operator.  Launch 1 evaluates the gate (with its side effects) and materialises the input
         // vector; the host calls the operator if the gate let the product through; launch 2 repeats the gate's

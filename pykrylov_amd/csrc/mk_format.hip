@@ -348,7 +348,7 @@ int plan_build(const mk_csr *A) {
     P.built = true;
     P.fmt = 0;
     const int want = A->want_fmt >= 0 ? A->want_fmt : default_format();
-    if (A->nnz == 0 || A->ntiles == 0 || !mk_ctx().ready || A->host_fn) return MK_OK;
+    if (A->nnz == 0 || A->ntiles == 0 || !mk_ctx().ready || A->host_fn || A->comp_kind) return MK_OK;
     auto plain = [&]() {                                     // plain CSR: column blocks if x is too long for an L2
         if (cblocks_build(A) != MK_OK) {
             for (mk_csr *B : P.cblocks) mk_csr_destroy(B);

@@ -118,6 +118,10 @@ struct mk_csr {
     mutable MkPlan plan;
     int want_fmt = -1;             // mk_csr_set_format: -1 = library default (MK_SPMV_FORMAT or 2)
     int want_cb_kb = -1;           // mk_csr_set_colblocks: -1 = library default (MK_COLBLOCK_KB or off)
+    // sum / difference / product of two device matrices (mk_csr_create_sum / _product): no arrays of its own
+    int comp_kind = 0;             // 0 none, 1 A + B, 2 A - B, 3 A * B
+    const mk_csr *comp_a = nullptr, *comp_b = nullptr;
+    double *d_comp_tmp = nullptr;  // first product's row sums (sum / difference) or B x (product)
     // matrix-free operator (mk_csr_create_callback): no arrays; products come from a host callback
     mk_matvec_fn host_fn = nullptr;
     void *host_user = nullptr;
@@ -129,6 +133,7 @@ struct mk_csr {
     mk_rowop ops[MK_ROWPROG_MAX] = {};
     // length of the vector an SpMV reads (ncols, or n_local + n_halo with a halo plan)
     int64_t x_len() const { return ex.mode == 0 ? ex.n_local + ex.n_halo : ncols; }
+    bool is_plain() const { return !comp_kind && !host_fn && ex.mode < 0; }
 };
 
 int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out);

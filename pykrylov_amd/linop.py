@@ -588,7 +588,22 @@ class CsrOperator(LinearOperator):
             dev = self._compose_with_term(other._mk_term, 'add' if f is np.add else 'sub')
             if dev is not None:
                 return dev
+        if isinstance(other, CsrOperator) and self.shape == other.shape:
+            dev = _PairCsrOperator.build(self, other, 'add' if f is np.add else 'sub')   # A + B, A - B on the device
+            if dev is not None:
+                return dev
         return LinearOperator._combine(self, other, f)
+
+    def _times_linop(self, op):
+        if isinstance(op, CsrOperator) and self.nargin == op.nargout:
+            dev = _PairCsrOperator.build(self, op, 'mul')                                 # A * B on the device
+            if dev is not None:
+                return dev
+        return LinearOperator._times_linop(self, op)
+
+    def _pair_ok(self):
+        "May this operator be an operand of a device sum / product?  (a matrix of its own, not partitioned)"
+        return getattr(self, 'local_size', None) is None
 
     def _device_matvec(self, x):
         if getattr(self, 'local_size', None) is not None:
@@ -630,6 +645,70 @@ class CsrOperator(LinearOperator):
 
     def __del__(self):
         self.free()
+
+
+class _PairCsrOperator(CsrOperator):
+    """`A + B`, `A - B`, `A * B` of two CsrOperators as ONE device operator (mk_csr_create_sum / _product): evaluated
+    as the reference's closures are -- `(A*x) + (B*x)`, `A*(B*x)`, two complete products and one element-wise step
+    (linop.py:332-354, :375-426) -- but on the device, inside the solver kernels' product site, so the result is
+    accepted by the device solvers without host round trips.  Products are counted on this operator and on both
+    operands, as the reference's closures do."""
+
+    @classmethod
+    def build(cls, a, b, how):
+        if not (a._pair_ok() and b._pair_ok()):
+            return None
+        lib = _lib.init()
+        h = ctypes.c_void_p()
+        if how == 'mul':
+            rc = lib.mk_csr_create_product(a.handle, b.handle, ctypes.byref(h))
+        else:
+            rc = lib.mk_csr_create_sum(a.handle, b.handle, 1 if how == 'add' else -1, ctypes.byref(h))
+        if rc != 0:
+            return None                                       # e.g. an operand is itself a pair: host closure
+        sym = a.symmetric and b.symmetric and how != 'mul'
+        self = cls.from_handle(h.value, symmetric=sym)
+        self._parts = (a, b, how)                             # keeps the operands alive
+        return self
+
+    def _pair_ok(self):
+        return False
+
+    def _compose(self, steps, diag_bufs=()):
+        return None                                           # alpha * (A + B): host closure (works through callbacks)
+
+    def _get_count(self):
+        return self.__dict__.get('_count', 0)
+
+    def _set_count(self, v):
+        delta = v - self.__dict__.get('_count', 0)
+        self.__dict__['_count'] = v
+        parts = self.__dict__.get('_parts')
+        if parts is not None and delta:
+            parts[0]._nMatvec += delta
+            parts[1]._nMatvec += delta
+
+    _nMatvec = property(_get_count, _set_count)
+
+    @property
+    def T(self):
+        if self.symmetric:
+            return self
+        if self._T_cache is None:
+            a, b, how = self._parts
+            if how == 'mul':
+                t = b.T * a.T                                 # (A B)^T = B^T A^T   (linop.py:350-351)
+            else:
+                t = (a.T + b.T) if how == 'add' else (a.T - b.T)
+            if isinstance(t, _PairCsrOperator):
+                t._T_cache = self
+            self._T_cache = t
+        return self._T_cache
+
+    H = T
+
+    def to_csr_arrays(self):
+        raise NotImplementedError('a device sum / product has no matrix of its own; use its operands')
 
 
 class HostOperatorShell(object):

@@ -46,26 +46,149 @@ def test_composed_products_match_reference_bits(golden, form):
     assert isinstance(y, np.ndarray) and y is not (op * d["x"])
 
 
-def test_unsupported_compositions_stay_host_operators(golden):
+def test_host_compositions_still_solve(golden):
     from pykrylov_amd import CsrOperator, CG, LinearOperator
     d = golden("composed_ops.npz")
     A = golden_csr(d, "A_")
-    a, b = op_from(A, symmetric=True), op_from(A, symmetric=True)
-    for op in (a + b, a * b, (2 + 1j) * a):
-        assert isinstance(op, LinearOperator) and not isinstance(op, CsrOperator)
-    y = (a + b) * d["x"]
-    assert np.array_equal(y, A.matvec(d["x"]) + A.matvec(d["x"]))
-    # a host composition is an operator like any other: the device loop calls it back at each product site (its
-    # matvec in turn runs the two device products through the plumbing path), reference semantics (linop.py:332-354)
-    n = A.shape[0]
-    s = CG(a + b)
-    s.solve((a + b) * np.ones(n))
-    assert s.converged and np.allclose(s.x, 1.0, rtol=0, atol=1e-3)
+    a = op_from(A, symmetric=True)
+    op = (2 + 1j) * a                                          # complex scalar: a host closure, as in the reference
+    assert isinstance(op, LinearOperator) and not isinstance(op, CsrOperator)
     deep = a
     for _ in range(4):
         deep = 2.0 * deep
     assert isinstance(deep, CsrOperator)
-    assert not isinstance(2.0 * deep, CsrOperator)             # more than MK_ROWPROG_MAX steps: host closure
+    deeper = 2.0 * deep                                        # more than MK_ROWPROG_MAX steps: host closure ...
+    assert not isinstance(deeper, CsrOperator)
+    n = A.shape[0]
+    s = CG(deeper)                                             # ... which the device loop calls back at each product
+    s.solve(deeper * np.ones(n))
+    assert s.converged and np.allclose(s.x, 1.0, rtol=0, atol=1e-3)
+
+
+def pair_matrices():
+    rng = np.random.default_rng(21)
+    n = 1500
+    def rnd(seed, m=n, k=n, nz=6000):
+        r = np.random.default_rng(seed)
+        return csr_ref.from_coo(np.concatenate([r.integers(0, m, nz), np.arange(min(m, k))]),
+                                np.concatenate([r.integers(0, k, nz), np.arange(min(m, k))]),
+                                np.concatenate([r.standard_normal(nz), 5.0 + r.random(min(m, k))]), (m, k))
+    return rnd(1), rnd(2), rng
+
+
+def test_sum_difference_product_are_device_operators_with_reference_bits():
+    """(A + B) * x = (A*x) + (B*x), (A - B) * x, (A * B) * x = A * (B * x): the reference's closures
+    (linop.py:332-354, :375-426), evaluated on the device with the same bits; products are counted on the composite
+    and on both operands."""
+    from pykrylov_amd import CsrOperator
+    A, B, rng = pair_matrices()
+    a, b = op_from(A), op_from(B)
+    x = rng.standard_normal(A.shape[1])
+    for op, want in ((a + b, A.matvec(x) + B.matvec(x)), (a - b, A.matvec(x) - B.matvec(x)),
+                     (a * b, A.matvec(B.matvec(x)))):
+        assert isinstance(op, CsrOperator) and op.shape == A.shape
+        assert np.array_equal(op * x, want)
+    assert a.nMatvec == 3 and b.nMatvec == 3
+    # transposes
+    u = rng.standard_normal(A.shape[0])
+    assert np.array_equal((a + b).T * u, A.rmatvec(u) + B.rmatvec(u))
+    assert np.array_equal((a * b).T * u, B.rmatvec(A.rmatvec(u)))
+    # scaled operands keep their row programs; a pair of pairs falls back to a host closure that still works
+    assert np.array_equal((2.0 * a - 0.5 * b) * x, 2.0 * A.matvec(x) - 0.5 * B.matvec(x))
+    nested = (a + b) + a
+    assert not isinstance(nested, CsrOperator)
+    assert np.array_equal(nested * x, (A.matvec(x) + B.matvec(x)) + A.matvec(x))
+    # rectangular product
+    C = csr_ref.from_coo(rng.integers(0, 1500, 4000), rng.integers(0, 700, 4000), rng.standard_normal(4000), (1500, 700))
+    c = op_from(C)
+    z = rng.standard_normal(700)
+    ac = a * c
+    assert isinstance(ac, CsrOperator) and ac.shape == (1500, 700)
+    assert np.array_equal(ac * z, A.matvec(C.matvec(z)))
+    with pytest.raises(Exception):
+        c * a                                                                # shapes do not chain
+
+
+def test_solvers_on_device_sums_and_products(monkeypatch):
+    """The fused epilogues and gates of the solver kernels around a two-launch product: bit-exact against the oracle
+    run on the same composite (dots in the device's order)."""
+    from pykrylov_amd import CG, BiCGSTAB, Minres, CsrOperator
+    monkeypatch.setattr(kr, "_sq", lambda a: a * a)
+    P = csr_ref.poisson2d(35)
+    n = P.shape[0]
+    dgl = csr_ref.from_coo(np.arange(n), np.arange(n), 0.5 + np.arange(n) / n, (n, n))
+    p, dgo = op_from(P, symmetric=True), op_from(dgl, symmetric=True)
+    # CG on P + D (SPD)
+    op = p + dgo
+    assert isinstance(op, CsrOperator) and op.symmetric
+    rhs = P.matvec(np.ones(n)) + dgl.matvec(np.ones(n))
+    s = CG(op)
+    s.solve(rhs)
+
+    class Sum(object):
+        shape = P.shape
+
+        def matvec(self, x):
+            return P.matvec(x) + dgl.matvec(x)
+        __call__ = matvec
+    ref = kr.cg(Sum(), rhs, red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], gpu_order.launch_geometry(op))))
+    assert s.nMatvec == ref["nMatvec"] and np.array_equal(s.x, ref["x"])
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"])
+    assert p.nMatvec == s.nMatvec and dgo.nMatvec == s.nMatvec                # counted on the operands too
+    # MINRES on P * P (symmetric positive definite, declared unsymmetric like the reference's product): the scaled
+    # gather (epilogue xin) belongs to the INNER product only
+    pp = p * p
+
+    class Prod(object):
+        shape = P.shape
+
+        def matvec(self, x):
+            return P.matvec(P.matvec(x))
+        __call__ = matvec
+    rhs2 = Prod().matvec(np.ones(n))
+    m = Minres(pp)
+    m.solve(rhs2, show=False, check=False, etol=0.0, rtol=1e-10, itnlim=60)
+    refm = kr.minres(Prod(), rhs2, check=False, etol=0.0, rtol=1e-10, itnlim=60,
+                     red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["minres"], gpu_order.launch_geometry(pp))))
+    assert (m.istop, m.itn) == (refm["istop"], refm["itn"])
+    assert np.array_equal(np.array(m.residHistory), refm["residHistory"]) and np.array_equal(m.x, refm["x"])
+    # BiCGSTAB on A - B (nonsymmetric), gates in both products
+    A, B, _ = pair_matrices()
+    a, b = op_from(A), op_from(B)
+    amb = a - 0.25 * b
+
+    class Diff(object):
+        shape = A.shape
+
+        def matvec(self, x):
+            return A.matvec(x) - 0.25 * B.matvec(x)
+        __call__ = matvec
+    rhs3 = Diff().matvec(np.ones(A.shape[0]))
+    q = BiCGSTAB(amb, reltol=1e-9)
+    q.solve(rhs3, matvec_max=80)
+    refq = kr.bicgstab(Diff(), rhs3, reltol=1e-9, matvec_max=80,
+                       red=kr.Reductions(gpu_order.GpuDots(A.shape[0], gpu_order.SPMV_SITES["bicgstab"],
+                                                           gpu_order.launch_geometry(amb))))
+    assert q.nMatvec == refq["nMatvec"] and q.residNorm == refq["residNorm"] and np.array_equal(q.x, refq["x"])
+
+
+def test_lsqr_on_a_device_product():
+    from pykrylov_amd.lls import LSQRFramework
+    from oracle import lls_ref
+    rng = np.random.default_rng(31)
+    A = csr_ref.from_coo(np.concatenate([rng.integers(0, 90, 500), np.arange(60)]),
+                         np.concatenate([rng.integers(0, 60, 500), np.arange(60)]),
+                         np.concatenate([rng.standard_normal(500), 3.0 * np.ones(60)]), (90, 60))
+    B = csr_ref.from_coo(np.concatenate([rng.integers(0, 60, 300), np.arange(40)]),
+                         np.concatenate([rng.integers(0, 40, 300), np.arange(40)]),
+                         np.concatenate([rng.standard_normal(300), 2.0 * np.ones(40)]), (60, 40))
+    op = op_from(A) * op_from(B)
+    b = rng.standard_normal(90)
+    s = LSQRFramework(op)
+    s.solve(b, show=False)
+    ref = lls_ref.lsqr(lambda v: A.matvec(B.matvec(v)), lambda u: B.rmatvec(A.rmatvec(u)), (90, 40), b.copy())
+    assert abs(s.itn - ref["itn"]) <= 1 and s.istop == ref["istop"]
+    assert np.linalg.norm(s.x - ref["x"]) <= 1e-9 * np.linalg.norm(ref["x"])
 
 
 def test_rectangular_scaling_and_transpose():
