@@ -840,6 +840,272 @@ __global__ __launch_bounds__(BLOCK) void spmv_w5(const int* __restrict__ ip, con
     if (tid == 0) part[blockIdx.x] = tot;
 }
 
+
+// ================================================================================================= version 6
+// Row-phase-only kernel: slots, value codes (or raw values) and the x windows of a tile go straight to LDS with
+// global_load_lds (no VGPR round trip, no per-nonzero staging work); after ONE barrier lane t walks row t left to
+// right, reading slot, code, x and value from LDS.  No product staging, few registers (8 workgroups per CU).
+constexpr int T6 = TILE + 16;                           // nonzeros staged per tile (stream start aligned to 16)
+#define MK_DMA16(gptr, lptr) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+template <int VC, int RUNL, int MAP, int WSKIP = 0>
+__global__ __launch_bounds__(BLOCK, 8) void spmv_w6(const int* __restrict__ ip, const uint16_t* __restrict__ sl, const double* __restrict__ dv,
+                                                    const uint8_t* __restrict__ vc, const double* __restrict__ dict, const int* __restrict__ wg,
+                                                    const unsigned* __restrict__ wn, const double* __restrict__ x, double* __restrict__ y,
+                                                    long nrows, long ntiles, int nchunk, double* part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+    double* xw = (double*)smem6;                                     // nchunk * 128 doubles (+ 2)
+    unsigned short* sslot = (unsigned short*)(xw + nchunk * 128 + 2);
+    unsigned char* scode = (unsigned char*)(sslot + T6);             // VC: codes ; raw: values (16-byte aligned)
+    double* sval = (double*)(sslot + T6);
+    __shared__ double s4[4];
+    __shared__ int sptr[BLOCK + 1];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (VC) sdict[tid] = dict[tid];
+    double acc = 0.0;
+    struct Meta { int p_lo, p_hi, my_lo; };
+    auto load_meta = [&](long tile, Meta& m) {
+        m.p_lo = m.p_hi = m.my_lo = 0;
+        if (tile < ntiles) {
+            const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+            m.p_lo = ip[r0]; m.p_hi = ip[rend]; m.my_lo = ip[(r < rend) ? r : rend];
+        }
+    };
+    Meta cur, nxt;
+    const long G = gridDim.x;
+    // runs of RUNL consecutive tiles per workgroup: position q -> tile (q / RUNL) * G * RUNL ... i.e. workgroup b handles
+    // tiles [ (s*G + b)*RUNL, +RUNL ) for s = 0, 1, ...
+    long q = 0;                                          // index within this workgroup's sequence
+    const long bx = (MAP && G % 8 == 0) ? (long)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;   // XCD-contiguous blocks per step
+    auto tile_of = [&](long qq) { return ((qq / RUNL) * G + bx) * RUNL + (qq % RUNL); };
+    long tile = tile_of(q);
+    load_meta(tile, cur);
+    for (; tile < ntiles; ++q, tile = tile_of(q)) {
+        const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+        const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
+        const int base = p_lo & ~15, cnt = p_hi - base;
+        const double xr = (WSKIP >= 2) ? 1.0 : ((r < rend) ? x[r] : 0.0);
+        load_meta(tile_of(q + 1), nxt);
+        // ---- everything the tile needs, straight into LDS
+        {
+            const i4v g = *(const i4v*)(wg + (tile * 4 + wv) * 4);
+            const unsigned nvw = wn[tile * 4 + wv];
+            const int gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hc = (int)((nvw >> (8 * i)) & 0xffu);
+                if (hc > 0 && i < 4 - WSKIP) { const int l2 = min(lane, hc - 1); MK_DMA16(x + gs[i] + 2 * l2, xw + (wv + 4 * i) * 128); }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {                            // slots: 512 per wave-level copy
+                const int c0 = (wv + 4 * c) * 512;
+                if (c0 < cnt) MK_DMA16(sl + base + c0 + 8 * lane, sslot + c0);
+            }
+            if (VC) {
+                const int c0 = wv * 1024;                            // codes: 1024 per wave-level copy
+                if (c0 < cnt) MK_DMA16(vc + base + c0 + 16 * lane, scode + c0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {                        // values: 128 per wave-level copy
+                    const int c0 = (wv + 4 * c) * 128;
+                    if (c0 < cnt) MK_DMA16(dv + base + c0 + 2 * lane, sval + c0);
+                }
+            }
+        }
+        sptr[tid] = my_lo;
+        if (tid == 0) sptr[BLOCK] = p_hi;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int my_hi = sptr[tid + 1];
+        // ---- row phase
+        const int lo = my_lo - base, len = my_hi - my_lo;
+        double sum = 0.0;
+        unsigned short sk[8];
+        unsigned char ck[8];
+        double vk[8], xk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sk[k] = sslot[lo + k]; if (VC) ck[k] = scode[lo + k]; else vk[k] = sval[lo + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xk[k] = xw[sk[k]]; if (VC) vk[k] = sdict[ck[k]]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const double t = vk[k] * xk[k]; sum += (k < len) ? t : 0.0; }
+        for (int k = 8; k < len; ++k) sum += (VC ? sdict[scode[lo + k]] : sval[lo + k]) * xw[sslot[lo + k]];
+        if (r < rend) { y[r] = sum; acc += xr * sum; }
+        __syncthreads();
+        cur = nxt;
+    }
+    const double tot = block_sum(acc, s4);
+    if (tid == 0) part[blockIdx.x] = tot;
+}
+
+
+// ================================================================================================= version 7
+// w6 with ONE 32-bit word per nonzero {slot:16 | code:8} (one conflict-free ds_read_b32 per nonzero instead of a
+// u16 and a u8 read) and, for dictionaries of <= 2 values, the value selected in registers instead of read from LDS.
+__global__ void pack_kernel(long nnz, const uint16_t* sl, const uint8_t* vc, unsigned* pk) {
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < nnz; j += (long)gridDim.x * 256) pk[j] = (unsigned)sl[j] | ((unsigned)vc[j] << 16);
+}
+
+template <int ND2, int MAP>
+__global__ __launch_bounds__(BLOCK, 8) void spmv_w7(const int* __restrict__ ip, const unsigned* __restrict__ pk, const double* __restrict__ dict,
+                                                    const int* __restrict__ wg, const unsigned* __restrict__ wn, const double* __restrict__ x,
+                                                    double* __restrict__ y, long nrows, long ntiles, int nchunk, double* part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
+    double* xw = (double*)smem7;
+    unsigned* spk = (unsigned*)(xw + nchunk * 128 + 2);
+    __shared__ double s4[4];
+    __shared__ int sptr[BLOCK + 1];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (!ND2) sdict[tid] = dict[tid];
+    const double d0 = dict[0], d1 = dict[1];
+    double acc = 0.0;
+    struct Meta { int p_lo, p_hi, my_lo; };
+    auto load_meta = [&](long tile, Meta& m) {
+        m.p_lo = m.p_hi = m.my_lo = 0;
+        if (tile < ntiles) {
+            const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+            m.p_lo = ip[r0]; m.p_hi = ip[rend]; m.my_lo = ip[(r < rend) ? r : rend];
+        }
+    };
+    Meta cur, nxt;
+    const long G = gridDim.x;
+    const long bx = (MAP && G % 8 == 0) ? (long)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    long tile = bx;
+    load_meta(tile, cur);
+    for (; tile < ntiles; tile += G) {
+        const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+        const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
+        const int base = p_lo & ~3, cnt = p_hi - base;
+        const double xr = (r < rend) ? x[r] : 0.0;
+        load_meta(tile + G, nxt);
+        {
+            const i4v g = *(const i4v*)(wg + (tile * 4 + wv) * 4);
+            const unsigned nvw = wn[tile * 4 + wv];
+            const int gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hc = (int)((nvw >> (8 * i)) & 0xffu);
+                if (hc > 0) { const int l2 = min(lane, hc - 1); MK_DMA16(x + gs[i] + 2 * l2, xw + (wv + 4 * i) * 128); }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {                            // packed words: 256 per wave-level copy
+                const int c0 = (wv + 4 * c) * 256;
+                if (c0 < cnt) MK_DMA16(pk + base + c0 + 4 * lane, spk + c0);
+            }
+        }
+        sptr[tid] = my_lo;
+        if (tid == 0) sptr[BLOCK] = p_hi;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int my_hi = sptr[tid + 1];
+        const int lo = my_lo - base, len = my_hi - my_lo;
+        double sum = 0.0;
+        unsigned wk[8];
+        double xk[8], vk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wk[k] = spk[lo + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xk[k] = xw[wk[k] & 0xffffu]; if (ND2) vk[k] = (wk[k] >> 16) ? d1 : d0; else vk[k] = sdict[wk[k] >> 16]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const double t = vk[k] * xk[k]; sum += (k < len) ? t : 0.0; }
+        for (int k = 8; k < len; ++k) { const unsigned w = spk[lo + k]; sum += (ND2 ? ((w >> 16) ? d1 : d0) : sdict[w >> 16]) * xw[w & 0xffffu]; }
+        if (r < rend) { y[r] = sum; acc += xr * sum; }
+        __syncthreads();
+        cur = nxt;
+    }
+    const double tot = block_sum(acc, s4);
+    if (tid == 0) part[blockIdx.x] = tot;
+}
+
+
+// ================================================================================================= version 8
+// w7 double-buffered: the next tile's DMA (packed words + windows) is issued into the other LDS buffer right after the
+// barrier that publishes the current one, so it lands during the row phase; ONE barrier per tile.
+template <int ND2, int MAP>
+__global__ __launch_bounds__(BLOCK, 4) void spmv_w8(const int* __restrict__ ip, const unsigned* __restrict__ pk, const double* __restrict__ dict,
+                                                    const int* __restrict__ wg, const unsigned* __restrict__ wn, const double* __restrict__ x,
+                                                    double* __restrict__ y, long nrows, long ntiles, int nchunk, double* part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    const int xwsz = nchunk * 128 + 2;                               // doubles per window buffer
+    const int bufbytes = xwsz * 8 + (TILE + 16) * 4;
+    __shared__ double s4[4];
+    __shared__ int sptr[2][BLOCK + 1];
+    __shared__ double sdict[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (!ND2) sdict[tid] = dict[tid];
+    const double d0 = dict[0], d1 = dict[1];
+    double acc = 0.0;
+    struct Meta { int p_lo, p_hi, my_lo; };
+    auto load_meta = [&](long tile, Meta& m) {
+        m.p_lo = m.p_hi = m.my_lo = 0;
+        if (tile < ntiles) {
+            const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+            m.p_lo = ip[r0]; m.p_hi = ip[rend]; m.my_lo = ip[(r < rend) ? r : rend];
+        }
+    };
+    auto issue = [&](long tile, const Meta& m, int b) {              // all of a tile's input -> LDS buffer b
+        if (tile >= ntiles) return;
+        double* xw = (double*)(smem8 + b * bufbytes);
+        unsigned* spk = (unsigned*)(xw + xwsz);
+        const i4v g = *(const i4v*)(wg + (tile * 4 + wv) * 4);
+        const unsigned nvw = wn[tile * 4 + wv];
+        const int gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hc = (int)((nvw >> (8 * i)) & 0xffu);
+            if (hc > 0) { const int l2 = min(lane, hc - 1); MK_DMA16(x + gs[i] + 2 * l2, xw + (wv + 4 * i) * 128); }
+        }
+        const int base = m.p_lo & ~3, cnt = m.p_hi - base;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int c0 = (wv + 4 * c) * 256;
+            if (c0 < cnt) MK_DMA16(pk + base + c0 + 4 * lane, spk + c0);
+        }
+        sptr[b][tid] = m.my_lo;
+        if (tid == 0) sptr[b][BLOCK] = m.p_hi;
+    };
+    Meta cur, nxt, nx2;
+    const long G = gridDim.x;
+    const long bx = (MAP && G % 8 == 0) ? (long)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    long tile = bx;
+    load_meta(tile, cur); load_meta(tile + G, nxt);
+    issue(tile, cur, 0);
+    int b = 0;
+    for (; tile < ntiles; tile += G, b ^= 1) {
+        const long r0 = tile * ROWS, rend = min(r0 + ROWS, nrows), r = r0 + tid;
+        const int p_lo = cur.p_lo, my_lo = cur.my_lo;
+        const int base = p_lo & ~3;
+        const double xr = (r < rend) ? x[r] : 0.0;
+        load_meta(tile + 2 * G, nx2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this tile's DMA (and the meta of the next) landed
+        __syncthreads();
+        issue(tile + G, nxt, b ^ 1);                                 // next tile -> other buffer, lands during the row phase
+        const double* xw = (const double*)(smem8 + b * bufbytes);
+        const unsigned* spk = (const unsigned*)(xw + xwsz);
+        const int my_hi = sptr[b][tid + 1];
+        const int lo = my_lo - base, len = my_hi - my_lo;
+        double sum = 0.0;
+        unsigned wk[8];
+        double xk[8], vk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wk[k] = spk[lo + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xk[k] = xw[wk[k] & 0xffffu]; if (ND2) vk[k] = (wk[k] >> 16) ? d1 : d0; else vk[k] = sdict[wk[k] >> 16]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const double t = vk[k] * xk[k]; sum += (k < len) ? t : 0.0; }
+        for (int k = 8; k < len; ++k) { const unsigned w = spk[lo + k]; sum += (ND2 ? ((w >> 16) ? d1 : d0) : sdict[w >> 16]) * xw[w & 0xffffu]; }
+        if (r < rend) { y[r] = sum; acc += xr * sum; }
+        cur = nxt; nxt = nx2;
+    }
+    const double tot = block_sum(acc, s4);
+    if (tid == 0) part[blockIdx.x] = tot;
+}
+
 template <class F> float timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -852,9 +1118,9 @@ int main(int argc, char** argv) {
     int reps = argc > 4 ? atoi(argv[4]) : 10;
     long n = nx * ny * nz, nnz = pre3(n, nx, ny, nz), ntiles = (n + ROWS - 1) / ROWS;
     int *ip, *ix, *stats; double *dv, *x, *y, *y0, *part, *dict; uint16_t* sl; uint8_t* vc; WDesc* wd;
-    CK(hipMalloc(&ip, (n + 1) * 4)); CK(hipMalloc(&ix, (nnz + 16) * 4)); CK(hipMalloc(&dv, (nnz + 16) * 8));
-    CK(hipMalloc(&sl, (nnz + 16) * 2)); CK(hipMalloc(&vc, nnz + 16)); CK(hipMalloc(&wd, ntiles * sizeof(WDesc)));
-    CK(hipMemset(sl, 0, (nnz + 16) * 2)); CK(hipMemset(vc, 0, nnz + 16)); CK(hipMemset(dv, 0, (nnz + 16) * 8)); CK(hipMemset(ix, 0, (nnz + 16) * 4));
+    CK(hipMalloc(&ip, (n + 1) * 4)); CK(hipMalloc(&ix, (nnz + 16) * 4)); CK(hipMalloc(&dv, (nnz + 4096) * 8));
+    CK(hipMalloc(&sl, (nnz + 16) * 2)); CK(hipMalloc(&vc, nnz + 4096)); CK(hipMalloc(&wd, ntiles * sizeof(WDesc)));
+    CK(hipMemset(sl, 0, (nnz + 16) * 2)); CK(hipMemset(vc, 0, nnz + 4096)); CK(hipMemset(dv, 0, (nnz + 4096) * 8)); CK(hipMemset(ix, 0, (nnz + 16) * 4));
     CK(hipMalloc(&x, (n + 2) * 8)); CK(hipMalloc(&y, n * 8)); CK(hipMalloc(&y0, n * 8)); CK(hipMalloc(&part, 8192 * 8));
     CK(hipMalloc(&dict, 256 * 8)); CK(hipMalloc(&stats, 8)); CK(hipMemset(stats, 0, 8));
     std::vector<double> hd(256, 0.0); hd[0] = -1.0; hd[1] = 6.0; CK(hipMemcpy(dict, hd.data(), 256 * 8, hipMemcpyHostToDevice));
@@ -877,7 +1143,7 @@ int main(int argc, char** argv) {
         float ms = timeit([&] { hipLaunchKernelGGL((spmv_win<VC, WL, DMA>), dim3(g), dim3(BLOCK), lds, 0, ip, sl, dv, vc, dict, wd, x, y, n, ntiles, part); }, reps); \
         printf("win vc=%d WL=%d dma=%d grid=%4d : %9.1f us  %.2f TB/s  %s\n", VC, WL, DMA, g, ms * 1e3, bytes / ms / 1e9, check(y)); }
     int *wg; unsigned* wn; uint16_t* sl2;
-    CK(hipMalloc(&wg, ntiles * CMAX * 4)); CK(hipMalloc(&wn, ntiles * 16)); CK(hipMalloc(&sl2, (nnz + 16) * 2)); CK(hipMemset(sl2, 0, (nnz + 16) * 2));
+    CK(hipMalloc(&wg, ntiles * CMAX * 4)); CK(hipMalloc(&wn, ntiles * 16)); CK(hipMalloc(&sl2, (nnz + 4096) * 2)); CK(hipMemset(sl2, 0, (nnz + 4096) * 2));
     CK(hipMemset(stats, 0, 8));
     cms = timeit([&] { hipLaunchKernelGGL(cover2_kernel, dim3(2048), dim3(BLOCK), 0, 0, ip, ix, n, ntiles, CMAX, wg, wn, sl2, stats); }, 1);
     CK(hipMemcpy(hs, stats, 8, hipMemcpyDeviceToHost));
@@ -905,8 +1171,29 @@ int main(int argc, char** argv) {
         CK(hipMemset(y, 0, n * 8)); \
         float ms = timeit([&] { hipLaunchKernelGGL((spmv_w5<VC>), dim3(g), dim3(BLOCK), lds, 0, ip, sl5, dv, vc, dict, qd, x, y, n, ntiles, wcap, part); }, reps); \
         printf("w5 vc=%d grid=%4d lds=%zu : %9.1f us  %.2f TB/s  %s\n", VC, g, lds, ms * 1e3, bytes / ms / 1e9, check(y)); }
-      RUN5(0) RUN5(1)
     }
-    RUN3(0, 0, 0) RUN3(1, 0, 0) RUN3(1, 1, 0)
+#define RUN6(VC, RL, MP) for (int g : {1024, 1536, 2048}) { const size_t lds = (hs[0] * 128 + 2) * 8 + T6 * 2 + (VC ? T6 : T6 * 8) + 64; \
+        CK(hipMemset(y, 0, n * 8)); \
+        float ms = timeit([&] { hipLaunchKernelGGL((spmv_w6<VC, RL, MP>), dim3(g), dim3(BLOCK), lds, 0, ip, sl2, dv, vc, dict, wg, wn, x, y, n, ntiles, hs[0], part); }, reps); \
+        printf("w6 vc=%d run=%d map=%d grid=%4d lds=%zu : %9.1f us  %.2f TB/s  %s\n", VC, RL, MP, g, lds, ms * 1e3, bytes / ms / 1e9, check(y)); }
+    RUN6(1, 1, 0)
+    { unsigned* pk; CK(hipMalloc(&pk, (nnz + 4096) * 4)); CK(hipMemset(pk, 0, (nnz + 4096) * 4));
+      hipLaunchKernelGGL(pack_kernel, dim3(4096), dim3(256), 0, 0, nnz, sl2, vc, pk); CK(hipDeviceSynchronize());
+#define RUN7(ND2, MP) for (int g : {1024}) { const size_t lds = (hs[0] * 128 + 2) * 8 + (TILE + 16) * 4 + 64; \
+        CK(hipMemset(y, 0, n * 8)); \
+        float ms = timeit([&] { hipLaunchKernelGGL((spmv_w7<ND2, MP>), dim3(g), dim3(BLOCK), lds, 0, ip, pk, dict, wg, wn, x, y, n, ntiles, hs[0], part); }, reps); \
+        printf("w7 nd2=%d map=%d grid=%4d lds=%zu : %9.1f us  %.2f TB/s  %s\n", ND2, MP, g, lds, ms * 1e3, bytes / ms / 1e9, check(y)); }
+      RUN7(1, 0)
+#define RUN8(ND2, MP) for (int g : {768, 1024, 1280, 1536}) { const size_t lds = 2 * ((hs[0] * 128 + 2) * 8 + (TILE + 16) * 4); \
+        CK(hipMemset(y, 0, n * 8)); \
+        float ms = timeit([&] { hipLaunchKernelGGL((spmv_w8<ND2, MP>), dim3(g), dim3(BLOCK), lds, 0, ip, pk, dict, wg, wn, x, y, n, ntiles, hs[0], part); }, reps); \
+        printf("w8 nd2=%d map=%d grid=%4d lds=%zu : %9.1f us  %.2f TB/s  %s\n", ND2, MP, g, lds, ms * 1e3, bytes / ms / 1e9, check(y)); }
+      RUN8(1, 0) RUN8(1, 1) RUN8(0, 1)
+    }
+#define RUN6S(VC, WS) for (int g : {1024, 2048}) { const size_t lds = (hs[0] * 128 + 2) * 8 + T6 * 2 + (VC ? T6 : T6 * 8) + 64; \
+        float ms = timeit([&] { hipLaunchKernelGGL((spmv_w6<VC, 1, 0, WS>), dim3(g), dim3(BLOCK), lds, 0, ip, sl2, dv, vc, dict, wg, wn, x, y, n, ntiles, hs[0], part); }, reps); \
+        printf("w6 vc=%d WSKIP=%d grid=%4d : %9.1f us  (timing only: window chunks i >= %d of each wave not loaded%s)\n", VC, WS, g, ms * 1e3, 4 - WS, WS >= 2 ? ", no x[r] load" : ""); }
+    RUN6S(1, 4)
+    RUN3(0, 0, 0) RUN3(1, 0, 0)
     return 0;
 }
