@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s per GPU
 METRIC = "Krylov iters/sec + SpMV achieved HBM GB/s (% of peak), fp64"
 FMT_NAMES = {0: "csr (int32 columns + fp64 values, x gathered)",
              1: "windowed tiles (x windows in LDS, uint16 slots + fp64 values)",
-             2: "windowed tiles + value dictionary (uint16 slots + uint8 value codes)"}
+             2: "windowed tiles + value dictionary (one packed 32-bit word per nonzero: LDS slot + value code)"}
 
 
 def spmv_bytes(nrows, ncols, nnz):

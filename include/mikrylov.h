@@ -131,7 +131,8 @@ int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn, void *
  *   0  plain CSR: 4-byte columns + 8-byte values, x gathered through L1/L2;
  *   1  windowed tiles: per 256-row tile the referenced columns are covered by contiguous windows of x that the kernel
  *      stages in LDS with coalesced loads; per nonzero a uint16 LDS slot replaces the column (2 + 8 bytes);
- *   2  format 1 + value dictionary: matrices with <= 256 distinct values store one byte per value (2 + 1 bytes).
+ *   2  format 1 + value dictionary: matrices with <= 256 distinct values store ONE 32-bit word per nonzero
+ *      {LDS slot : 16 | dictionary index : 8} and no values (4 bytes); slots, words and windows go to LDS by direct copies.
  * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 2).  A request the matrix does not qualify for
  * degrades silently (2 -> 1 -> 0): tiles with scattered columns always take the gather path of format 0.
  * mk_csr_format_info reports what is in use: the format, the number of windowed tiles, the LDS chunks (128

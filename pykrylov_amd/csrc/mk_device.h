@@ -43,7 +43,7 @@ struct MkCsrView {
     const uint16_t *slots;   // per nonzero: position of its x entry in the tile's LDS window buffer
     const int32_t *wg;       // per tile and wave: global start of the wave's (<= 4) window chunks; bit 0 of [0]: tile eligible
     const uint32_t *wn;      // per tile and wave: half lengths of those chunks, one byte each
-    const uint8_t *codes;    // per nonzero: index of its value in `dict` (fmt 2)
+    const uint32_t *pk;      // fmt 2, per nonzero: {LDS slot : 16 | index of its value in `dict` : 8}
     const double *dict;
     // column-blocked products (fmt 0): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
     const double *sum_in;
@@ -76,15 +76,15 @@ int mk_host_product(const mk_csr *A, hipStream_t st);   // mk_core.hip: D2H, hos
 
 // SpMV grid = the workgroups that are resident at once (persistent tiles; a second round only adds a tail).
 // CSR path: 4 per CU at <= 64 registers, twice as many smaller shares while the problem is cache resident.
-// Windowed path: 4 per CU (raw values, ~100 registers) or 5 per CU (dictionary) -- measured on 512^3 and 2-D
-// n = 1e6: 1024 / 1280 workgroups beat every other count by 5-25 % (tools/sweep_fmt.sh).
+// Windowed paths: 4 per CU (1024 workgroups); the dictionary kernel takes 5 per CU while the problem is cache
+// resident -- measured on 512^3 and 2-D n = 1e6 (tools/sweep_fmt.sh): every other count loses 5-25 %.
 static inline int mk_grid_spmv_for(const mk_csr *A) {
     if (A->comp_kind) return mk_grid_spmv_for(A->comp_kind == 3 ? A->comp_a : A->comp_b);   // the final launch's matrix
     int g = mk_grid_spmv(A->ntiles);
     if (getenv("MK_GRID_SPMV") || A->host_fn) return g;
     const MkPlan *P = mk_csr_plan(A);
     int64_t cap = mk_cap_spmv();
-    if (P && P->fmt == 2) cap = 1280;
+    if (P && P->fmt == 2) cap = mk_xcd_chunks(A) ? 1280 : 1024;
     else if (P && P->fmt == 1) cap = 1024;
     else if (mk_xcd_chunks(A)) cap = 2 * cap > MK_MAXP ? MK_MAXP : 2 * cap;
     g = (int)(A->ntiles > cap ? cap : (A->ntiles < 1 ? 1 : A->ntiles));
@@ -123,7 +123,7 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.slots = P->d_slots;
         v.wg = P->d_wg;
         v.wn = P->d_wn;
-        v.codes = P->d_codes;
+        v.pk = P->d_pk;
         v.dict = P->d_dict;
     }
     return v;
@@ -189,7 +189,8 @@ __device__ __forceinline__ double mk_rowprog(const MkCsrView &A, double t, const
 //    scalar loads) and pass 1 multiplies against ds_read_b64 at a per-nonzero uint16 slot.  No gather goes
 //    through the texture-address path, which is what saturates first in a CSR product on this chip, and
 //    a nonzero costs 2 (slot) + 8 (value) bytes of HBM traffic instead of 4 + 8; with a value dictionary (fmt 2,
-//    matrices with <= 256 distinct values) 2 + 1.  The whole input of the NEXT tile (matrix stream and windows)
+//    matrices with <= 256 distinct values) one packed 4-byte word and a kernel of its own (below).  In fmt 1 the whole
+//    input of the NEXT tile (matrix stream and windows)
 //    is issued into registers as soon as this tile's registers have been consumed, so it lands while the row
 //    sums are formed; two barriers per tile.
 //  * gathers (fmt 0 and every tile the builder could not cover: scattered columns, > 2048 nonzeros): four
@@ -217,6 +218,28 @@ typedef unsigned mk_u4 __attribute__((ext_vector_type(4)));
 constexpr int MK_PROD_LD = MK_BLOCK + 1;
 constexpr int MK_PROD_LDS = 8 * MK_PROD_LD;          // doubles reserved for products (>= MK_SPMV_TILE of the gather path)
 __device__ __forceinline__ int mk_phys(int idx) { return (idx & 7) * MK_PROD_LD + (idx >> 3); }
+
+// Tile id of position p of a launch's tile list, as a SCALAR: every lane computes the same value, but only an explicit
+// readfirstlane lets the compiler keep it (and everything indexed by it: window descriptors, row-pointer ends) in
+// scalar registers and fetch it with scalar loads -- as a vector value each tile started with a dependent vector
+// load of its descriptor in front of all of its copies (measured: 18 % of the fmt 2 kernel at 512^3).
+// Wave-uniform read-only data (tile lists, row-pointer ends, window descriptors) through the SCALAR cache: a load from
+// the constant address space at a uniform address becomes an s_load.  (Pointers that arrive inside the by-value view
+// struct are not scalarised by the compiler on its own: it emits a vector load + s_waitcnt vmcnt(0) + readfirstlane,
+// i.e. a full memory round trip that also drains every copy already in flight.)
+template <class T>
+__device__ __forceinline__ T mk_sload(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
+__device__ __forceinline__ int64_t mk_tile_at(const MkCsrView &A, int64_t p) {
+#ifdef MK_AB_VECTOR_TILE
+    return A.tiles ? (int64_t)A.tiles[p] : p;
+#else
+    const int t = A.tiles ? mk_sload(A.tiles + p) : (int)p;
+    return (int64_t)__builtin_amdgcn_readfirstlane(t);
+#endif
+}
 
 struct MkTileMeta {
     int p_lo, p_hi, my_lo;
@@ -324,12 +347,17 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     auto load_meta = [&](int64_t p, MkTileMeta &m) {         // p: position in the tile list of this launch
         m.p_lo = m.p_hi = m.my_lo = 0;
         if (p < end) {
-            const int64_t tile = A.tiles ? (int64_t)A.tiles[p] : p;
+            const int64_t tile = mk_tile_at(A, p);
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
             const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
             const int64_t r = r0 + tid;
+#ifdef MK_AB_VECTOR_TILE
             m.p_lo = A.indptr[r0];
             m.p_hi = A.indptr[rend];
+#else
+            m.p_lo = mk_sload(A.indptr + r0);
+            m.p_hi = mk_sload(A.indptr + rend);
+#endif
             m.my_lo = A.indptr[(r < rend) ? r : rend];      // rows past the end start (and end) at p_hi
         }
     };
@@ -337,7 +365,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         MkTileMeta cur, nxt;
         load_meta(pos, cur);
         for (; pos < end; pos += stride) {
-            const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
+            const int64_t tile = mk_tile_at(A, pos);
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
             const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
             const int64_t r = r0 + tid;
@@ -353,13 +381,123 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             if (r < rend) epi.row(r, sum, acc);
             cur = nxt;
         }
+    } else if constexpr (FMT == 2) {
+        // ---- windowed tiles with a value dictionary: ROW PHASE ONLY.  One 32-bit word per nonzero {slot | code};
+        // the words and the x windows of a tile go straight to LDS with global_load_lds (no VGPR round trip, no
+        // per-nonzero staging work); after one barrier lane t walks row t left to right: word, x and value from LDS
+        // (consecutive rows read consecutive words / x entries: conflict free for the usual odd row lengths).
+        // Measured against the product-staging design of fmt 1 with the codes: 512^3 1.50 -> 1.32 ms, 2-D n = 1e6
+        // 13.1 -> 9.1 us (tools/ubench/spmv_win2.hip, w3 vs w7).
+        const int lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        uint32_t *spk = reinterpret_cast<uint32_t *>(xw + 128 * A.wchunks + 2);
+        __shared__ double sdict[256];
+        sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // (read after a barrier below)
+        const double d0 = A.dict[0], d1 = A.dict[A.ndict > 1 ? 1 : 0];
+        const bool two = A.ndict <= 2;                       // value picked in registers instead of read from LDS
+        // this wave's window descriptor of a tile (scalar loads, issued one tile ahead like the row pointers)
+        struct Desc {
+            mk_i4 g;
+            unsigned nvw;
+        };
+        auto load_desc = [&](int64_t p, Desc &d) {
+            d.g = mk_i4{0, 0, 0, 0};
+            d.nvw = 0;
+            if (p < end) {
+                const int64_t t = mk_tile_at(A, p);
+                d.g = mk_sload(reinterpret_cast<const mk_i4 *>(A.wg + (t * 4 + wv) * 4));
+                d.nvw = mk_sload(A.wn + t * 4 + wv);
+            }
+        };
+        MkTileMeta cur, nxt;
+        Desc dcur, dnxt;
+        load_meta(pos, cur);
+        load_desc(pos, dcur);
+        for (; pos < end; pos += stride) {
+            const int64_t tile = mk_tile_at(A, pos);
+            const int64_t r0 = tile * MK_ROWS_PER_TILE;
+            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
+            const int64_t r = r0 + tid;
+            if constexpr (MkHasPre<Epi>::value) {
+                if (r < rend) epi.pre(r);
+            }
+            const mk_i4 g = dcur.g;
+            double sum = 0.0;
+            if (g.x & 1) {
+                const unsigned nvw = dcur.nvw;
+                const int gs[4] = {g.x & ~1, g.y, g.z, g.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hc = (int)((nvw >> (8 * i)) & 0xffu);
+                    if (hc > 0) {
+                        const int l2 = (lane < hc) ? lane : hc - 1;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + gs[i] + 2 * l2),
+                                                         (__attribute__((address_space(3))) void *)(xw + (wv + 4 * i) * 128),
+                                                         16, 0, 0);
+                    }
+                }
+                const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
+                const int base = p_lo & ~3, cnt = p_hi - base;             // 0 < cnt <= MK_SPMV_TILE + 3 (builder)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {                                // 256 words per wave-level copy
+                    const int c0 = (wv + 4 * c) * 256;
+                    if (c0 < cnt)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.pk + base + c0 + 4 * lane),
+                                                         (__attribute__((address_space(3))) void *)(spk + c0), 16, 0, 0);
+                }
+                load_meta(pos + stride, nxt);                // next tile's row pointers and descriptor go in flight
+                load_desc(pos + stride, dnxt);
+                sptr[tid] = my_lo;
+                if (tid == 0) sptr[MK_BLOCK] = p_hi;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int my_hi = sptr[tid + 1];
+                const int lo = my_lo - base, len = my_hi - my_lo;
+                unsigned wk[8];
+                double xk[8], vk[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wk[k] = spk[lo + k];
+                if (two) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        xk[k] = epi.xin(xw[wk[k] & 0xffffu]);
+                        vk[k] = (wk[k] >> 16) ? d1 : d0;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        xk[k] = epi.xin(xw[wk[k] & 0xffffu]);
+                        vk[k] = sdict[wk[k] >> 16];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const double t = vk[k] * xk[k];
+                    sum += (k < len) ? t : 0.0;              // (+0.0 never changes a running sum that started at +0.0)
+                }
+                for (int k = 8; k < len; ++k) {
+                    const unsigned w = spk[lo + k];
+                    sum += sdict[w >> 16] * epi.xin(xw[w & 0xffffu]);
+                }
+                __syncthreads();                             // the next tile's copies overwrite this LDS
+            } else {
+                load_meta(pos + stride, nxt);
+                load_desc(pos + stride, dnxt);
+                sum = mk_tile_gather(A, x, epi, prod, sptr, cur);
+            }
+            if constexpr (PROG) {
+                if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
+            }
+            if (r < rend) epi.row(r, sum, acc);
+            cur = nxt;
+            dcur = dnxt;
+        }
     } else {
         const int lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         struct WRegs {
             mk_u4 s;
             mk_d2 val[4];
-            mk_u2 code;
             mk_d2 w[4];
             unsigned nvw;
             bool valid;
@@ -369,11 +507,12 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             R.valid = false;
             R.nvw = 0;
             if (p >= end) return;
-            const int64_t tile = A.tiles ? (int64_t)A.tiles[p] : p;
-            const mk_i4 g = *reinterpret_cast<const mk_i4 *>(A.wg + (tile * 4 + wv) * 4);
+            const int64_t tile = mk_tile_at(A, p);
+            const mk_i4 g = mk_sload(reinterpret_cast<const mk_i4 *>(A.wg + (tile * 4 + wv) * 4));
+            const unsigned nvw = mk_sload(A.wn + tile * 4 + wv);
             if (!(g.x & 1)) return;                          // the builder could not cover this tile: gather path
             R.valid = true;
-            R.nvw = A.wn[tile * 4 + wv];
+            R.nvw = nvw;
             const int gs[4] = {g.x & ~1, g.y, g.z, g.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -387,15 +526,9 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             int j = 8 * tid;
             j = (j < cnt) ? j : ((cnt - 1) & ~7);
             R.s = *reinterpret_cast<const mk_u4 *>(A.slots + base + j);
-            if constexpr (FMT == 2) {
-                R.code = *reinterpret_cast<const mk_u2 *>(A.codes + base + j);
-            } else {
 #pragma unroll
-                for (int h = 0; h < 4; ++h) R.val[h] = *reinterpret_cast<const mk_d2 *>(A.data + base + j + 2 * h);
-            }
+            for (int h = 0; h < 4; ++h) R.val[h] = *reinterpret_cast<const mk_d2 *>(A.data + base + j + 2 * h);
         };
-        __shared__ double sdict[FMT == 2 ? 256 : 1];
-        if constexpr (FMT == 2) sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // read after a barrier below
         MkTileMeta cur, nxt, nx2;
         WRegs R;
         load_meta(pos, cur);
@@ -404,7 +537,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         bool lds_busy = false;                               // products of a windowed tile may still be read by slower waves
         bool zero_ok = false;                                // the zero column of the staging buffer is in place
         for (; pos < end; pos += stride) {
-            const int64_t tile = A.tiles ? (int64_t)A.tiles[pos] : pos;
+            const int64_t tile = mk_tile_at(A, pos);
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
             const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
             const int64_t r = r0 + tid;
@@ -436,17 +569,8 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const double x0 = xw[sw[h] & 0xffffu], x1 = xw[sw[h] >> 16];
-                    double v0, v1;
-                    if constexpr (FMT == 2) {
-                        const unsigned cw = (h < 2) ? R.code.x : R.code.y;
-                        v0 = sdict[(cw >> (16 * (h & 1))) & 0xffu];
-                        v1 = sdict[(cw >> (16 * (h & 1) + 8)) & 0xffu];
-                    } else {
-                        v0 = R.val[h].x;
-                        v1 = R.val[h].y;
-                    }
-                    pr[2 * h] = v0 * x0;
-                    pr[2 * h + 1] = v1 * x1;
+                    pr[2 * h] = R.val[h].x * x0;
+                    pr[2 * h + 1] = R.val[h].y * x1;
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) prod[i * MK_PROD_LD + tid] = pr[i];
@@ -500,11 +624,13 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, FMT == 0 ? 8 : (FMT == 1 ? 4 : 5)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, FMT == 0 ? 8 : 4) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) double mk_smem[];     // products [MK_PROD_LDS], then the windows
+    // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
+    // packed words share the space the gather path of uncovered tiles uses for products (never live together)
+    extern __shared__ __attribute__((aligned(16))) double mk_smem[];
     double *prod = mk_smem;
-    double *xw = mk_smem + MK_PROD_LDS;
+    double *xw = (FMT == 2) ? mk_smem : mk_smem + MK_PROD_LDS;
     __shared__ double s4[4];
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -556,7 +682,11 @@ __global__ __launch_bounds__(MK_BLOCK, FMT == 0 ? 8 : (FMT == 1 ? 4 : 5)) void m
 template <class Epi, class Gate, bool PROG>
 static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t st, const double *x, const Epi &epi,
                                       const Gate &gate, MkHalt halt, double *partials) {
-    const size_t lds = sizeof(double) * (size_t)(MK_PROD_LDS + (v.fmt ? 128 * v.wchunks : 0));
+    size_t lds = sizeof(double) * (size_t)(MK_PROD_LDS + (v.fmt == 1 ? 128 * v.wchunks + 2 : 0));
+    if (v.fmt == 2) {                                        // windows + packed words, or the gather path's products
+        const size_t w = sizeof(double) * (size_t)(128 * v.wchunks + 2) + sizeof(uint32_t) * (MK_SPMV_TILE + 16);
+        lds = w > lds ? w : lds;
+    }
     if (v.fmt == 2)
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 2>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                            halt, partials);

@@ -11,7 +11,8 @@
 //    (counted from the 8-aligned start of its stream) and its cover needs <= 16 chunks.  Per nonzero the builder
 //    stores the uint16 position of its x entry in the tile's LDS window buffer.
 //  * value dictionary: when the whole matrix holds <= 256 distinct values (bit patterns), `data` is replaced
-//    by one byte per nonzero that indexes the sorted dictionary -- constant-coefficient stencils, graph Laplacians,
+//    by an 8-bit index into the sorted dictionary, packed with the slot into ONE 32-bit word per nonzero --
+//    constant-coefficient stencils, graph Laplacians,
 //    incidence matrices.  Lossless: the product multiplies exactly the same doubles.
 //
 // Everything is integer work on the device; the row sums are still formed left to right from the same products,
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(MK_BLOCK) void dict_finalize(const unsigned long lo
 
 __global__ __launch_bounds__(MK_BLOCK) void dict_encode(int64_t nnz, const double *__restrict__ data,
                                                         const double *__restrict__ dict, int count,
-                                                        uint8_t *__restrict__ codes) {
+                                                        const uint16_t *__restrict__ slots, uint32_t *__restrict__ pk) {
     __shared__ unsigned long long k[256];
     k[threadIdx.x] = (threadIdx.x < count) ? (unsigned long long)__double_as_longlong(dict[threadIdx.x]) : ~0ULL;
     __syncthreads();
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(MK_BLOCK) void dict_encode(int64_t nnz, const doubl
 #pragma unroll
         for (int step = 128; step >= 1; step >>= 1)
             if (lo + step < 256 && k[lo + step] <= key) lo += step;
-        codes[j] = (uint8_t)lo;
+        pk[j] = (uint32_t)slots[j] | ((uint32_t)lo << 16);
     }
 }
 
@@ -265,7 +266,7 @@ void plan_free(MkPlan &P) {
     hipFree(P.d_slots);
     hipFree(P.d_wg);
     hipFree(P.d_wn);
-    hipFree(P.d_codes);
+    hipFree(P.d_pk);
     hipFree(P.d_dict);
     P = MkPlan();
 }
@@ -418,10 +419,13 @@ int plan_build(const mk_csr *A) {
         P.d_dict = nullptr;
         return MK_OK;
     }
-    if (hipMalloc((void **)&P.d_codes, pad) != hipSuccess) return fail("hipMalloc");
-    hipMemsetAsync(P.d_codes, 0, pad, st);
+    // (the kernel copies whole 1 KiB pieces of the word stream: room for one piece behind the last nonzero)
+    const size_t pkpad = (size_t)A->nnz + 256 + MK_CSR_PAD;
+    if (hipMalloc((void **)&P.d_pk, sizeof(uint32_t) * pkpad) != hipSuccess) return fail("hipMalloc");
+    hipMemsetAsync(P.d_pk, 0, sizeof(uint32_t) * pkpad, st);
     hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, P.d_dict);
-    hipLaunchKernelGGL(dict_encode, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, P.d_dict, h_state[0], P.d_codes);
+    hipLaunchKernelGGL(dict_encode, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, P.d_dict, h_state[0], P.d_slots,
+                       P.d_pk);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail("dictionary encode");
     hipFree(d_table);
     P.ndict = h_state[0];
@@ -462,13 +466,13 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
     if (dict_size) *dict_size = P->ndict;
     if (matrix_bytes_per_product) {
         // bytes of matrix data one product streams from HBM (x and y not included): per nonzero 4 + 8 (CSR),
-        // 2 + 8 (windows) or 2 + 1 (windows + dictionary), plus row pointers and the window descriptors
+        // 2 + 8 (windows) or 4 (windows + dictionary: one packed word), plus row pointers and the window descriptors
         int64_t b = 4 * (A->nrows + 1);
         if (P->fmt == 0) b += 12 * A->nnz;
         else {
             // nonzeros of windowed tiles are not kept; the mixed case is bounded by the covered share
             const double share = A->ntiles ? (double)P->covered / (double)A->ntiles : 0.0;
-            const double per = (P->fmt == 2) ? 3.0 : 10.0;
+            const double per = (P->fmt == 2) ? 4.0 : 10.0;
             b += (int64_t)(A->nnz * (share * per + (1.0 - share) * 12.0)) + 80 * A->ntiles;
         }
         *matrix_bytes_per_product = b;

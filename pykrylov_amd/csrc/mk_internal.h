@@ -98,7 +98,7 @@ struct MkPlan {
     uint16_t *d_slots = nullptr;
     int32_t *d_wg = nullptr;
     uint32_t *d_wn = nullptr;
-    uint8_t *d_codes = nullptr;
+    uint32_t *d_pk = nullptr;      // fmt 2: {slot | code << 16} per nonzero
     double *d_dict = nullptr;
     // column blocks (plain-CSR matrices whose x does not fit an XCD's L2): A = [A_0 | A_1 | ...] by column range,
     // each block a CSR matrix over all rows; a product runs block after block with the running row sums carried

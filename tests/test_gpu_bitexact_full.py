@@ -38,14 +38,14 @@ def device_rhs_ones(op, shift=0.0):
 @pytest.mark.parametrize("fmt", [2, 0])
 def test_cg_config2_n1e6_bit_exact_full_run(fmt):
     """configs[1]: CG, 2-D Poisson n = 1e6, defaults: all 1474 iterations, history and iterate bit for bit, in the
-    windowed+dictionary format (1 280 workgroups) and in plain CSR (2 048 workgroups, XCD-chunked)."""
+    windowed+dictionary format (1 280 workgroups, XCD-chunked) and in plain CSR (2 048 workgroups, XCD-chunked)."""
     from pykrylov_amd import CG, gallery, _lib
     op = gallery.poisson2d(1000)
     _lib.check(_lib.init().mk_csr_set_format(op.handle, fmt))
     n = op.shape[0]
     rhs = device_rhs_ones(op)
     geo = gpu_order.launch_geometry(op)
-    assert geo[0] > 1024                                       # really a multi-step, multi-chunk launch
+    assert geo[0] >= 1024                                      # really a multi-step, multi-chunk launch (3907 tiles)
     s = CG(op)
     s.solve(rhs)
     A = csr_ref.poisson2d(1000)

@@ -1125,7 +1125,10 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dict, 256 * 8)); CK(hipMalloc(&stats, 8)); CK(hipMemset(stats, 0, 8));
     std::vector<double> hd(256, 0.0); hd[0] = -1.0; hd[1] = 6.0; CK(hipMemcpy(dict, hd.data(), 256 * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(gen3, dim3(4096), dim3(256), 0, 0, nx, ny, nz, ip, ix, dv, vc);
-    std::vector<double> hx(n); for (long i = 0; i < n; ++i) hx[i] = 1.0 + (double)(i % 977) * 1e-3;
+    const int xmode = argc > 5 ? atoi(argv[5]) : 0;       // 0: smooth x, 1: random bits (data-dependent clocks)
+    std::vector<double> hx(n);
+    if (xmode == 0) for (long i = 0; i < n; ++i) hx[i] = 1.0 + (double)(i % 977) * 1e-3;
+    else { unsigned long long st = 88172645463325252ULL; for (long i = 0; i < n; ++i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; hx[i] = ((double)(st >> 11) / 9007199254740992.0 - 0.5) * 1e3; } }
     CK(hipMemcpy(x, hx.data(), n * 8, hipMemcpyHostToDevice)); CK(hipDeviceSynchronize());
     float cms = timeit([&] { hipLaunchKernelGGL(cover_kernel, dim3(2048), dim3(BLOCK), 0, 0, ip, ix, n, ntiles, 8192, wd, sl, stats); }, 1);
     int hs[2]; CK(hipMemcpy(hs, stats, 8, hipMemcpyDeviceToHost));
