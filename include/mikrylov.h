@@ -57,6 +57,10 @@ int mk_memset(void *dst_dev, int byte, size_t bytes);
  * (write = 0) or writing (write = 1).  Known byte counts to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE. */
 int mk_calib_stream(void *dev, int64_t bytes, int width, int write);
 
+/* Device vectors handed to this library (x, y, rhs, guess, preconditioner diagonals ...) must be 16-byte aligned and
+ * readable up to an even number of entries (kernels move vectors in 16-byte pairs); every buffer from mk_malloc is.
+ * Misaligned pointers are rejected with MK_ERR_ARG. */
+
 /* ------------------------------------------------------------------ CSR -------- */
 /* The device-resident operator behind `linop.LinearOperator`: replaces the user
  * `matvec` callable of pykrylov/linop/linop.py:114,:289 (Pysparse in

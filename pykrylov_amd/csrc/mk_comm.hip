@@ -26,10 +26,15 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *) = nullptr;   // optional
 };
 
 Rccl g_rccl;
 ncclComm_t g_comm = nullptr;
+// The halo messages of an overlapped product travel on a second stream while all-reduces are enqueued on the main
+// one: they get their own communicator (ncclCommSplit of the first), so that no two operations of ONE communicator
+// are ever in flight on different streams.  Falls back to the shared communicator if the library lacks the call.
+ncclComm_t g_comm_halo = nullptr;
 int g_nranks = 1, g_rank = 0;
 
 // Host-staged transport (mk_comm_init_host): the same collectives carried by caller-supplied functions that work
@@ -77,6 +82,7 @@ int load_rccl() {
     MK_SYM(GroupEnd, "ncclGroupEnd");
     MK_SYM(GetErrorString, "ncclGetErrorString");
 #undef MK_SYM
+    g_rccl.CommSplit = (decltype(g_rccl.CommSplit))dlsym(h, "ncclCommSplit");
     g_rccl.handle = h;
     return MK_OK;
 }
@@ -184,6 +190,11 @@ extern "C" int mk_comm_init(int nranks, int rank, const void *id128) {
     MK_NCCL(g_rccl.CommInitRank(&g_comm, nranks, id, rank));
     g_nranks = nranks;
     g_rank = rank;
+    g_comm_halo = nullptr;
+    if (nranks > 1 && g_rccl.CommSplit && !getenv("MK_SHARED_COMM")) {
+        ncclComm_t c2 = nullptr;
+        if (g_rccl.CommSplit(g_comm, 0, rank, &c2, nullptr) == ncclSuccess && c2) g_comm_halo = c2;
+    }
     return MK_OK;
 }
 
@@ -209,7 +220,9 @@ extern "C" int mk_comm_destroy(void) {
         g_host = HostComm();
     }
     if (g_comm) {
-        if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+        if (mk_ctx().ready) hipDeviceSynchronize();
+        if (g_comm_halo) g_rccl.CommDestroy(g_comm_halo);
+        g_comm_halo = nullptr;
         g_rccl.CommDestroy(g_comm);
         g_comm = nullptr;
     }
@@ -361,13 +374,14 @@ int mk_exchange_begin(const mk_csr *A, double *x_ext) {
     MK_HIP(hipEventRecord(ex.ev_pack, st));
     MK_HIP(hipStreamWaitEvent(ex.comm_stream, ex.ev_pack, 0));
     MK_HIP(hipEventRecord(ex.ev_comm0, ex.comm_stream));
+    ncclComm_t hc = g_comm_halo ? g_comm_halo : g_comm;
     MK_NCCL(g_rccl.GroupStart());
     for (int r = 0; r < g_nranks; ++r) {
         if (ex.send_count[r] > 0)
-            MK_NCCL(g_rccl.Send(ex.d_send_buf + ex.send_off[r], (size_t)ex.send_count[r], ncclDouble, r, g_comm,
+            MK_NCCL(g_rccl.Send(ex.d_send_buf + ex.send_off[r], (size_t)ex.send_count[r], ncclDouble, r, hc,
                                 ex.comm_stream));
         if (ex.recv_count[r] > 0)
-            MK_NCCL(g_rccl.Recv(x_ext + ex.n_local + ex.recv_off[r], (size_t)ex.recv_count[r], ncclDouble, r, g_comm,
+            MK_NCCL(g_rccl.Recv(x_ext + ex.n_local + ex.recv_off[r], (size_t)ex.recv_count[r], ncclDouble, r, hc,
                                 ex.comm_stream));
     }
     MK_NCCL(g_rccl.GroupEnd());

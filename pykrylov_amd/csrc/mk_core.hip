@@ -372,6 +372,7 @@ static MkHalt never_halt() { return MkHalt{g_halt0, 0, 0}; }
 extern "C" int mk_spmv(const mk_csr *A, const double *x, double *y) {
     MK_REQUIRE_INIT();
     MK_ARG(A && x && y);
+    MK_ARG(MK_ALIGNED16(x) && MK_ALIGNED16(y));              // kernels read / write vectors in 16-byte pairs
     if (A->nrows == 0) return MK_OK;
     MkPlainEpi epi{y};
     mk_spmv_launch(A, mk_grid_spmv_for(A), mk_ctx().stream, x, epi, MkNoGate(), never_halt(), mk_ctx().d_scratch);
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_finalize_kernel(const double *par
 static int dot_impl(int64_t n, const double *x, const double *y, double *result, int do_sqrt) {
     MK_REQUIRE_INIT();
     MK_ARG(n >= 0 && result && (n == 0 || (x && y)));
+    MK_ARG(MK_ALIGNED16(x) && MK_ALIGNED16(y));
     MkContext &c = mk_ctx();
     if (n == 0) {
         *result = 0.0;
@@ -442,6 +444,7 @@ struct OpAxpby {   // y = alpha*x + beta*y  (mode 0), y += alpha*x (mode 1), x *
 static int axpby_impl(int64_t n, double alpha, const double *x, double beta, double *y, int mode) {
     MK_REQUIRE_INIT();
     MK_ARG(n >= 0 && (n == 0 || y) && (n == 0 || mode == 2 || x));
+    MK_ARG(MK_ALIGNED16(x) && MK_ALIGNED16(y));
     if (n == 0) return MK_OK;
     OpAxpby op{x, y, alpha, beta, mode};
     hipLaunchKernelGGL(mk_stream_kernel<OpAxpby>, dim3(mk_grid_stream(n)), dim3(MK_BLOCK), 0, mk_ctx().stream, op, n,

@@ -62,6 +62,9 @@ int mk_fail(int code, const char *fmt, ...);
                                     __FILE__, __LINE__);                                      \
     } while (0)
 
+// device vectors that cross the C ABI are read and written in 16-byte pairs
+#define MK_ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+
 // --------------------------------------------------------------------------------------
 // exchange plan (multi-GPU); empty for a single-device matrix
 // --------------------------------------------------------------------------------------

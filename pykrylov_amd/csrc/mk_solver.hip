@@ -231,6 +231,7 @@ extern "C" int mk_solver_set_transpose(mk_solver *s, const mk_csr *At) {
 
 extern "C" int mk_solver_set_precon_diag(mk_solver *s, const double *diag) {
     MK_ARG(s);
+    MK_ARG(MK_ALIGNED16(diag));
     if (diag && !s->takes_precon())
         return mk_fail(MK_ERR_UNSUPPORTED, "this solver kind has no device preconditioner hook");
     s->d_prec = diag;
@@ -267,6 +268,7 @@ extern "C" int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void
 
 extern "C" int mk_solver_set_lls_precon(mk_solver *s, const double *diag_m, const double *diag_n) {
     MK_ARG(s);
+    MK_ARG(MK_ALIGNED16(diag_m) && MK_ALIGNED16(diag_n));
     if (s->prm.kind < MK_LSQR || s->prm.kind > MK_CRAIGMR)
         return mk_fail(MK_ERR_UNSUPPORTED, "mk_solver_set_lls_precon: not a least-squares solver");
     return mk_lls_set_metric(s, diag_m, diag_n);
@@ -279,6 +281,7 @@ extern "C" int mk_solver_destroy(mk_solver *s) {
 
 extern "C" int mk_solver_setup(mk_solver *s, const double *rhs, const double *guess) {
     MK_ARG(s && rhs);
+    MK_ARG(MK_ALIGNED16(rhs) && MK_ALIGNED16(guess));        // borrowed vectors are read in 16-byte pairs
     s->q = 0;
     s->it = 0;
     s->halted = false;

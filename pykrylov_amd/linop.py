@@ -533,10 +533,22 @@ class CsrOperator(LinearOperator):
     def T(self):
         if self.symmetric:
             return self
+        if getattr(self, 'local_size', None) is not None:
+            raise NotImplementedError('the transpose of a row-partitioned operator is not available (its columns '
+                                      'are localised); transpose before partitioning')
         if self._T_cache is None:
             h = ctypes.c_void_p()
             _lib.check(self._lib.mk_csr_transpose(self._handle, ctypes.byref(h)))
-            self._T_cache = CsrOperator.from_handle(h.value, transpose_of=self)
+            t = type(self).from_handle(h.value, transpose_of=self) if isinstance(self, _ComposedCsrOperator) \
+                else CsrOperator.from_handle(h.value, transpose_of=self)
+            # (alpha A + D)^T = alpha A^T + D: the C handle carries the row program over; so must the Python object,
+            # or a further composition would not see the steps already used
+            for attr in ('_steps', '_diag_bufs'):
+                if hasattr(self, attr):
+                    setattr(t, attr, getattr(self, attr))
+            if hasattr(self, '_base'):
+                t._base = self._base.T if self._base is not self else t
+            self._T_cache = t
         return self._T_cache
 
     H = T
@@ -556,7 +568,8 @@ class CsrOperator(LinearOperator):
         for k, (code, has_scale, scale, dptr) in enumerate(steps):
             ops[k].code, ops[k].has_scale, ops[k].scale, ops[k].diag = code, has_scale, scale, dptr
         h = ctypes.c_void_p()
-        _lib.check(self._lib.mk_csr_compose(self._handle, len(steps), ops, ctypes.byref(h)))
+        if self._lib.mk_csr_compose(self._handle, len(steps), ops, ctypes.byref(h)) != 0:
+            return None                                   # (too many steps, pair operator ...): host composition
         new = _ComposedCsrOperator.from_handle(h.value, symmetric=self.symmetric)
         new._base = self                                  # keeps the arrays (and earlier diagonals) alive
         new._diag_bufs = tuple(diag_bufs)

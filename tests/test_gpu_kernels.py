@@ -287,3 +287,50 @@ def test_spmv_randomised_structures_bit_exact():
         u = rng.standard_normal(m)
         assert same(op.T * u, A.transpose().matvec(u)), (trial, m, n, kind)
         op.free()
+
+
+def test_misaligned_device_pointers_are_rejected():
+    """kernels move vectors in 16-byte pairs, so pointers that cross the C ABI must be 16-byte aligned
+    (every mk_malloc buffer is); an odd-offset view into a larger buffer is refused instead of faulting."""
+    import ctypes
+    from pykrylov_amd import _lib
+    lib = _lib.init()
+    A = csr_ref.poisson2d(12)
+    op = op_from(A, symmetric=True)
+    n = A.shape[0]
+    buf = _lib.DeviceArray(n + 2)
+    y = _lib.DeviceArray(n)
+    assert lib.mk_spmv(op.handle, buf.ptr + 8, y.ptr) != 0 and b"argument check" in lib.mk_last_error()
+    assert lib.mk_spmv(op.handle, buf.ptr, y.ptr) == 0
+    r = ctypes.c_double()
+    assert lib.mk_dot(n, buf.ptr + 8, y.ptr, ctypes.byref(r)) != 0
+    assert lib.mk_axpy(n, 1.0, buf.ptr + 8, y.ptr) != 0
+    p = _lib.MkParams()
+    p.struct_size = ctypes.sizeof(_lib.MkParams)
+    p.kind = _lib.MK_CG
+    p.matvec_max = 5
+    h = ctypes.c_void_p()
+    _lib.check(lib.mk_solver_create(op.handle, ctypes.byref(p), ctypes.byref(h)))
+    assert lib.mk_solver_setup(h, buf.ptr + 8, None) != 0
+    assert lib.mk_solver_set_precon_diag(h, buf.ptr + 8) != 0
+    assert lib.mk_solver_setup(h, buf.ptr, None) == 0
+    lib.mk_solver_destroy(h)
+
+
+def test_transpose_of_a_composed_operator_keeps_its_row_program():
+    """(alpha A - sigma I)^T carries the row program in C; the Python wrapper must carry the step count too,
+    so that a further composition beyond MK_ROWPROG_MAX falls back to a host closure instead of raising."""
+    from pykrylov_amd import CsrOperator, IdentityOperator
+    rng = np.random.default_rng(4)
+    A = csr_ref.from_coo(rng.integers(0, 300, 2000), rng.integers(0, 300, 2000), rng.standard_normal(2000), (300, 300))
+    op = op_from(A)
+    c = 2.0 * (op - 1.5 * IdentityOperator(300))                   # two steps
+    ct = c.T
+    assert isinstance(ct, CsrOperator) and len(ct._steps) == 2
+    x = rng.standard_normal(300)
+    assert np.array_equal(ct * x, 2.0 * (A.rmatvec(x) - 1.5 * x))
+    d = 0.5 * (ct + 0.25 * IdentityOperator(300))                  # four steps: still a device operator
+    assert isinstance(d, CsrOperator)
+    e = 3.0 * d                                                    # five: host closure, same result
+    assert not isinstance(e, CsrOperator)
+    assert np.array_equal(e * x, 3.0 * (0.5 * ((2.0 * (A.rmatvec(x) - 1.5 * x)) + 0.25 * x)))
