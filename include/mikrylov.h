@@ -288,6 +288,13 @@ int mk_solver_destroy(mk_solver *s);
  * transposed matrix (mk_csr_transpose) before mk_solver_setup.  rhs then has nrows(A) entries and x
  * ncols(A) (CRAIG-MR: nrows(A), craigmr.py:112). */
 int mk_solver_set_transpose(mk_solver *s, const mk_csr *At);
+/* Several GPUs: mark `A` as THIS rank's block of consecutive rows of a taller m x n operator (its columns are global
+ * and unlocalized; no mk_csr_set_exchange).  The least-squares solvers then keep every m-space vector (rhs, u, r;
+ * x of CRAIG-MR) sliced like the rows and every n-space vector (v, w, x) whole on every rank: `A * v` needs no
+ * exchange, `A.T * u` (lsqr.py:264) is the local transposed block's product summed over the ranks (one all-reduce
+ * of n doubles per iteration) and only the m-space inner products are all-reduced.  `At` is the transpose of the
+ * local block.  Needs a communicator (mk_comm_init / mk_comm_init_host); without one the flag changes nothing. */
+int mk_csr_set_row_block(mk_csr *A, int on);
 /* Diagonal (Jacobi-type) preconditioner: `diag` is a device array with nrows(A) entries holding the diagonal of
  * the operator the reference applies as `precon * r` (cg.py:91-92,137-138; bicgstab.py:96-99,120-123;
  * cgs.py:79-82,88-91; tfqmr.py:77-80; minres.py:162-163,249; symmlq.py:134,228), i.e. what a

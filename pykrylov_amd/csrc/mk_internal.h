@@ -132,6 +132,9 @@ struct mk_csr {
     double *h_cb_in = nullptr, *h_cb_out = nullptr;    // pinned staging (x_len / nrows doubles)
     double *d_cb_in = nullptr, *d_cb_out = nullptr;    // device: materialised input, product
     int *d_cb_go = nullptr;                            // device flag: the gate let this product through
+    // mk_csr_set_row_block: this matrix is one rank's block of ROWS of a taller operator whose column space is
+    // replicated on every rank (least-squares solvers: u sliced, v whole, A' u summed over the ranks)
+    bool row_block = false;
     int32_t nops = 0;              // row program (mk_csr_compose)
     mk_rowop ops[MK_ROWPROG_MAX] = {};
     // length of the vector an SpMV reads (ncols, or n_local + n_halo with a halo plan)

@@ -142,6 +142,40 @@ struct EpiV {        // Nv <- A' u - beta Nv ; v = N(Nv) ; <v, Nv>
     }
 };
 
+// Row-block partition (mk_csr_set_row_block): A' u arrives as t = sum over ranks of the local blocks' products; this
+// is EpiV's row step on it, run identically by every rank (v is replicated)
+struct OpVt {        // Nv <- t - beta Nv ; v = N(Nv) ; <v, Nv>
+    static constexpr int NACC = 1, SLOT0 = SLOT_VV;
+    const double *scal;
+    const double *t;
+    double *v;
+    const double *dn;
+    double *Nv;
+    double beta;
+    __device__ bool prologue(double *, bool) {
+        beta = scal[S_BETA];
+        return false;
+    }
+    __device__ bool skip() const { return !(beta > 0); }          // lsqr.py:258 (the gate of the fused product)
+    __device__ void one(int64_t j, double *acc) {
+        if (dn) {
+            const double w = t[j] - beta * Nv[j];                 // lsqr.py:264
+            Nv[j] = w;
+            const double vv = dn[j] * w;                          // lsqr.py:266
+            v[j] = vv;
+            acc[0] += vv * w;                                     // lsqr.py:269
+        } else {
+            const double w = t[j] - beta * v[j];                  // lsqr.py:264
+            v[j] = w;
+            acc[0] += w * w;                                      // lsqr.py:269
+        }
+    }
+    __device__ void pair(int64_t j, double *acc) {
+        one(j, acc);
+        one(j + 1, acc);
+    }
+};
+
 struct OpScaleNv {   // Nv /= alpha where the solver's G4 did v /= alpha (lsqr.py:272): only with a preconditioner N
     static constexpr int NACC = 0, SLOT0 = 0;
     const double *scal;
@@ -939,15 +973,37 @@ struct LlsSolver : mk_solver {
     const double *d_dm = nullptr, *d_dn = nullptr; // diagonals of M (m entries) and N (n entries), borrowed
     int np_A = 1, np_At = 1, np_n = 1, np_m = 1;
     int64_t itnlim = 0;
+    // several GPUs, A = this rank's row block (mk_csr_set_row_block): m-space vectors are slices, n-space vectors
+    // whole and identical on every rank
+    bool dist = false;
+    double *d_t = nullptr;                       // A' u of the local block, then its sum over the ranks
+
+    // <u, Mu> is an m-space inner product: its partial sums are added across the ranks
+    int sum_uu() { return dist ? allreduce(SLOT_UU, 1) : (int)MK_OK; }
+    // G3: v <- A' u - beta v with <v, v>
+    int product_At(bool) {
+        if (!dist) {
+            mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, d_dn, d_Nv, 0.0}, GateV{d_scal});
+            return MK_OK;
+        }
+        mk_launch_spmv_on(this, At, d_u, MkPlainEpi{d_t}, GateV{d_scal});
+        int rc = mk_comm_allreduce_sum(d_t, nn, stream);   // (a skipped product leaves old data: OpVt skips as well)
+        if (rc != MK_OK) return rc;
+        mk_launch_stream(this, OpVt{d_scal, d_t, d_v, d_dn, d_Nv, 0.0}, nn);
+        return MK_OK;
+    }
 
     explicit LlsSolver(int k) : kind(k) {}
 
     int setup(const double *rhs, const double *guess) override {
         if (guess) return mk_fail(MK_ERR_UNSUPPORTED, "the least-squares solvers start from x = 0");
         if (!At) return mk_fail(MK_ERR_STATE, "least-squares solver: call mk_solver_set_transpose first");
-        if (A->ex.mode >= 0 || At->ex.mode >= 0 || mk_comm_active())
-            return mk_fail(MK_ERR_UNSUPPORTED, "the least-squares solvers run on one GPU only: A^T u of a row-partitioned "
-                           "A needs a reduce-scatter that is not implemented");
+        if (A->ex.mode >= 0 || At->ex.mode >= 0)
+            return mk_fail(MK_ERR_UNSUPPORTED, "least-squares solvers: partition A by row blocks (mk_csr_set_row_block), "
+                           "not with a halo / all-gather exchange plan");
+        dist = A->row_block && mk_comm_active();
+        if (dist && (A->host_fn || At->host_fn))
+            return mk_fail(MK_ERR_UNSUPPORTED, "least-squares solvers: matrix-free operators are single-GPU");
         if (prm.window < 1 || prm.window > MAXWIN) return mk_fail(MK_ERR_ARG, "window must be in 1..%d", MAXWIN);
         use_hist2 = true;
         m = A->nrows;
@@ -957,6 +1013,9 @@ struct LlsSolver : mk_solver {
         np_At = mk_grid_spmv_for(At);
         np_n = mk_grid_stream(nn);
         np_m = mk_grid_stream(m);
+        // (row blocks: all-reduced slots mean the same on every rank only if all MK_MAXP entries are added; the
+        //  producers clear what their grids leave unused, MkHalt::clear_tail)
+        if (dist) np_A = np_At = np_n = np_m = MK_MAXP;
         if (!d_u) {
             int rc;
             if ((rc = alloc_vec(&d_u, m)) || (rc = alloc_vec(&d_v, nn)) ||
@@ -971,6 +1030,7 @@ struct LlsSolver : mk_solver {
         int rc2;
         if (d_dm && !d_Mu && (rc2 = alloc_vec(&d_Mu, m))) return rc2;
         if (d_dn && !d_Nv && (rc2 = alloc_vec(&d_Nv, nn))) return rc2;
+        if (dist && !d_t && (rc2 = alloc_vec(&d_t, nn))) return rc2;
         if (d_Nv) MK_HIP(hipMemsetAsync(d_Nv, 0, sizeof(double) * (size_t)nn, stream));
         if (d_dm) {
             mk_launch_stream(this, MkOpCopy{rhs, d_Mu}, m);                            // Mu = rhs.copy()   lsqr.py:188
@@ -980,9 +1040,10 @@ struct LlsSolver : mk_solver {
             mk_launch_stream(this, MkOpCopy{rhs, d_u}, m);                             // Mu = rhs.copy()   lsqr.py:188
             mk_launch_stream(this, MkOpDot<SLOT_UU>{d_u, d_u}, m);                     // lsqr.py:195
         }
+        if ((rc2 = sum_uu()) != MK_OK) return rc2;
         mk_launch_stream(this, OpNormU{d_part, np_m, d_scal, d_u, d_dm ? d_Mu : nullptr, 0.0}, m);   // lsqr.py:197-198
         // Nv = A' u (Nv is zero: the epilogue's "- beta Nv" term vanishes exactly)     lsqr.py:200
-        mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, d_dn, d_Nv, 0.0}, GateV{d_scal});
+        if ((rc2 = product_At(true)) != MK_OK) return rc2;
         hipLaunchKernelGGL(lls_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_At, d_scal, d_status,
                            next_halt(), kind, itnlim);
         mk_launch_stream(this, OpInitN{d_scal, kind, d_v, d_a, d_b, d_x, 0, 0, 0, 0}, nn);
@@ -1007,8 +1068,10 @@ struct LlsSolver : mk_solver {
                                          prm.conlim > 0 ? 1.0 / prm.conlim : 0.0});
         else
             mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0}, craig::CountGate{d_status, it, itnlim});
+        int rc = sum_uu();
+        if (rc != MK_OK) return rc;
         mk_launch_stream(this, OpNormU{d_part, np_A, d_scal, d_u, d_dm ? d_Mu : nullptr, 0.0}, m);       // G2
-        mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, d_dn, d_Nv, 0.0}, GateV{d_scal});             // G3
+        if ((rc = product_At(false)) != MK_OK) return rc;                                                // G3
         if (kind == MK_LSQR) {
             mk_launch_stream(this, lsqr::OpN{d_part, np_At, d_scal, d_status, d_hist, par, itn, prm.window, prm.damp,
                                              prm.atol, prm.btol, prm.etol, d_v, d_a, d_x, 0, 0, 0, 0, false}, nn);

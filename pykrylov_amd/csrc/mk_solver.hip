@@ -7,7 +7,8 @@ int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
     n = A->ex.mode >= 0 ? A->ex.n_local : A->nrows;
     const bool rectangular_ok = prm.kind >= MK_LSQR;
     if (rectangular_ok && A->ex.mode >= 0)
-        return mk_fail(MK_ERR_UNSUPPORTED, "the least-squares solvers are single-GPU in this version");
+        return mk_fail(MK_ERR_UNSUPPORTED, "the least-squares solvers partition by row blocks with a replicated column "
+                       "space (mk_csr_set_row_block), not with a halo / all-gather exchange plan");
     if (!rectangular_ok && A->ex.mode < 0 && A->nrows != A->ncols)
         return mk_fail(MK_ERR_ARG, "solver needs a square operator, got %lld x %lld", (long long)A->nrows,
                        (long long)A->ncols);
@@ -226,6 +227,14 @@ extern "C" int mk_solver_set_transpose(mk_solver *s, const mk_csr *At) {
     MK_ARG(s && At);
     MK_ARG(At->nrows == s->A->ncols && At->ncols == s->A->nrows && At->nnz == s->A->nnz);
     s->At = At;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_set_row_block(mk_csr *A, int on) {
+    MK_ARG(A != nullptr);
+    if (on && A->ex.mode >= 0)
+        return mk_fail(MK_ERR_STATE, "mk_csr_set_row_block: the matrix already carries a halo / all-gather exchange plan");
+    A->row_block = on != 0;
     return MK_OK;
 }
 

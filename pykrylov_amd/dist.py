@@ -253,6 +253,23 @@ def partition_host_csr(world, indptr, indices, data, n, mode="halo"):
                            p["send_idx"]), p["ranges"]
 
 
+def partition_row_blocks(world, indptr, indices, data, shape):
+    """Row blocks of a (replicated) host m x n CSR matrix for the least-squares solvers (lls/): this rank keeps rows
+    ``ranges[rank]`` with their GLOBAL columns.  m-space vectors (rhs, u, r; x of CRAIG-MR) are sliced like the rows,
+    n-space vectors (v, w, x) are whole and identical on every rank: ``A * v`` needs no exchange, ``A.T * u``
+    (lsqr.py:264) is the local transposed block's product summed over the ranks (`mk_csr_set_row_block`)."""
+    from .linop import CsrOperator
+    from .sparse import csr_row_slice
+    m, n = int(shape[0]), int(shape[1])
+    ranges = row_ranges(m, world.nranks)
+    r0, r1 = ranges[world.rank]
+    lp, li, ld = csr_row_slice(indptr, indices, data, r0, r1)
+    op = CsrOperator(lp, li, ld, (r1 - r0, n))
+    _lib.check(_lib.init().mk_csr_set_row_block(op.handle, 1))
+    op.row_range, op.global_shape = (r0, r1), (m, n)
+    return op, ranges
+
+
 def partition_poisson3d(world, nx, ny, nz, mode="halo"):
     """7-point Poisson matrix on an nx x ny x nz grid, slab-partitioned in z, generated per rank in
     HBM (BASELINE config 5: 512^3 never exists on the host)."""

@@ -175,7 +175,7 @@ class LSMRFramework(_LlsBase):
 
     def solve(self, b, damp=0.0, atol=1e-9, btol=1e-9, conlim=1e8, M=None, N=None, itnlim=None, show=False,
               **kwargs):
-        m, n = self.A.shape
+        m, n = getattr(self.A, 'global_shape', self.A.shape)    # (row blocks on several GPUs: the same limit everywhere)
         if itnlim is None:
             itnlim = min([m, n])
         res, x, _, itn = self._run(b, itnlim, damp, atol, btol, conlim, M, N, kwargs)
@@ -228,7 +228,7 @@ class CRAIGMRFramework(_LlsBase):
 
     def solve(self, b, damp=0.0, atol=1e-9, btol=1e-9, conlim=1e8, M=None, N=None, itnlim=None, show=False,
               **kwargs):
-        m, n = self.A.shape
+        m, n = getattr(self.A, 'global_shape', self.A.shape)
         if itnlim is None:
             itnlim = min([m, n])
         res, x, _, itn = self._run(b, itnlim, damp, atol, btol, conlim, M, N, kwargs, x_rows=True)

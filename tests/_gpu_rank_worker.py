@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: F401,E402  (before libmikrylov: DESIGN.md section 5)
 import torch.distributed as td  # noqa: E402
 
-from oracle import csr_ref, krylov_ref as kr  # noqa: E402
+from oracle import csr_ref, krylov_ref as kr, lls_ref  # noqa: E402
 from pykrylov_amd import _lib, dist  # noqa: E402
 
 
@@ -157,6 +157,57 @@ def main():
     s.solve(rhs_d[c0:c1], check_curvature=False)
     counts = world.allgather_object(int(s.nMatvec))
     assert len(set(counts)) == 1 and 600 < counts[0] <= 2 * 1001, counts
+    op.free()
+
+    # ---- least-squares solvers on row blocks (mk_csr_set_row_block): m-space vectors sliced, n-space vectors whole
+    # on every rank, A' u summed over the ranks.  Compared with the reference's own golden runs of the 2000 x 1500
+    # problem (the same tolerances as the single-GPU test against them, tests/test_gpu_lls.py).
+    from pykrylov_amd import lls
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lls_random.npz"), allow_pickle=False)
+    L = csr_ref.RefCsr(g["l_A_indptr"], g["l_A_indices"], g["l_A_data"], g["l_A_shape"])
+    mL, nL = L.shape
+    for solver, btag, kw in (("lsqr", "ls", dict(damp=0.0)), ("lsqr", "cons", dict(damp=0.1)),
+                             ("lsmr", "ls", dict(damp=0.0)), ("craig", "cons", {}), ("craigmr", "cons", {})):
+        op, ranges = dist.partition_row_blocks(world, L.indptr, L.indices, L.data, L.shape)
+        r0, r1 = ranges[rank]
+        assert op.shape == (r1 - r0, nL) and op.global_shape == (mL, nL)
+        b = g["l_b_" + btag]
+        key = "l_%s_%s_d%g_e%g_" % (solver, btag, kw.get("damp", 0.0), 1e-6)
+        cls = dict(lsqr=lls.LSQRFramework, lsmr=lls.LSMRFramework, craig=lls.CRAIGFramework,
+                   craigmr=lls.CRAIGMRFramework)[solver]
+        s = cls(op)
+        ret = s.solve(b[r0:r1], etol=1e-6, **kw)
+        if solver == "lsmr":                                # (returns its results, lsmr.py:492)
+            s.istop, s.itn = ret[1], ret[2]
+        x = np.asarray(s.x)
+        if solver == "craigmr":                             # x has nargout entries (craigmr.py:112): sliced like rows
+            x = gather_x(world, x)
+        else:                                               # whole on every rank, and the same bits everywhere
+            xs = world.allgather_object(x)
+            assert all(np.array_equal(xs[0], xr) for xr in xs), solver
+        xref = g[key + "x"]
+        itn = int(s.itn)
+        itns = world.allgather_object(itn)
+        assert len(set(itns)) == 1, itns
+        ent = dict(itn=itn, ref=int(g[key + "itn"]), istop=int(s.istop),
+                   x_err=float(np.linalg.norm(x - xref) / np.linalg.norm(xref)))
+        if solver == "craig":
+            r = gather_x(world, s.r)                        # (the golden run kept no r: the oracle's)
+            rref = lls_ref.craig(L.matvec, L.transpose().matvec, L.shape, b.copy(), etol=1e-6)["r"]
+            ent["r_err"] = float(np.linalg.norm(r - rref) / np.linalg.norm(b))
+        out["lls_%s_%s" % (solver, btag)] = ent
+        op.free()
+    # diagonal preconditioners: M sliced like the rows, N whole
+    dm = 1.0 + 0.5 * np.cos(np.arange(mL))
+    dn = 1.0 + 0.25 * np.sin(np.arange(nL))
+    op, ranges = dist.partition_row_blocks(world, L.indptr, L.indices, L.data, L.shape)
+    r0, r1 = ranges[rank]
+    s = lls.LSQRFramework(op)
+    s.solve(g["l_b_ls"][r0:r1], M=DiagonalOperator(dm[r0:r1]), N=DiagonalOperator(dn), etol=0.0)
+    Lt = L.transpose()
+    ref = lls_ref.lsqr(L.matvec, Lt.matvec, L.shape, g["l_b_ls"].copy(), etol=0.0, M=lambda v: dm * v, N=lambda v: dn * v)
+    out["lls_lsqr_precon"] = dict(itn=int(s.itn), ref=int(ref["itn"]), istop=int(s.istop),
+                                  x_err=float(np.linalg.norm(s.x - ref["x"]) / np.linalg.norm(ref["x"])))
     op.free()
 
     _lib.load().mk_comm_destroy()

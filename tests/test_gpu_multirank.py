@@ -32,6 +32,13 @@ def test_partitioned_solvers_on_one_gpu(nranks):
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     out = json.loads(line[len("RESULT "):])
     assert len(out) >= 10, sorted(out)
+    lls_keys = [k for k in out if k.startswith("lls_")]
+    assert len(lls_keys) == 6, lls_keys
+    for k in lls_keys:
+        # (the tolerances of the single-GPU runs against the same golden traces, tests/test_gpu_lls.py)
+        r = out.pop(k)
+        assert abs(r["itn"] - r["ref"]) <= 1 and r["istop"] > 0 and r["x_err"] <= 1e-5, (k, r)
+        assert r.get("r_err", 0.0) <= 1e-5, (k, r)
     for key, r in out.items():
         # partitioning changes the summation order of the dots (per-rank partials), nothing else: same counts on
         # these well-conditioned problems, 1e-12 on histories and iterates
