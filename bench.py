@@ -44,7 +44,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s per GPU
 METRIC = "Krylov iters/sec + SpMV achieved HBM GB/s (% of peak), fp64"
 FMT_NAMES = {0: "csr (int32 columns + fp64 values, x gathered)",
              1: "windowed tiles (x windows in LDS, uint16 slots + fp64 values)",
-             2: "windowed tiles + value dictionary (one packed 32-bit word per nonzero: LDS slot + value code)"}
+             2: "windowed tiles + value dictionary (one packed 32-bit word per nonzero: LDS slot + value code)",
+             3: "csr, tile resident in LDS, gathers ordered by column block (x longer than an L2)"}
 
 
 def spmv_bytes(nrows, ncols, nnz):
@@ -184,7 +185,8 @@ def format_info(lib, op):
     grid, tmap = ctypes.c_int32(), ctypes.c_int32()
     _lib.check(lib.mk_csr_launch_info(op.handle, ctypes.byref(grid), ctypes.byref(tmap)))
     return {"format": fmt.value, "format_name": FMT_NAMES[fmt.value], "tiles_windowed": tiles.value,
-            "lds_window_chunks": chunks.value, "dictionary_size": nd.value,
+            "lds_window_chunks": chunks.value if fmt.value != 3 else 0,
+            "column_phases": chunks.value if fmt.value == 3 else 0, "dictionary_size": nd.value,
             "matrix_bytes_per_product": mbytes.value, "grid": grid.value, "tile_order": tmap.value}
 
 

@@ -37,7 +37,8 @@ struct MkCsrView {
     int poff;
     int part;
     // windowed tile format (mk_format.hip); fmt 0: none of this is read
-    int fmt;                 // 0 plain CSR (gathers), 1 windows + uint16 LDS slots, 2 windows + slots + value dictionary
+    int fmt;                 // 0 plain CSR (gathers), 1 windows + uint16 LDS slots, 2 windows + slots + value dictionary,
+                             // 3 plain CSR with the tile resident in LDS and the gathers ordered by column block
     int wchunks;             // LDS chunks (128 doubles each) reserved for the x windows of a tile
     int ndict;
     const uint16_t *slots;   // per nonzero: position of its x entry in the tile's LDS window buffer
@@ -45,7 +46,9 @@ struct MkCsrView {
     const uint32_t *wn;      // per tile and wave: half lengths of those chunks, one byte each
     const uint32_t *pk;      // fmt 2, per nonzero: {LDS slot : 16 | index of its value in `dict` : 8}
     const double *dict;
-    // column-blocked products (fmt 0): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
+    // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
+    int rt_cap, rt_k, rt_w;
+    // column-blocked products (fmt 0, 3): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
     const double *sum_in;
     // matrix-free operators (host callback): cb_mode 1 = materialise the product's input vector (`vin[j] = xin(x[j])`,
     // `xlen` entries) and report the gate's decision in *cb_go; 2 = the row sums are the entries of `y_ext`
@@ -84,6 +87,11 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
     if (getenv("MK_GRID_SPMV") || A->host_fn) return g;
     const MkPlan *P = mk_csr_plan(A);
     int64_t cap = mk_cap_spmv();
+    if (P && P->fmt == 3) {                                  // as many as fit at once with one tile in LDS each
+        int g3 = (int)(A->ntiles > MK_MAXP ? MK_MAXP : A->ntiles);
+        if (g3 >= 8) g3 -= g3 % 8;
+        return g3;
+    }
     if (P && P->fmt == 2) cap = mk_xcd_chunks(A) ? 1280 : 1024;
     else if (P && P->fmt == 1) cap = 1024;
     else if (mk_xcd_chunks(A)) cap = 2 * cap > MK_MAXP ? MK_MAXP : 2 * cap;
@@ -117,7 +125,11 @@ static inline MkCsrView mk_view(const mk_csr *A) {
     v.part = 0;
     const MkPlan *P = mk_csr_plan(A);
     v.fmt = P ? P->fmt : 0;
-    if (v.fmt) {
+    if (v.fmt == 3) {
+        v.rt_cap = P->rt_cap;
+        v.rt_k = P->rt_k;
+        v.rt_w = P->rt_w;
+    } else if (v.fmt) {
         v.wchunks = P->wchunks;
         v.ndict = P->ndict;
         v.slots = P->d_slots;
@@ -381,6 +393,73 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             if (r < rend) epi.row(r, sum, acc);
             cur = nxt;
         }
+    } else if constexpr (FMT == 3) {
+        // ---- resident tiles with column phases: for matrices whose x is too long for an XCD's L2 and whose columns no
+        // window covers (BASELINE config 3).  The tile's (column, value) stream goes to LDS once (global_load_lds);
+        // then lane t walks row t with a cursor, left to right as everywhere, but in rt_k PHASES: phase k takes the
+        // row's entries whose column lies in block k (columns ascend within a row, so a phase is a contiguous run).
+        // All workgroups of the grid are resident and start their tiles together, so at any moment the whole chip
+        // gathers from ONE slice of x that an L2 holds, instead of pulling a 64-byte sector through the fabric per
+        // nonzero (rocprof on the gather path: 371 MB of fabric reads for 80 MB of algorithmic bytes; the raw cost of
+        // 5 M scattered 8-byte gathers from 8 MB alone is 40 us, tools/ubench/spmv_cb.hip).  No barrier and no
+        // global load other than the gathers inside the phases.
+        const int lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int cap = A.rt_cap;
+        double *lv = prod;                                   // [cap] values, then [cap] columns
+        int *lc = reinterpret_cast<int *>(prod + cap);
+        for (; pos < end; pos += stride) {
+            const int64_t tile = mk_tile_at(A, pos);
+            const int64_t r0 = tile * MK_ROWS_PER_TILE;
+            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
+            const int64_t r = r0 + tid;
+            const int p_lo = mk_sload(A.indptr + r0), p_hi = mk_sload(A.indptr + rend);
+            const int base = p_lo & ~3, cnt = p_hi - base;   // cnt <= cap (builder)
+            const int last = (cnt > 0) ? ((cnt - 1) & ~3) : 0;
+            for (int c0 = wv * 256; c0 < cnt; c0 += 4 * 256) {                  // 256 columns per wave-level copy
+                int j = c0 + 4 * lane;
+                j = j < last ? j : last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.indices + base + j),
+                                                 (__attribute__((address_space(3))) void *)(lc + c0), 16, 0, 0);
+            }
+            const int lastv = (cnt > 0) ? ((cnt - 1) & ~1) : 0;
+            for (int c0 = wv * 128; c0 < cnt; c0 += 4 * 128) {                  // 128 values per wave-level copy
+                int j = c0 + 2 * lane;
+                j = j < lastv ? j : lastv;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.data + base + j),
+                                                 (__attribute__((address_space(3))) void *)(lv + c0), 16, 0, 0);
+            }
+            int cur = 0, fin = 0;
+            if (r < rend) {
+                cur = A.indptr[r] - base;
+                fin = A.indptr[r + 1] - base;
+            }
+            if constexpr (MkHasPre<Epi>::value) {
+                if (r < rend) epi.pre(r);
+            }
+            double sum = (A.sum_in && r < rend) ? A.sum_in[r] : 0.0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int k = 0; k < A.rt_k; ++k) {
+                const int c1 = (k + 1 < A.rt_k) ? (k + 1) * A.rt_w : 0x7fffffff;
+                for (;;) {
+                    int ca = 0x7fffffff;
+                    if (cur < fin) ca = lc[cur];
+                    const bool oa = ca < c1;
+                    if (oa) {
+                        const double xa = x[ca];
+                        sum += lv[cur] * epi.xin(xa);
+                        cur += 1;
+                    }
+                    if (!__any(oa)) break;                   // (wave level: no lane of this wave has more in phase k)
+                }
+            }
+            if constexpr (PROG) {
+                if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
+            }
+            if (r < rend) epi.row(r, sum, acc);
+            __syncthreads();                                 // the next tile's copies overwrite this LDS
+        }
     } else if constexpr (FMT == 2) {
         // ---- windowed tiles with a value dictionary: ROW PHASE ONLY.  One 32-bit word per nonzero {slot | code};
         // the words and the x windows of a tile go straight to LDS with global_load_lds (no VGPR round trip, no
@@ -624,7 +703,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, FMT == 0 ? 8 : 4) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : 4) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
@@ -687,7 +766,11 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         const size_t w = sizeof(double) * (size_t)(128 * v.wchunks + 2) + sizeof(uint32_t) * (MK_SPMV_TILE + 16);
         lds = w > lds ? w : lds;
     }
-    if (v.fmt == 2)
+    if (v.fmt == 3) {                                        // the tile's values and columns
+        lds = (size_t)v.rt_cap * 12;
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 3>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                           halt, partials);
+    } else if (v.fmt == 2)
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 2>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                            halt, partials);
     else if (v.fmt == 1)

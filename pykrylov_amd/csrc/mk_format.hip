@@ -275,7 +275,7 @@ int default_format() {
     static int f = [] {
         const char *e = getenv("MK_SPMV_FORMAT");
         int v = e ? atoi(e) : 2;
-        return v < 0 ? 0 : (v > 2 ? 2 : v);
+        return v < 0 ? 0 : (v > 3 ? 3 : v);
     }();
     return f;
 }
@@ -344,22 +344,70 @@ int cblocks_build(const mk_csr *A) {
 }
 
 // build the plan of an owning (non-alias) matrix; on any failure the matrix stays on the plain CSR path
+// longest tile stream (nonzeros of 256 rows, counted from the 4-aligned start the kernels copy from)
+__global__ __launch_bounds__(MK_BLOCK) void tile_extent_kernel(const int32_t *__restrict__ indptr, int64_t nrows,
+                                                               int64_t ntiles, int *__restrict__ out) {
+    int mx = 0;
+    for (int64_t t = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; t < ntiles; t += (int64_t)gridDim.x * MK_BLOCK) {
+        const int64_t r0 = t * MK_ROWS_PER_TILE;
+        const int64_t r1 = (r0 + MK_ROWS_PER_TILE < nrows) ? r0 + MK_ROWS_PER_TILE : nrows;
+        const int len = indptr[r1] - (indptr[r0] & ~3);
+        mx = len > mx ? len : mx;
+    }
+    atomicMax(out, mx);
+}
+
+// fmt 3: a matrix that stays on plain CSR, whose x is too long for an XCD's L2 (4 MiB) and whose tiles fit LDS eight
+// to a CU: resident tiles, gathers ordered by column block (mk_device.h).  Slices of <= 1.5 MiB: measured best on
+// 1e6 x 5 random (BiCGSTAB's fused product: K = 4 / 6 / 8 -> 38.8 / 37.9 / 38.7 us, 50.6 us with one phase, 53 us on
+// the gather path; tools/ubench/spmv_cb.hip has the kernel variants that were tried).
+constexpr int64_t RT_SLICE_BYTES = 3 << 19;
+constexpr int RT_CAP_MAX = 2560;                             // 30 KB of LDS per workgroup
+int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
+    const int64_t xbytes = 8 * A->x_len();
+    if (!forced && (xbytes <= 3 * (1 << 20) || getenv("MK_NO_RESIDENT"))) return MK_OK;
+    if (A->ex.mode >= 0 && !forced) return MK_OK;            // (partitioned matrices: their x slices are short already)
+    hipStream_t st = mk_ctx().stream;
+    int *d_max = nullptr, h_max = 0;
+    if (hipMalloc((void **)&d_max, sizeof(int)) != hipSuccess) return MK_OK;
+    hipMemsetAsync(d_max, 0, sizeof(int), st);
+    int grid = (int)((A->ntiles + MK_BLOCK - 1) / MK_BLOCK);
+    grid = grid > 1024 ? 1024 : grid;
+    hipLaunchKernelGGL(tile_extent_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, A->d_indptr, A->nrows, A->ntiles, d_max);
+    const bool ok = hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                    hipStreamSynchronize(st) == hipSuccess;
+    hipFree(d_max);
+    if (!ok || h_max < 1) return MK_OK;
+    const int cap = (h_max + 255) / 256 * 256;
+    if (cap > RT_CAP_MAX) return MK_OK;                      // long rows: the chunked gather path
+    int64_t k = (xbytes + RT_SLICE_BYTES - 1) / RT_SLICE_BYTES;
+    static const char *env = getenv("MK_RT_PHASES");
+    if (env && atoi(env) > 0) k = atoi(env);
+    k = k < 1 ? 1 : (k > 64 ? 64 : k);
+    P.fmt = 3;
+    P.rt_cap = cap;
+    P.rt_k = (int)k;
+    P.rt_w = (int)((A->x_len() + k - 1) / k);
+    return MK_OK;
+}
+
 int plan_build(const mk_csr *A) {
     MkPlan &P = A->plan;
     P.built = true;
     P.fmt = 0;
     const int want = A->want_fmt >= 0 ? A->want_fmt : default_format();
     if (A->nnz == 0 || A->ntiles == 0 || !mk_ctx().ready || A->host_fn || A->comp_kind) return MK_OK;
-    auto plain = [&]() {                                     // plain CSR: column blocks if x is too long for an L2
-        if (cblocks_build(A) != MK_OK) {
+    auto plain = [&]() -> int {                              // plain CSR: x too long for an L2?
+        if (cblocks_build(A) != MK_OK) {                     // (separate launches per column block: off by default)
             for (mk_csr *B : P.cblocks) mk_csr_destroy(B);
             P.cblocks.clear();
             hipFree(P.d_cbsum);
             P.d_cbsum = nullptr;
         }
+        if (P.cblocks.empty() && want != 0) return resident_plan(A, P, want == 3);
         return MK_OK;
     };
-    if (want == 0) return plain();
+    if (want == 0 || want == 3) return plain();
     hipStream_t st = mk_ctx().stream;
     const size_t pad = (size_t)A->nnz + MK_CSR_PAD;
     int *d_stats = nullptr;
@@ -447,7 +495,7 @@ void mk_csr_plan_reset(const mk_csr *A) {
 
 extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {
     MK_REQUIRE_INIT();
-    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 2);
+    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 3);
     if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_format: set the format on the matrix a composed operator was built from");
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
@@ -461,14 +509,14 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
     if (fmt) *fmt = P->fmt;
-    if (tiles_windowed) *tiles_windowed = P->fmt ? P->covered : 0;
-    if (lds_chunks) *lds_chunks = P->fmt ? P->wchunks : 0;
+    if (tiles_windowed) *tiles_windowed = (P->fmt == 1 || P->fmt == 2) ? P->covered : 0;
+    if (lds_chunks) *lds_chunks = (P->fmt == 1 || P->fmt == 2) ? P->wchunks : (P->fmt == 3 ? P->rt_k : 0);
     if (dict_size) *dict_size = P->ndict;
     if (matrix_bytes_per_product) {
         // bytes of matrix data one product streams from HBM (x and y not included): per nonzero 4 + 8 (CSR),
         // 2 + 8 (windows) or 4 (windows + dictionary: one packed word), plus row pointers and the window descriptors
         int64_t b = 4 * (A->nrows + 1);
-        if (P->fmt == 0) b += 12 * A->nnz;
+        if (P->fmt == 0 || P->fmt == 3) b += 12 * A->nnz + (P->fmt == 3 ? 4 * A->nrows : 0);   // (fmt 3 reads every row pointer twice)
         else {
             // nonzeros of windowed tiles are not kept; the mixed case is bounded by the covered share
             const double share = A->ntiles ? (double)P->covered / (double)A->ntiles : 0.0;

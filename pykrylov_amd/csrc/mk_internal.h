@@ -94,7 +94,8 @@ constexpr int MK_WCHUNK = 128;     // doubles per window chunk (one wave-level 1
 constexpr int MK_WCHUNKS_MAX = 16; // chunks per tile (4 per wave): 16 KiB of LDS windows at most
 struct MkPlan {
     bool built = false;
-    int fmt = 0;                   // 0 plain CSR, 1 windows + uint16 slots, 2 windows + slots + value dictionary
+    int fmt = 0;                   // 0 plain CSR, 1 windows + uint16 slots, 2 windows + slots + value dictionary,
+                                   // 3 plain CSR, tile resident in LDS, gathers ordered by column block
     int wchunks = 0;               // max chunks of a tile
     int ndict = 0;
     int64_t covered = 0;           // tiles on the windowed path
@@ -103,6 +104,10 @@ struct MkPlan {
     uint32_t *d_wn = nullptr;
     uint32_t *d_pk = nullptr;      // fmt 2: {slot | code << 16} per nonzero
     double *d_dict = nullptr;
+    // fmt 3 (resident tiles, column phases): plain CSR arrays, only launch parameters
+    int rt_cap = 0;                // LDS capacity per tile in nonzeros (max tile stream length rounded up to 256)
+    int rt_k = 1;                  // column phases
+    int rt_w = 0;                  // columns per phase
     // column blocks (plain-CSR matrices whose x does not fit an XCD's L2): A = [A_0 | A_1 | ...] by column range,
     // each block a CSR matrix over all rows; a product runs block after block with the running row sums carried
     std::vector<struct mk_csr *> cblocks;

@@ -1,5 +1,5 @@
-"""The storage formats of the SpMV (csrc/mk_format.hip, mk_device.h): plain CSR gathers (0), windowed tiles (1) and
-windowed tiles + value dictionary (2).  Whatever format a tile ends up in, the product must be BIT-identical to the
+"""The storage formats of the SpMV (csrc/mk_format.hip, mk_device.h): plain CSR gathers (0), windowed tiles (1),
+windowed tiles + value dictionary (2), LDS-resident tiles with column phases (3).  Whatever format a tile ends up in, the product must be BIT-identical to the
 scalar left-to-right CSR loop of the oracle -- including matrices that mix eligible and ineligible tiles, so that
 both code paths run inside one launch and hand over to each other."""
 import ctypes
@@ -102,6 +102,49 @@ def test_spmv_bit_exact_in_every_format(name, fmt):
     op.free()
 
 
+@pytest.mark.parametrize("name", sorted(MATS))
+def test_resident_tile_format_bit_exact(name):
+    """Format 3 (tile resident in LDS, gathers ordered by column block) is meant for long x vectors; forced here on
+    small matrices, with several phase counts, it must still give the scalar loop's bits.  Tiles longer than the
+    LDS budget (the dense rows) keep the matrix on the chunked gather path."""
+    A, _ = MATS[name]
+    op = op_with_format(A, 3)
+    info = fmt_info(op)
+    ip = np.asarray(A.indptr, dtype=np.int64)
+    starts = np.arange(0, A.shape[0], 256)
+    ends = np.minimum(starts + 256, A.shape[0])
+    longest = int(np.max(ip[ends] - (ip[starts] & ~3)))          # tile streams as the kernel copies them
+    assert info["fmt"] == (3 if longest <= 2560 else 0), (name, info, longest)
+    assert (name in ("banded_plus_dense_rows", "banded_plus_scattered_block")) == (longest > 2560)
+    rng = np.random.default_rng(3)
+    for x in (np.ones(A.shape[1]), rng.standard_normal(A.shape[1]), 1e200 * rng.standard_normal(A.shape[1])):
+        assert np.array_equal(op * x, A.matvec(x))
+    assert np.array_equal(op_with_format(A.transpose(), 3) * np.ones(A.shape[0]), A.rmatvec(np.ones(A.shape[0])))
+    op.free()
+
+
+@pytest.mark.parametrize("phases", ["1", "3", "7", "64"])
+def test_resident_tile_phase_counts(phases, monkeypatch):
+    """The phase count only reorders WHEN a row's entries are gathered, never the order they are added in."""
+    import subprocess, sys, os
+    code = ("import numpy as np, ctypes\n"
+            "from oracle import csr_ref\n"
+            "from pykrylov_amd import CsrOperator, _lib\n"
+            "A = csr_ref.random_diagdom(20011, seed=2)\n"
+            "op = CsrOperator(A.indptr, A.indices, A.data, A.shape)\n"
+            "_lib.check(_lib.init().mk_csr_set_format(op.handle, 3))\n"
+            "x = np.random.default_rng(1).standard_normal(20011)\n"
+            "assert np.array_equal(op * x, A.matvec(x))\n"
+            "f, k = ctypes.c_int32(), ctypes.c_int32()\n"
+            "_lib.check(_lib.load().mk_csr_format_info(op.handle, ctypes.byref(f), None, ctypes.byref(k), None, None))\n"
+            "print('FMT', f.value, k.value)\n")
+    env = dict(os.environ, MK_RT_PHASES=phases)              # (read once per process)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "FMT 3 %s" % phases in p.stdout, p.stdout
+
+
 def test_mixed_tiles_really_mix():
     A, _ = MATS["banded_plus_dense_rows"]
     op = op_with_format(A, 1)
@@ -167,7 +210,11 @@ def test_column_blocked_product_is_bit_exact(big_random):
     A = big_random
     n = A.shape[0]
     op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
-    assert fmt_info(op)["fmt"] == 0 and colblocks(op) == 0           # off by default
+    info = fmt_info(op)                                            # x = 5.6 MB: resident tiles, 4 column phases
+    assert info["fmt"] == 3 and info["chunks"] == 4 and colblocks(op) == 0
+    rng = np.random.default_rng(8)
+    for x in (np.ones(n), rng.standard_normal(n)):
+        assert np.array_equal(op * x, A.matvec(x))
     blocked(op)
     assert fmt_info(op)["fmt"] == 0 and colblocks(op) == 3
     rng = np.random.default_rng(8)
@@ -183,15 +230,20 @@ def test_column_blocked_product_is_bit_exact(big_random):
     op.free()
 
 
+@pytest.mark.parametrize("how", ["resident", "blocked"])
 @pytest.mark.parametrize("solver", ["bicgstab", "cgs", "tfqmr"])
-def test_column_blocked_solvers_bit_exact(big_random, solver):
-    """Fused epilogues and gates across the block launches: same bits as the oracle in the device's dot order."""
+def test_column_blocked_solvers_bit_exact(big_random, solver, how):
+    """Fused epilogues and gates with the column phases inside one launch (format 3, the default for this matrix) and
+    across the block launches: same bits as the oracle in the device's dot order."""
     import pykrylov_amd
     from pykrylov_amd import CsrOperator
     from oracle import gpu_order, krylov_ref as kr
     A = big_random
     n = A.shape[0]
-    op = blocked(CsrOperator(A.indptr, A.indices, A.data, A.shape))
+    op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
+    if how == "blocked":
+        blocked(op)
+    assert fmt_info(op)["fmt"] == (3 if how == "resident" else 0)
     rhs = A.matvec(np.ones(n))
     cls = {"bicgstab": pykrylov_amd.BiCGSTAB, "cgs": pykrylov_amd.CGS, "tfqmr": pykrylov_amd.TFQMR}[solver]
     s = cls(op, reltol=1e-9)
@@ -214,15 +266,21 @@ def test_column_blocked_minres_scaled_gather(big_random, monkeypatch):
     rows = np.repeat(np.arange(n), np.diff(R.indptr))
     S = csr_ref.from_coo(np.concatenate([rows, R.indices]), np.concatenate([R.indices, rows]),
                          np.concatenate([R.data, R.data]), (n, n))                    # R + R^T: symmetric, scattered
-    op = blocked(CsrOperator(S.indptr, S.indices, S.data, S.shape, symmetric=True))
-    assert colblocks(op) == 3
+    op = CsrOperator(S.indptr, S.indices, S.data, S.shape, symmetric=True)
     rhs = S.matvec(np.ones(n))
-    s = Minres(op)
-    s.solve(rhs, show=False, check=False, etol=0.0, rtol=1e-12, itnlim=25)
-    ref = kr.minres(S, rhs, check=False, etol=0.0, rtol=1e-12, itnlim=25,
-                    red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["minres"], gpu_order.launch_geometry(op))))
-    assert (s.istop, s.itn) == (ref["istop"], ref["itn"])
-    assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
+    for how in ("resident", "blocked"):
+        if how == "blocked":
+            blocked(op)
+            assert colblocks(op) == 3
+        else:
+            assert fmt_info(op)["fmt"] == 3
+        s = Minres(op)
+        s.solve(rhs, show=False, check=False, etol=0.0, rtol=1e-12, itnlim=25)
+        geo = gpu_order.launch_geometry(op)
+        ref = kr.minres(S, rhs, check=False, etol=0.0, rtol=1e-12, itnlim=25,
+                        red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["minres"], geo)))
+        assert (s.istop, s.itn) == (ref["istop"], ref["itn"]), how
+        assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"]), how
     op.free()
 
 

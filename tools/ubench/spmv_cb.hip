@@ -1,0 +1,344 @@
+// spmv_cb -- micro-benchmark: column-blocked tiles for matrices whose x does not fit an XCD's L2 (BASELINE config 3:
+// 1M rows, diagonal + 4 random columns per row, x = 8 MB against 4 MiB of L2 per XCD).
+//
+// Today's gather kernel pulls one 64-byte sector through the fabric per nonzero (rocprof: 371 MB of fabric reads for
+// 80 MB of algorithmic bytes).  Here every 256-row tile stores its nonzeros grouped by column block (K blocks of
+// n/K columns), and all workgroups walk the blocks in the same order with their row sums in registers, so at any time
+// the whole chip gathers from ONE slice of x that fits L2.  Row sums still run left to right (columns are sorted, the
+// blocks ascend): same bits as plain CSR.
+//   lane : one row per lane, no LDS, no barriers
+//   lds  : nonzeros loaded coalesced, products to LDS, row sums from LDS (two barriers per tile-block)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); exit(1);} } while (0)
+constexpr int BLOCK = 256, ROWS = 256, PCAP = 4096;
+
+template <int TW>
+__global__ __launch_bounds__(BLOCK) void cb_lane(int T, int K, int n, const int* __restrict__ seg, const uint16_t* __restrict__ rowoff,
+                                                  const int* __restrict__ cols, const double* __restrict__ vals,
+                                                  const double* __restrict__ x, double* __restrict__ y) {
+    double sum[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) sum[i] = 0.0;
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            const int t = blockIdx.x + i * gridDim.x;
+            if (t < T) {
+                const int s = t * K + k, base = seg[s];
+                const uint16_t* ro = rowoff + (size_t)s * (ROWS + 1);
+                const int lo = ro[threadIdx.x], hi = ro[threadIdx.x + 1];
+                for (int j = lo; j < hi; ++j) sum[i] += vals[base + j] * x[cols[base + j]];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        const int t = blockIdx.x + i * gridDim.x;
+        const long r = (long)t * ROWS + threadIdx.x;
+        if (t < T && r < n) y[r] = sum[i];
+    }
+}
+
+template <int TW>
+__global__ __launch_bounds__(BLOCK) void cb_lds(int T, int K, int n, const int* __restrict__ seg, const uint16_t* __restrict__ rowoff,
+                                                 const int* __restrict__ cols, const double* __restrict__ vals,
+                                                 const double* __restrict__ x, double* __restrict__ y) {
+    __shared__ double prod[2][PCAP];
+    double sum[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) sum[i] = 0.0;
+    int buf = 0;
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            const int t = blockIdx.x + i * gridDim.x;
+            if (t < T) {                                     // (uniform per workgroup)
+                const int s = t * K + k, base = seg[s], len = seg[s + 1] - base;
+                const uint16_t* ro = rowoff + (size_t)s * (ROWS + 1);
+                const int lo = ro[threadIdx.x], hi = ro[threadIdx.x + 1];
+                double* p = prod[buf];
+                for (int j = threadIdx.x; j < len; j += BLOCK) p[j] = vals[base + j] * x[cols[base + j]];
+                __syncthreads();                             // one barrier per step: the buffers alternate
+                for (int j = lo; j < hi; ++j) sum[i] += p[j];
+                buf ^= 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        const int t = blockIdx.x + i * gridDim.x;
+        const long r = (long)t * ROWS + threadIdx.x;
+        if (t < T && r < n) y[r] = sum[i];
+    }
+}
+
+// wave : every wave owns 64-row sub-tiles; nonzeros loaded coalesced within the wave, products to a wave-private LDS
+//        region, row sums from there -- coalesced matrix reads without any workgroup barrier
+constexpr int WCAP = 1024;
+template <int SW>
+__global__ __launch_bounds__(BLOCK) void cb_wave(int S, int K, int n, const int* __restrict__ seg, const uint16_t* __restrict__ rowoff,
+                                                  const int* __restrict__ cols, const double* __restrict__ vals,
+                                                  const double* __restrict__ x, double* __restrict__ y) {
+    __shared__ double prod[4][2][WCAP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+    double sum[SW];
+#pragma unroll
+    for (int i = 0; i < SW; ++i) sum[i] = 0.0;
+    int buf = 0;
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int i = 0; i < SW; ++i) {
+            const int st = gw + i * nw;
+            if (st < S) {
+                const int s = st * K + k, base = seg[s], len = seg[s + 1] - base;
+                const uint16_t* ro = rowoff + (size_t)s * 65;
+                const int lo = ro[lane], hi = ro[lane + 1];
+                double* p = prod[wv][buf];
+                for (int j = lane; j < len; j += 64) p[j] = vals[base + j] * x[cols[base + j]];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int j = lo; j < hi; ++j) sum[i] += p[j];
+                buf ^= 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SW; ++i) {
+        const int st = gw + i * nw;
+        const long r = (long)st * 64 + lane;
+        if (st < S && r < n) y[r] = sum[i];
+    }
+}
+
+// res  : plain CSR, no format change.  The workgroup's tiles are loaded once into LDS (coalesced), then the K column
+//        blocks are walked with a cursor per row: only the x gathers go to memory during the phases, and at any
+//        time they all fall into one slice of x
+constexpr int RCAP = 1536;
+template <int TW, int U>
+__global__ __launch_bounds__(BLOCK) void cb_res(int T, int K, int n, int W, const int* __restrict__ ip,
+                                                 const int* __restrict__ cols, const double* __restrict__ vals,
+                                                 const double* __restrict__ x, double* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* lv = (double*)smem;                              // [TW][RCAP]
+    int* lc = (int*)(lv + TW * RCAP);                        // [TW][RCAP]
+    int cur[TW], end[TW];
+    double sum[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        const int t = blockIdx.x + i * gridDim.x;
+        sum[i] = 0.0;
+        cur[i] = end[i] = 0;
+        if (t < T) {
+            const int row0 = t * ROWS, rowe = min(n, row0 + ROWS);
+            const int e0 = ip[row0], e1 = ip[rowe];
+            for (int j = threadIdx.x; j < e1 - e0; j += BLOCK) {
+                lc[i * RCAP + j] = cols[e0 + j];
+                lv[i * RCAP + j] = vals[e0 + j];
+            }
+            const int r = row0 + threadIdx.x;
+            if (r < n) { cur[i] = ip[r] - e0; end[i] = ip[r + 1] - e0; }
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        const int c1 = min(n, (k + 1) * W);
+        for (;;) {
+            bool more = false;
+            double xv[TW][U], vv[TW][U];
+            bool ok[TW][U];
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = cur[i] + u;
+                    int c = 0x7fffffff;
+                    if (p < end[i]) c = lc[i * RCAP + p];
+                    ok[i][u] = c < c1;
+                    xv[i][u] = 0.0; vv[i][u] = 0.0;
+                    if (ok[i][u]) { xv[i][u] = x[c]; vv[i][u] = lv[i * RCAP + p]; }
+                }
+#pragma unroll
+            for (int i = 0; i < TW; ++i) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ok[i][u]) { sum[i] += vv[i][u] * xv[i][u]; cur[i] += 1; }
+                more |= ok[i][U - 1];
+            }
+            if (!__any(more)) break;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        const int t = blockIdx.x + i * gridDim.x;
+        const long r = (long)t * ROWS + threadIdx.x;
+        if (t < T && r < n) y[r] = sum[i];
+    }
+}
+
+// gath : the raw cost of the gathers alone: out[lane] = sum of x[idx[j]] over a grid-stride range (no values, no rows)
+template <int U>
+__global__ __launch_bounds__(BLOCK) void gath(long nnz, const int* __restrict__ idx, const double* __restrict__ x, double* __restrict__ out) {
+    const long S = (long)gridDim.x * BLOCK;
+    double s = 0.0;
+    long j = (long)blockIdx.x * BLOCK + threadIdx.x;
+    for (; j + (U - 1) * S < nnz; j += U * S) {
+        int c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = idx[j + u * S];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += x[c[u]];
+    }
+    for (; j < nnz; j += S) s += x[idx[j]];
+    out[(long)blockIdx.x * BLOCK + threadIdx.x] = s;
+}
+
+struct Csr { int n; std::vector<int> ip, ix; std::vector<double> dv; };
+
+static Csr make_random(int n, int k, uint64_t seed) {
+    Csr A; A.n = n; A.ip.assign(n + 1, 0);
+    uint64_t s = seed * 6364136223846793005ULL + 1442695040888963407ULL;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    std::vector<std::pair<int, double>> row;
+    for (int r = 0; r < n; ++r) {
+        row.clear();
+        double dsum = 1.0;
+        for (int q = 0; q < k; ++q) {
+            int c = (int)(rnd() % (uint64_t)n);
+            double v = ((double)(rnd() % 2000001) - 1000000.0) / 500000.0;
+            if (c == r || v == 0.0) continue;
+            bool dup = false;
+            for (auto& e : row) if (e.first == c) { e.second += v; dup = true; }
+            if (!dup) row.push_back({c, v});
+        }
+        for (auto& e : row) dsum += e.second < 0 ? -e.second : e.second;
+        row.push_back({r, dsum});
+        std::sort(row.begin(), row.end());
+        for (auto& e : row) { A.ix.push_back(e.first); A.dv.push_back(e.second); }
+        A.ip[r + 1] = (int)A.ix.size();
+    }
+    return A;
+}
+
+template <class F> float timeit(F f, int reps) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a)); for (int i = 0; i < reps; ++i) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 1000000;
+    const int reps = argc > 2 ? atoi(argv[2]) : 50;
+    Csr A = make_random(n, 4, 7);
+    const long nnz = (long)A.ix.size();
+    const int T = (n + ROWS - 1) / ROWS;
+    std::vector<double> x(n), yref(n);
+    for (int i = 0; i < n; ++i) x[i] = 1.0 + (double)(i % 977) / 977.0;
+    for (int r = 0; r < n; ++r) { double s = 0; for (int j = A.ip[r]; j < A.ip[r + 1]; ++j) s += A.dv[j] * x[A.ix[j]]; yref[r] = s; }
+    const double alg = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
+    printf("n = %d nnz = %ld tiles = %d algorithmic bytes = %.1f MB\n", n, nnz, T, alg / 1e6);
+    double *dx, *dy; CK(hipMalloc(&dx, 8L * n)); CK(hipMalloc(&dy, 8L * n));
+    CK(hipMemcpy(dx, x.data(), 8L * n, hipMemcpyHostToDevice));
+    int *dip, *dix; double* ddv;
+    CK(hipMalloc(&dip, 4L * (n + 1))); CK(hipMalloc(&dix, 4 * nnz)); CK(hipMalloc(&ddv, 8 * nnz));
+    CK(hipMemcpy(dip, A.ip.data(), 4L * (n + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dix, A.ix.data(), 4 * nnz, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ddv, A.dv.data(), 8 * nnz, hipMemcpyHostToDevice));
+    {
+        double* dout; CK(hipMalloc(&dout, 8L * 4096 * BLOCK));
+        for (int G : {1024, 2048, 4096}) {
+            float m1 = timeit([&] { hipLaunchKernelGGL((gath<1>), dim3(G), dim3(BLOCK), 0, 0, nnz, dix, dx, dout); }, reps);
+            float m5 = timeit([&] { hipLaunchKernelGGL((gath<5>), dim3(G), dim3(BLOCK), 0, 0, nnz, dix, dx, dout); }, reps);
+            printf("gather only grid=%4d : U=1 %6.1f us  U=5 %6.1f us  (%ld gathers of 8 B from %.1f MB)\n", G, m1 * 1e3, m5 * 1e3, nnz, 8.0 * n / 1e6);
+        }
+        CK(hipFree(dout));
+    }
+    std::vector<int> Ks;
+    for (int a = 3; a < argc; ++a) Ks.push_back(atoi(argv[a]));
+    if (Ks.empty()) Ks = {1, 2, 4, 8};
+    for (int K : Ks) {
+        const long W = ((long)n + K - 1) / K;
+        std::vector<int> seg((size_t)T * K + 1), cols(nnz);
+        std::vector<double> vals(nnz);
+        std::vector<uint16_t> ro((size_t)T * K * (ROWS + 1));
+        long p = 0; int maxlen = 0;
+        for (int t = 0; t < T; ++t)
+            for (int k = 0; k < K; ++k) {
+                const size_t s = (size_t)t * K + k;
+                seg[s] = (int)p;
+                const long c0 = k * W, c1 = std::min<long>(n, c0 + W);
+                for (int q = 0; q <= ROWS; ++q) {
+                    ro[s * (ROWS + 1) + q] = (uint16_t)(p - seg[s]);
+                    const long r = (long)t * ROWS + q;
+                    if (q == ROWS || r >= n) continue;
+                    for (int j = A.ip[r]; j < A.ip[r + 1]; ++j)
+                        if (A.ix[j] >= c0 && A.ix[j] < c1) { cols[p] = A.ix[j]; vals[p] = A.dv[j]; ++p; }
+                }
+                maxlen = std::max(maxlen, (int)(p - seg[s]));
+            }
+        seg[(size_t)T * K] = (int)p;
+        if (p != nnz || maxlen > PCAP) { printf("format error %ld %ld %d\n", p, nnz, maxlen); return 1; }
+        int *dseg, *dcols; double* dvals; uint16_t* dro;
+        CK(hipMalloc(&dseg, 4 * seg.size())); CK(hipMalloc(&dcols, 4 * nnz)); CK(hipMalloc(&dvals, 8 * nnz)); CK(hipMalloc(&dro, 2 * ro.size()));
+        CK(hipMemcpy(dseg, seg.data(), 4 * seg.size(), hipMemcpyHostToDevice));
+        CK(hipMemcpy(dcols, cols.data(), 4 * nnz, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dvals, vals.data(), 8 * nnz, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dro, ro.data(), 2 * ro.size(), hipMemcpyHostToDevice));
+        auto check = [&](const char* nm) {
+            std::vector<double> y(n); CK(hipMemcpy(y.data(), dy, 8L * n, hipMemcpyDeviceToHost));
+            long bad = 0; for (int i = 0; i < n; ++i) bad += (y[i] != yref[i]);
+            if (bad) printf("   !! %s: %ld rows differ\n", nm, bad);
+        };
+#define RUN(KERN, TW, G, NAME) { CK(hipMemset(dy, 0, 8L * n)); float ms = timeit([&] { hipLaunchKernelGGL((KERN<TW>), dim3(G), dim3(BLOCK), 0, 0, T, K, n, dseg, dro, dcols, dvals, dx, dy); }, reps); \
+            CK(hipGetLastError()); check(NAME); printf("K=%2d %-5s grid=%4d tiles/wg=%d : %7.1f us  %5.2f TB/s (frac %.3f)  maxseg=%d\n", K, NAME, G, TW, ms * 1e3, alg / ms / 1e9, alg / ms / 1e9 / 8.0, maxlen); }
+        const int g1 = T, g2 = (T + 1) / 2, g4 = (T + 3) / 4;
+#define RUNRES(TW, U, G) { CK(hipMemset(dy, 0, 8L * n)); const size_t lds = (size_t)TW * RCAP * 12; \
+            CK(hipFuncSetAttribute((const void*)cb_res<TW, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            float ms = timeit([&] { hipLaunchKernelGGL((cb_res<TW, U>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy); }, reps); \
+            CK(hipGetLastError()); check("res"); printf("K=%2d res%d  grid=%4d tiles/wg=%d : %7.1f us  %5.2f TB/s (frac %.3f)\n", K, U, G, TW, ms * 1e3, alg / ms / 1e9, alg / ms / 1e9 / 8.0); }
+        RUNRES(1, 1, g1) RUNRES(1, 2, g1) RUNRES(2, 1, g2) RUNRES(2, 2, g2) RUNRES(4, 1, g4) RUNRES(4, 2, g4)
+        if (getenv("RES_ONLY")) { CK(hipFree(dseg)); CK(hipFree(dcols)); CK(hipFree(dvals)); CK(hipFree(dro)); continue; }
+        RUN(cb_lane, 1, g1, "lane") RUN(cb_lane, 2, g2, "lane") RUN(cb_lane, 4, g4, "lane")
+        RUN(cb_lds, 1, g1, "lds") RUN(cb_lds, 2, g2, "lds") RUN(cb_lds, 4, g4, "lds")
+        CK(hipFree(dseg)); CK(hipFree(dro));
+        {   // sub-tile (64 rows) format for the wave variant
+            const int S = (n + 63) / 64;
+            std::vector<int> seg2((size_t)S * K + 1);
+            std::vector<uint16_t> ro2((size_t)S * K * 65);
+            long p2 = 0; int maxl = 0;
+            for (int st = 0; st < S; ++st)
+                for (int k = 0; k < K; ++k) {
+                    const size_t s2 = (size_t)st * K + k;
+                    seg2[s2] = (int)p2;
+                    const long c0 = k * W, c1 = std::min<long>(n, c0 + W);
+                    for (int q = 0; q <= 64; ++q) {
+                        ro2[s2 * 65 + q] = (uint16_t)(p2 - seg2[s2]);
+                        const long r = (long)st * 64 + q;
+                        if (q == 64 || r >= n) continue;
+                        for (int j = A.ip[r]; j < A.ip[r + 1]; ++j)
+                            if (A.ix[j] >= c0 && A.ix[j] < c1) { cols[p2] = A.ix[j]; vals[p2] = A.dv[j]; ++p2; }
+                    }
+                    maxl = std::max(maxl, (int)(p2 - seg2[s2]));
+                }
+            seg2[(size_t)S * K] = (int)p2;
+            if (p2 != nnz || maxl > WCAP) { printf("format error %ld %ld %d\n", p2, nnz, maxl); return 1; }
+            CK(hipMalloc(&dseg, 4 * seg2.size())); CK(hipMalloc(&dro, 2 * ro2.size()));
+            CK(hipMemcpy(dseg, seg2.data(), 4 * seg2.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dro, ro2.data(), 2 * ro2.size(), hipMemcpyHostToDevice));
+            CK(hipMemcpy(dcols, cols.data(), 4 * nnz, hipMemcpyHostToDevice));
+            CK(hipMemcpy(dvals, vals.data(), 8 * nnz, hipMemcpyHostToDevice));
+            const int T = S; const int maxlen = maxl;    // (RUN prints these)
+            const int w1 = (S + 3) / 4, w2 = (S + 7) / 8, w4 = (S + 15) / 16;
+            RUN(cb_wave, 1, w1, "wave") RUN(cb_wave, 2, w2, "wave") RUN(cb_wave, 4, w4, "wave")
+        }
+        CK(hipFree(dseg)); CK(hipFree(dcols)); CK(hipFree(dvals)); CK(hipFree(dro));
+    }
+    return 0;
+}
