@@ -16,7 +16,8 @@ OBJDIR = os.path.join(HERE, "build")
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-    "-ffp-contract=off", *([] if not os.environ.get("MK_AB_FLAGS") else os.environ["MK_AB_FLAGS"].split()),          # one rounding per multiply and per add, like the NumPy expressions replaced
+    "-ffp-contract=off",          # one rounding per multiply and per add, like the NumPy expressions replaced
+    *os.environ.get("MK_EXTRA_HIPCC_FLAGS", "").split(),     # (experiments: a second build with other -D switches)
     "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
 ]
 

@@ -245,12 +245,8 @@ __device__ __forceinline__ T mk_sload(const T *p) {
 }
 
 __device__ __forceinline__ int64_t mk_tile_at(const MkCsrView &A, int64_t p) {
-#ifdef MK_AB_VECTOR_TILE
-    return A.tiles ? (int64_t)A.tiles[p] : p;
-#else
     const int t = A.tiles ? mk_sload(A.tiles + p) : (int)p;
     return (int64_t)__builtin_amdgcn_readfirstlane(t);
-#endif
 }
 
 struct MkTileMeta {
@@ -363,13 +359,8 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
             const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
             const int64_t r = r0 + tid;
-#ifdef MK_AB_VECTOR_TILE
-            m.p_lo = A.indptr[r0];
-            m.p_hi = A.indptr[rend];
-#else
             m.p_lo = mk_sload(A.indptr + r0);
             m.p_hi = mk_sload(A.indptr + rend);
-#endif
             m.my_lo = A.indptr[(r < rend) ? r : rend];      // rows past the end start (and end) at p_hi
         }
     };
