@@ -277,6 +277,8 @@ def main():
     ap.add_argument("--spmv-launches", type=int, default=200,
                     help="back-to-back launches of the fused SpMV kernel timed by one HIP event pair")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--one-device", action="store_true",
+                    help="test aid: every rank on GPU 0 (RCCL refuses that, which exercises the host-staged fallback)")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="host: collectives staged through host memory over gloo, all ranks on GPU 0 -- a smoke test "
@@ -300,15 +302,37 @@ def main():
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         td.init_process_group(backend="gloo", rank=rank, world_size=world_size)
-        if args.transport == "host":
+        if args.transport == "host" or args.one_device:
             local_rank = 0
 
     from pykrylov_amd import _lib, dist
     from pykrylov_amd.generic import DeviceRun
     lib = _lib.init(local_rank)
     world = dist.World(rank, world_size, td)
+    transport_used, transport_note = args.transport, None
     if world_size > 1:
-        world.init_device_comm(transport=args.transport)
+        # RCCL, checked with one small all-reduce; if any rank cannot get a working communicator, ALL ranks fall
+        # back to the host-staged transport (gloo on pinned buffers): slow, but a measured line with the reason in
+        # it is worth more than no line
+        ok, err = True, ""
+        try:
+            world.init_device_comm(transport=args.transport)
+            probe = (ctypes.c_double * 1)(float(rank + 1))
+            _lib.check(lib.mk_comm_allreduce_host(probe, 1))
+            if probe[0] != world_size * (world_size + 1) / 2.0:
+                raise RuntimeError("all-reduce self-test returned %r" % probe[0])
+        except Exception as e:                               # noqa: BLE001 - any failure triggers the fallback
+            ok, err = False, "rank %d: %r" % (rank, e)
+        states = world.allgather_object((ok, err))
+        if not all(o for o, _ in states):
+            first = [e for o, e in states if not o][0][:300]
+            if args.transport != "rccl":
+                raise SystemExit("communicator setup failed: " + first)
+            lib.mk_comm_destroy()
+            world.init_device_comm(transport="host")
+            transport_used, transport_note = "host", "RCCL communicator unavailable (%s): host-staged gloo fallback" % first
+            if rank == 0:
+                sys.stderr.write("bench.py: " + transport_note + "\n")
 
     name = args.workload
     if name == "auto":
@@ -452,8 +476,8 @@ def main():
                                        "is reported under extra") if name == "poisson3d-512" else name,
                    "solver": "cg", "rows": n_g, "nnz": nnz_global, "storage_format": info["fmt"],
                    "parallelism": "1 GPU" if not multi else "row-partition x%d, %s exchange + allreduce(dots), %s"
-                                  % (world_size, first_mode, "RCCL (gloo bootstrap)" if args.transport == "rccl"
-                                     else "host-staged gloo (smoke test)")},
+                                  % (world_size, first_mode, "RCCL (gloo bootstrap)" if transport_used == "rccl"
+                                     else "host-staged gloo (%s)" % (transport_note or "smoke test"))},
         "roofline": roof,
         "iteration_roofline": it_roof,
         "device_loop_ms": tm["iterate_ms"],
