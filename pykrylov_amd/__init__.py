@@ -18,3 +18,4 @@ from .tfqmr import TFQMR                                                        
 from .minres import Minres                                                                      # noqa: F401
 from .symmlq import Symmlq                                                                      # noqa: F401
 from . import lls                                                                               # noqa: F401
+from . import blkop                                                                             # noqa: F401

@@ -29,6 +29,8 @@ class OracleOp(object):
     def rmatvec(self, u):
         return self.op.T * u
 
+    __call__ = matvec                                       # (the MINRES / SYMMLQ restatements call `A(v)`)
+
 
 @pytest.mark.parametrize("n", [10, 100, 1000, 10000])
 def test_reference_protocol_poisson1d(n):
@@ -262,3 +264,35 @@ def test_host_operator_and_host_preconditioner_together():
                 red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geometry(n))))
     assert s.nMatvec == ref["nMatvec"] and np.array_equal(s.x, ref["x"])
     assert np.array_equal(np.array(s.residHistory), ref["residHistory"])
+
+
+def test_block_operator_of_device_matrices_in_minres(monkeypatch):
+    """A symmetric saddle-point operator [[A, B^T], [B, -D]] built with BlockLinearOperator from device matrices
+    (pykrylov_amd/blkop.py; reference linop/blkop.py:8-152): the block products run on the GPU one block at a time,
+    the MINRES loop on the GPU as well, and the whole agrees bit for bit with the oracle run on the same callable
+    with its dots in the device's order."""
+    from pykrylov_amd import CsrOperator, DiagonalOperator, Minres
+    from pykrylov_amd.blkop import BlockLinearOperator
+    monkeypatch.setattr(kr, "_sq", lambda a: a * a)
+    P = csr_ref.poisson2d(20)                                              # 400 x 400, symmetric
+    rng = np.random.default_rng(4)
+    rows = np.repeat(np.arange(100), 3)
+    Bm = csr_ref.from_coo(rows, rng.integers(0, 400, 300), rng.standard_normal(300), (100, 400))
+    A = CsrOperator(P.indptr, P.indices, P.data, P.shape, symmetric=True)
+    B = CsrOperator(Bm.indptr, Bm.indices, Bm.data, Bm.shape)
+    D = DiagonalOperator(-(1.0 + rng.random(100)))
+    K = BlockLinearOperator([[A, B.T], [D]], symmetric=True)
+    assert K.shape == (500, 500) and K[1, 0] is B and K.T is K
+    x = rng.standard_normal(500)
+    want = np.concatenate([(0.0 + P.matvec(x[:400])) + Bm.rmatvec(x[400:]), (0.0 + Bm.matvec(x[:400])) + D.diag * x[400:]])
+    assert np.array_equal(K * x, want)
+    rhs = K * np.ones(500)
+    s = Minres(K)
+    s.solve(rhs, show=False, check=True, etol=0.0, rtol=1e-10)
+    ref = kr.minres(OracleOp(K), rhs, check=False, etol=0.0, rtol=1e-10,
+                    red=kr.Reductions(gpu_order.GpuDots(500, gpu_order.SPMV_SITES["minres"], geometry(500))))
+    assert (s.istop, s.itn) == (ref["istop"], ref["itn"]) and s.itn > 20
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
+    assert np.linalg.norm(s.x - 1.0) < 1e-6
+    A.free()
+    B.free()
