@@ -357,7 +357,8 @@ __global__ __launch_bounds__(MK_BLOCK) void tile_extent_kernel(const int32_t *__
     atomicMax(out, mx);
 }
 
-// fmt 3: a matrix that stays on plain CSR, whose x is too long for an XCD's L2 (4 MiB) and whose tiles fit LDS eight
+// fmt 3: a matrix that stays on plain CSR, whose x is longer than an XCD's L2 (4 MiB; the gather path still wins up
+// to 5 MiB, tools/fmt_compare.py) and whose tiles fit LDS eight
 // to a CU: resident tiles, gathers ordered by column block (mk_device.h).  Slices of <= 1.5 MiB: measured best on
 // 1e6 x 5 random (BiCGSTAB's fused product: K = 4 / 6 / 8 -> 38.8 / 37.9 / 38.7 us, 50.6 us with one phase, 53 us on
 // the gather path; tools/ubench/spmv_cb.hip has the kernel variants that were tried).
@@ -365,7 +366,7 @@ constexpr int64_t RT_SLICE_BYTES = 3 << 19;
 constexpr int RT_CAP_MAX = 2560;                             // 30 KB of LDS per workgroup
 int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     const int64_t xbytes = 8 * A->x_len();
-    if (!forced && (xbytes <= 3 * (1 << 20) || getenv("MK_NO_RESIDENT"))) return MK_OK;
+    if (!forced && (xbytes <= 5 * (1 << 20) || getenv("MK_NO_RESIDENT"))) return MK_OK;   // (crossover measured at 650 k rows x 5)
     if (A->ex.mode >= 0 && !forced) return MK_OK;            // (partitioned matrices: their x slices are short already)
     hipStream_t st = mk_ctx().stream;
     int *d_max = nullptr, h_max = 0;
