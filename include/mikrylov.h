@@ -315,6 +315,12 @@ int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void *user);
  * lines of lsmr.py, craig.py, craigmr.py): device arrays with the diagonals of M (nrows(A) entries) and N
  * (ncols(A) entries), either may be NULL; borrowed until the solver is destroyed.  Call before mk_solver_setup. */
 int mk_solver_set_lls_precon(mk_solver *s, const double *diag_m, const double *diag_n);
+/* M and / or N as HOST callbacks `fn(user, in_host, out_host)` -- any callable the reference would apply as
+ * `u = M(Mu)` (nrows(A) entries) or `v = N(Nv)` (ncols(A) entries); a NULL function leaves that side to
+ * mk_solver_set_lls_precon.  The loop stays on the device: the vector is copied to the host right after the kernel that
+ * formed it, the callback's result replaces u / v and <u, Mu> / <v, Nv> are re-formed on the device.  Not invoked once
+ * the loop has halted, nor for N when beta = 0 (lsqr.py:258).  Single GPU.  Call before mk_solver_setup. */
+int mk_solver_set_lls_precon_callback(mk_solver *s, mk_precon_fn fn_m, void *user_m, mk_precon_fn fn_n, void *user_n);
 /* Everything before the `while` loop of the reference's solve().  rhs_dev has n_local
  * entries; guess_dev may be NULL (x0 = 0).  Neither is modified. */
 int mk_solver_setup(mk_solver *s, const double *rhs_dev, const double *guess_dev);

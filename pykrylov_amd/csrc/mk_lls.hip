@@ -963,6 +963,10 @@ struct OpInitM {     // CRAIG: d = u / rho ; r = tau d.  CRAIG-MR: d = u / alpha
     __device__ void one(int64_t i, double *) { elem(i); }
 };
 
+__global__ __launch_bounds__(MK_BLOCK) void lls_fill_kernel(double *v, int64_t n, double a) {
+    for (int64_t i = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MK_BLOCK) v[i] = a;
+}
+
 struct LlsSolver : mk_solver {
     int kind;
     int64_t m = 0, nn = 0;
@@ -973,6 +977,93 @@ struct LlsSolver : mk_solver {
     const double *d_dm = nullptr, *d_dn = nullptr; // diagonals of M (m entries) and N (n entries), borrowed
     int np_A = 1, np_At = 1, np_n = 1, np_m = 1;
     int64_t itnlim = 0;
+    // M / N as host callbacks (mk_solver_set_lls_precon_callback): the kernels run with a diagonal of ones and the
+    // vector `u = M(Mu)` / `v = N(Nv)` is replaced by the callback's result right after the kernel that formed it;
+    // <u, Mu> / <v, Nv> are then re-formed by a dot kernel (same scheme as mk_solver::host_precon)
+    mk_precon_fn fn_m = nullptr, fn_n = nullptr;
+    void *user_m = nullptr, *user_n = nullptr;
+    double *d_ones_m = nullptr, *d_ones_n = nullptr, *h_cb_in = nullptr, *h_cb_out = nullptr;
+    int64_t cb_cap = 0;
+
+    ~LlsSolver() override {
+        hipFree(d_ones_m);
+        hipFree(d_ones_n);
+        if (h_cb_in) hipHostFree(h_cb_in);
+        if (h_cb_out) hipHostFree(h_cb_out);
+    }
+
+    // out = fn(in) on the host.  Skipped once the loop has halted (unless `force`: the setup calls) and when the
+    // product that formed `in` did not run (`need_beta`: lsqr.py:258, everything about v happens `if beta > 0`).
+    int host_apply(mk_precon_fn fn, void *user, const double *in_dev, double *out_dev, int64_t len, bool force,
+                   bool need_beta) {
+        int h = 0;
+        double beta = 1.0;
+        MK_HIP(hipMemcpyAsync(&h, d_halt + (q & 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (need_beta) MK_HIP(hipMemcpyAsync(&beta, d_scal + S_BETA, sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (len > 0) MK_HIP(hipMemcpyAsync(h_cb_in, in_dev, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost, stream));
+        MK_HIP(hipStreamSynchronize(stream));
+        if ((h && !force) || !(beta > 0)) return MK_OK;
+        if (fn(user, h_cb_in, h_cb_out) != 0) {
+            const int rc = mk_fail(MK_ERR_STATE, "the host preconditioner callback (M or N) reported a failure");
+            if (mk_ctx().pending_rc == MK_OK) mk_ctx().pending_rc = rc;
+            return rc;
+        }
+        if (len > 0) MK_HIP(hipMemcpyAsync(out_dev, h_cb_out, sizeof(double) * (size_t)len, hipMemcpyHostToDevice, stream));
+        return MK_OK;
+    }
+    // <v, Nv> comes from the A' product's epilogue, or from the dot kernel that follows an N callback
+    int np_vv() const { return fn_n ? np_n : np_At; }
+    int apply_M(bool force) {                    // u = M(Mu) ; <u, Mu>
+        if (!fn_m) return MK_OK;
+        int rc = host_apply(fn_m, user_m, d_Mu, d_u, m, force, false);
+        if (rc != MK_OK) return rc;
+        mk_launch_stream(this, MkOpDot<SLOT_UU>{d_u, d_Mu}, m);
+        return MK_OK;
+    }
+    int apply_N(bool force) {                    // v = N(Nv) ; <v, Nv>
+        if (!fn_n) return MK_OK;
+        int rc = host_apply(fn_n, user_n, d_Nv, d_v, nn, force, true);
+        if (rc != MK_OK) return rc;
+        mk_launch_stream(this, MkOpDot<SLOT_VV>{d_v, d_Nv}, nn);
+        return MK_OK;
+    }
+    int set_callbacks(mk_precon_fn fm, void *um, mk_precon_fn fn, void *un) {
+        const int64_t mm = A->nrows, nc = A->ncols, cap = mm > nc ? mm : nc;
+        if ((fm || fn) && cap > cb_cap) {
+            if (h_cb_in) hipHostFree(h_cb_in);
+            if (h_cb_out) hipHostFree(h_cb_out);
+            h_cb_in = h_cb_out = nullptr;
+            MK_HIP(hipHostMalloc((void **)&h_cb_in, sizeof(double) * (size_t)(cap > 0 ? cap : 1), hipHostMallocDefault));
+            MK_HIP(hipHostMalloc((void **)&h_cb_out, sizeof(double) * (size_t)(cap > 0 ? cap : 1), hipHostMallocDefault));
+            cb_cap = cap;
+        }
+        auto ones = [&](double **p, int64_t len) -> int {
+            if (*p) return MK_OK;
+            MK_HIP(hipMalloc((void **)p, sizeof(double) * (size_t)(len > 0 ? len : 1) + 16));
+            hipLaunchKernelGGL(lls_fill_kernel, dim3(512), dim3(MK_BLOCK), 0, stream, *p, len, 1.0);
+            MK_HIP(hipGetLastError());
+            return MK_OK;
+        };
+        int rc;
+        if (fm) {
+            if ((rc = ones(&d_ones_m, mm)) != MK_OK) return rc;
+            d_dm = d_ones_m;
+        } else if (fn_m) {
+            d_dm = nullptr;
+        }
+        if (fn) {
+            if ((rc = ones(&d_ones_n, nc)) != MK_OK) return rc;
+            d_dn = d_ones_n;
+        } else if (fn_n) {
+            d_dn = nullptr;
+        }
+        fn_m = fm;
+        user_m = um;
+        fn_n = fn;
+        user_n = un;
+        return MK_OK;
+    }
+
     // several GPUs, A = this rank's row block (mk_csr_set_row_block): m-space vectors are slices, n-space vectors
     // whole and identical on every rank
     bool dist = false;
@@ -981,10 +1072,10 @@ struct LlsSolver : mk_solver {
     // <u, Mu> is an m-space inner product: its partial sums are added across the ranks
     int sum_uu() { return dist ? allreduce(SLOT_UU, 1) : (int)MK_OK; }
     // G3: v <- A' u - beta v with <v, v>
-    int product_At(bool) {
+    int product_At(bool in_setup) {
         if (!dist) {
             mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, d_dn, d_Nv, 0.0}, GateV{d_scal});
-            return MK_OK;
+            return apply_N(in_setup);
         }
         mk_launch_spmv_on(this, At, d_u, MkPlainEpi{d_t}, GateV{d_scal});
         int rc = mk_comm_allreduce_sum(d_t, nn, stream);   // (a skipped product leaves old data: OpVt skips as well)
@@ -1002,8 +1093,9 @@ struct LlsSolver : mk_solver {
             return mk_fail(MK_ERR_UNSUPPORTED, "least-squares solvers: partition A by row blocks (mk_csr_set_row_block), "
                            "not with a halo / all-gather exchange plan");
         dist = A->row_block && mk_comm_active();
-        if (dist && (A->host_fn || At->host_fn))
-            return mk_fail(MK_ERR_UNSUPPORTED, "least-squares solvers: matrix-free operators are single-GPU");
+        if (dist && (A->host_fn || At->host_fn || fn_m || fn_n))
+            return mk_fail(MK_ERR_UNSUPPORTED, "least-squares solvers: matrix-free operators and M / N callbacks are "
+                           "single-GPU");
         if (prm.window < 1 || prm.window > MAXWIN) return mk_fail(MK_ERR_ARG, "window must be in 1..%d", MAXWIN);
         use_hist2 = true;
         m = A->nrows;
@@ -1036,6 +1128,7 @@ struct LlsSolver : mk_solver {
             mk_launch_stream(this, MkOpCopy{rhs, d_Mu}, m);                            // Mu = rhs.copy()   lsqr.py:188
             mk_launch_stream(this, MkOpMul{d_dm, d_Mu, d_u}, m);                       // u = M(Mu)         lsqr.py:190
             mk_launch_stream(this, MkOpDot<SLOT_UU>{d_u, d_Mu}, m);                    // <u, Mu>           lsqr.py:195
+            if ((rc2 = apply_M(true)) != MK_OK) return rc2;
         } else {
             mk_launch_stream(this, MkOpCopy{rhs, d_u}, m);                             // Mu = rhs.copy()   lsqr.py:188
             mk_launch_stream(this, MkOpDot<SLOT_UU>{d_u, d_u}, m);                     // lsqr.py:195
@@ -1044,7 +1137,7 @@ struct LlsSolver : mk_solver {
         mk_launch_stream(this, OpNormU{d_part, np_m, d_scal, d_u, d_dm ? d_Mu : nullptr, 0.0}, m);   // lsqr.py:197-198
         // Nv = A' u (Nv is zero: the epilogue's "- beta Nv" term vanishes exactly)     lsqr.py:200
         if ((rc2 = product_At(true)) != MK_OK) return rc2;
-        hipLaunchKernelGGL(lls_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_At, d_scal, d_status,
+        hipLaunchKernelGGL(lls_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_vv(), d_scal, d_status,
                            next_halt(), kind, itnlim);
         mk_launch_stream(this, OpInitN{d_scal, kind, d_v, d_a, d_b, d_x, 0, 0, 0, 0}, nn);
         if (d_dn) mk_launch_stream(this, OpScaleNv{d_scal, d_scal + S_BLK, 0, d_Nv, 0.0, false}, nn);   // lsqr.py:209
@@ -1068,22 +1161,23 @@ struct LlsSolver : mk_solver {
                                          prm.conlim > 0 ? 1.0 / prm.conlim : 0.0});
         else
             mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0}, craig::CountGate{d_status, it, itnlim});
-        int rc = sum_uu();
+        int rc = apply_M(false);
         if (rc != MK_OK) return rc;
-        mk_launch_stream(this, OpNormU{d_part, np_A, d_scal, d_u, d_dm ? d_Mu : nullptr, 0.0}, m);       // G2
+        if ((rc = sum_uu()) != MK_OK) return rc;
+        mk_launch_stream(this, OpNormU{d_part, fn_m ? np_m : np_A, d_scal, d_u, d_dm ? d_Mu : nullptr, 0.0}, m);   // G2
         if ((rc = product_At(false)) != MK_OK) return rc;                                                // G3
         if (kind == MK_LSQR) {
-            mk_launch_stream(this, lsqr::OpN{d_part, np_At, d_scal, d_status, d_hist, par, itn, prm.window, prm.damp,
+            mk_launch_stream(this, lsqr::OpN{d_part, np_vv(), d_scal, d_status, d_hist, par, itn, prm.window, prm.damp,
                                              prm.atol, prm.btol, prm.etol, d_v, d_a, d_x, 0, 0, 0, 0, false}, nn);
         } else if (kind == MK_LSMR) {
-            mk_launch_stream(this, lsmr::OpN{d_part, np_At, d_scal, d_status, d_hist, par, itn, prm.window, prm.damp,
+            mk_launch_stream(this, lsmr::OpN{d_part, np_vv(), d_scal, d_status, d_hist, par, itn, prm.window, prm.damp,
                                              prm.etol, d_v, d_a, d_b, d_x, 0, 0, 0, 0, false}, nn);
         } else if (kind == MK_CRAIG) {
-            mk_launch_stream(this, craig::OpN{d_part, np_At, d_scal, d_status, d_hist, par, itn, itnlim, prm.window,
+            mk_launch_stream(this, craig::OpN{d_part, np_vv(), d_scal, d_status, d_hist, par, itn, itnlim, prm.window,
                                               prm.btol, prm.etol, d_v, d_a, d_b, d_x, 0, 0, 0, 0, 0, false}, nn);
             mk_launch_stream(this, craig::OpM{blk_next, d_u, d_d, d_r, 0, 0, 0}, m);
         } else {
-            mk_launch_stream(this, craig::OpNmr{d_part, np_At, d_scal, d_status, d_hist, par, itn, itnlim, prm.window,
+            mk_launch_stream(this, craig::OpNmr{d_part, np_vv(), d_scal, d_status, d_hist, par, itn, itnlim, prm.window,
                                                 prm.etol, d_v, 0, false}, nn);
             mk_launch_stream(this, craig::OpMmr{blk_next, d_u, d_d, d_dbar, d_x, 0, 0, 0, 0, 0}, m);
         }
@@ -1116,8 +1210,8 @@ struct LlsSolver : mk_solver {
     const double *x() const override { return d_x; }
     const double *vector(int i) const override { return i == 0 ? d_r : (i == 1 ? d_u : (i == 2 ? d_v : nullptr)); }
     int set_metric(const double *dm, const double *dn) {
-        d_dm = dm;
-        d_dn = dn;
+        if (!fn_m) d_dm = dm;                    // (a side that has a callback keeps its diagonal of ones)
+        if (!fn_n) d_dn = dn;
         return MK_OK;
     }
 };
@@ -1128,4 +1222,8 @@ mk_solver *mk_make_lls(int kind) { return new LlsSolver(kind); }
 
 int mk_lls_set_metric(mk_solver *s, const double *dm, const double *dn) {
     return static_cast<LlsSolver *>(s)->set_metric(dm, dn);
+}
+
+int mk_lls_set_callbacks(mk_solver *s, mk_precon_fn fn_m, void *user_m, mk_precon_fn fn_n, void *user_n) {
+    return static_cast<LlsSolver *>(s)->set_callbacks(fn_m, user_m, fn_n, user_n);
 }

@@ -103,6 +103,7 @@ mk_solver *mk_make_minres();
 mk_solver *mk_make_symmlq();
 mk_solver *mk_make_lls(int kind);
 int mk_lls_set_metric(mk_solver *s, const double *dm, const double *dn);
+int mk_lls_set_callbacks(mk_solver *s, mk_precon_fn fn_m, void *user_m, mk_precon_fn fn_n, void *user_n);
 
 #ifdef __HIPCC__
 // ------------------------------------------------------------------ small shared kernels

@@ -156,7 +156,10 @@ int mk_solver::iterate(int64_t max_iters, int64_t *done) {
         if (todo > batch) todo = batch;
         for (int64_t k = 0; k < todo; ++k) {
             int rc = enqueue_pass();
-            if (rc != MK_OK) return rc;
+            if (rc != MK_OK) {
+                mk_ctx().pending_rc = MK_OK;                 // (reported here: must not resurface in a later call)
+                return rc;
+            }
             ++it;
         }
         MK_HIP(hipGetLastError());
@@ -283,6 +286,14 @@ extern "C" int mk_solver_set_lls_precon(mk_solver *s, const double *diag_m, cons
     return mk_lls_set_metric(s, diag_m, diag_n);
 }
 
+extern "C" int mk_solver_set_lls_precon_callback(mk_solver *s, mk_precon_fn fn_m, void *user_m, mk_precon_fn fn_n,
+                                                 void *user_n) {
+    MK_ARG(s);
+    if (s->prm.kind < MK_LSQR || s->prm.kind > MK_CRAIGMR)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_solver_set_lls_precon_callback: not a least-squares solver");
+    return mk_lls_set_callbacks(s, fn_m, user_m, fn_n, user_n);
+}
+
 extern "C" int mk_solver_destroy(mk_solver *s) {
     delete s;
     return MK_OK;
@@ -303,8 +314,12 @@ extern "C" int mk_solver_setup(mk_solver *s, const double *rhs, const double *gu
     MK_HIP(hipMemsetAsync(s->d_status, 0, sizeof(MkStatus), s->stream));
     MK_HIP(hipMemsetAsync(s->d_scal, 0, sizeof(double) * MK_NSCAL, s->stream));
     MK_HIP(hipMemsetAsync(s->d_part, 0, sizeof(double) * MK_NDOT * MK_MAXP, s->stream));
+    mk_ctx().pending_rc = MK_OK;                             // (a failure of an earlier solve was reported there)
     int rc = s->setup(rhs, guess);
-    if (rc != MK_OK) return rc;
+    if (rc != MK_OK) {
+        mk_ctx().pending_rc = MK_OK;
+        return rc;
+    }
     MK_HIP(hipGetLastError());
     if (mk_ctx().pending_rc != MK_OK) {
         rc = mk_ctx().pending_rc;

@@ -40,13 +40,33 @@ class _LlsBase(KrylovMethod):
                     'The truncated direct error is small enough, given etol    ']
 
     def _lls_diag(self, P, size, which):
+        """M / N for the device loop: the fp64 diagonal of an operator that exposes one (DiagonalOperator,
+        linop.py:473-516; applied inside the kernels), else the callable itself -- the reference applies them as
+        functions, `u = M(Mu)` (lsqr.py:190) -- to be called back on the host at those sites."""
         if P is None:
             return None
         diag = getattr(P, 'diag', None)
         if diag is None or callable(diag):
-            raise NotImplementedError('%s: only diagonal preconditioners (an operator with a `.diag` array) run on the '
-                                      'device path; %s is a %s' % (self.__class__.__name__, which, type(P).__name__))
+            if not callable(P) and not hasattr(P, '__mul__'):
+                raise TypeError('%s: %s must be callable (the reference evaluates `%s(vector)`); got a %s'
+                                % (self.__class__.__name__, which, which, type(P).__name__))
+            return P
         return as_f64_vector(diag, size, which + '.diag')
+
+    @staticmethod
+    def _host_thunk(P, size, errors):
+        def call(user, ip, op_):
+            try:
+                vin = np.ctypeslib.as_array(ctypes.cast(ip, ctypes.POINTER(ctypes.c_double)), shape=(size,)).copy()
+                out = np.asarray(P(vin) if callable(P) else P * vin)
+                if out.shape != (size,):
+                    raise ValueError('preconditioner returned shape %s, expected (%d,)' % (out.shape, size))
+                np.ctypeslib.as_array(ctypes.cast(op_, ctypes.POINTER(ctypes.c_double)), shape=(size,))[:] = out
+                return 0
+            except BaseException as exc:                    # noqa: B902  (must not propagate through the C frames)
+                errors.append(exc)
+                return 1
+        return _lib.PRECON_FN(call)
 
     def _run(self, rhs, itnlim, damp, atol, btol, conlim, M, N, kwargs, x_rows=False):
         A = self._device_operator()
@@ -74,16 +94,24 @@ class _LlsBase(KrylovMethod):
         p.window = int(window)
         handle = ctypes.c_void_p()
         _lib.check(lib.mk_solver_create(A.handle, ctypes.byref(p), ctypes.byref(handle)))
-        d_dm = None if dm is None else _lib.DeviceArray.from_numpy(dm)
-        d_dn = None if dn is None else _lib.DeviceArray.from_numpy(dn)
+        cb_errors = []
+        cb_m = self._host_thunk(dm, m, cb_errors) if (dm is not None and not isinstance(dm, np.ndarray)) else None
+        cb_n = self._host_thunk(dn, n, cb_errors) if (dn is not None and not isinstance(dn, np.ndarray)) else None
+        d_dm = _lib.DeviceArray.from_numpy(dm) if isinstance(dm, np.ndarray) else None
+        d_dn = _lib.DeviceArray.from_numpy(dn) if isinstance(dn, np.ndarray) else None
         try:
             _lib.check(lib.mk_solver_set_transpose(handle, At.handle))
+            if cb_m is not None or cb_n is not None:
+                none = ctypes.cast(None, _lib.PRECON_FN)
+                _lib.check(lib.mk_solver_set_lls_precon_callback(handle, cb_m or none, None, cb_n or none, None))
             if d_dm is not None or d_dn is not None:
                 _lib.check(lib.mk_solver_set_lls_precon(handle, None if d_dm is None else d_dm.ptr,
                                                         None if d_dn is None else d_dn.ptr))
             def chk(rc):
                 if rc != 0 and hasattr(A, 'raise_pending'):
                     A.raise_pending()                         # what a matrix-free operator raised in its callback
+                if rc != 0 and cb_errors:
+                    raise cb_errors[0]                        # ... or M / N in theirs
                 _lib.check(rc)
             chk(lib.mk_solver_setup(handle, d_rhs.ptr, None))
             res = _lib.MkResult()

@@ -134,7 +134,7 @@ def test_lls_edge_cases(golden):
     c = lls.CRAIGMRFramework(op)
     c.solve(d["s_b_cons"])
     assert c.x.shape == (m,)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                          # M is called back with m entries; this one takes n
         s.solve(d["s_b_ls"], M=op)
     with pytest.raises(NotImplementedError):
         s.solve(d["s_b_ls"], wantvar=True)
@@ -187,3 +187,71 @@ def test_lls_diagonal_preconditioners(golden, solver, btag, ptag, monkeypatch):
     for key, v in got.items():
         if key not in ("x", "r", "istop", "itn"):
             assert v == ref[key], key
+
+
+@pytest.mark.parametrize("solver", ["lsqr", "lsmr", "craig", "craigmr"])
+@pytest.mark.parametrize("ptag", ["MN", "M", "N"])
+def test_lls_general_preconditioners_through_callbacks(golden, solver, ptag, monkeypatch):
+    """M and N as arbitrary callables (the reference applies them as functions, `u = M(Mu)`, `v = N(Nv)`:
+    lsqr.py:190,202,254,266): here SPD tridiagonal operators, called back on the host while the loop stays on the
+    device.  Bit equality with the oracle given the same callables and the device's summation order (the inner
+    products that involve a callback's result are re-formed by a stream dot kernel)."""
+    d = golden("lls_precon.npz")
+    A = golden_csr(d, "A_")
+    m, n = A.shape
+    b = d["b_cons"]
+
+    def spd(k, seed):
+        rng = np.random.default_rng(seed)
+        T = np.diag(2.0 + rng.random(k)) + np.diag(-0.5 * np.ones(k - 1), 1) + np.diag(-0.5 * np.ones(k - 1), -1)
+        return T
+    Mm, Nm = spd(m, 1), spd(n, 2)
+    calls = {"M": 0, "N": 0}
+
+    def M(u):
+        calls["M"] += 1
+        return Mm @ u
+
+    def N(v):
+        calls["N"] += 1
+        return Nm @ v
+    kw = {}
+    if "M" in ptag:
+        kw["M"] = M
+    if "N" in ptag:
+        kw["N"] = N
+    got, s = run_device(solver, op_from(A), b, 0.0, 0.0, **kw)
+    dev_calls = dict(calls)
+    monkeypatch.setattr(lls_ref, "_sq", lambda a: a * a)
+
+    class Dots(gpu_order.GpuDots):
+        def __call__(self, a, bb, site):
+            if site.endswith(".beta") and "M" not in ptag:
+                return gpu_order.total(gpu_order.spmv_partials(a, bb, (m + 255) // 256))
+            if (site.endswith(".alpha") or site.endswith(".alpha0")) and "N" not in ptag:
+                return gpu_order.total(gpu_order.spmv_partials(a, bb, (n + 255) // 256))
+            return gpu_order.stream_dot(a, bb)
+    calls.update(M=0, N=0)
+    ref = run_oracle(solver, A, b, 0.0, 0.0, red=kr.Reductions(Dots(0, [])), **kw)
+    assert (got["istop"], got["itn"]) == (ref["istop"], ref["itn"]) and got["itn"] > 5
+    assert np.array_equal(got["x"], ref["x"])
+    # called as often as the reference calls them (once in the setup, once per pass)
+    assert dev_calls == calls, (dev_calls, calls)
+
+
+def test_lls_callback_errors_propagate(golden):
+    from pykrylov_amd import lls
+    d = golden("lls_precon.npz")
+    A = golden_csr(d, "A_")
+
+    def bad(v):
+        if bad.n >= 3:
+            raise RuntimeError("N broke")
+        bad.n += 1
+        return v
+    bad.n = 0
+    s = lls.LSQRFramework(op_from(A))
+    with pytest.raises(RuntimeError, match="N broke"):
+        s.solve(d["b_cons"], N=bad)
+    with pytest.raises(TypeError):
+        lls.LSQRFramework(op_from(A)).solve(d["b_cons"], M=object())
