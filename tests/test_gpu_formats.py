@@ -300,3 +300,51 @@ def test_transpose_with_a_dense_column():
     u = rng.standard_normal(m)
     assert np.array_equal(op.T * u, A.rmatvec(u))
     op.free()
+
+
+def test_resident_tile_format_under_every_kind_of_launch():
+    """Format 3 forced on small matrices, reached through every launch path: composed operators (row program),
+    sums / products of two device matrices (two launches, wrapped epilogues), the fused epilogues and gates of a
+    solver, the transposed matrix of a least-squares solve."""
+    import pykrylov_amd
+    from pykrylov_amd import IdentityOperator, lls
+    from oracle import gpu_order, krylov_ref as kr, lls_ref
+    A = csr_ref.random_diagdom(5003, seed=11)
+    B = csr_ref.random_diagdom(5003, seed=12)
+    n = A.shape[0]
+    opA, opB = op_with_format(A, 3), op_with_format(B, 3)
+    assert fmt_info(opA)["fmt"] == 3 and fmt_info(opB)["fmt"] == 3
+    x = np.random.default_rng(5).standard_normal(n)
+    assert np.array_equal((2.0 * opA - 0.5 * IdentityOperator(n)) * x, 2.0 * A.matvec(x) - 0.5 * x)
+    assert np.array_equal((opA + opB) * x, A.matvec(x) + B.matvec(x))
+    assert np.array_equal((opA - opB) * x, A.matvec(x) - B.matvec(x))
+    assert np.array_equal((opA * opB) * x, A.matvec(B.matvec(x)))
+    rhs = A.matvec(np.ones(n))
+    for solver in ("bicgstab", "cgs", "tfqmr"):
+        cls = {"bicgstab": pykrylov_amd.BiCGSTAB, "cgs": pykrylov_amd.CGS, "tfqmr": pykrylov_amd.TFQMR}[solver]
+        s = cls(opA, reltol=1e-10)
+        s.solve(rhs)
+        ref = getattr(kr, solver)(A, rhs, reltol=1e-10, red=kr.Reductions(
+            gpu_order.GpuDots(n, gpu_order.SPMV_SITES[solver], gpu_order.launch_geometry(opA))))
+        assert s.nMatvec == ref["nMatvec"] and np.array_equal(s.x, ref["x"]), solver
+    # a solver on the sum of the two (second launch carries the fused epilogue)
+    S = opA + opB
+    s = pykrylov_amd.BiCGSTAB(S, reltol=1e-10)
+    s.solve(rhs)
+    assert s.converged and np.linalg.norm(A.matvec(s.x) + B.matvec(s.x) - rhs) <= 1e-8 * np.linalg.norm(rhs)
+    # least squares: A and its transpose both in format 3
+    R = csr_ref.from_coo(*[np.concatenate(c) for c in zip(
+        (np.arange(3000), np.arange(3000), np.ones(3000)),
+        (np.random.default_rng(1).integers(0, 4000, 9000), np.random.default_rng(2).integers(0, 3000, 9000),
+         np.random.default_rng(3).standard_normal(9000)))], (4000, 3000))
+    opR = op_with_format(R, 3)
+    from pykrylov_amd import _lib
+    _lib.check(_lib.init().mk_csr_set_format(opR.T.handle, 3))
+    assert fmt_info(opR)["fmt"] == 3 and fmt_info(opR.T)["fmt"] == 3
+    b = R.matvec(np.ones(3000))
+    s = lls.LSQRFramework(opR)
+    s.solve(b, etol=0.0)
+    ref = lls_ref.lsqr(R.matvec, R.transpose().matvec, R.shape, b.copy(), etol=0.0)
+    assert abs(s.itn - ref["itn"]) <= 1 and np.linalg.norm(s.x - ref["x"]) <= 1e-8 * np.linalg.norm(ref["x"])
+    for o in (opA, opB, opR):
+        o.free()
