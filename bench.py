@@ -295,6 +295,13 @@ def main():
     if world_size != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
     td = torch = None
+    json_out = sys.stdout
+    if world_size > 1:
+        # stdout carries exactly one line, the JSON record: RCCL prints a version banner there (at communicator
+        # teardown), so everything else this process writes to fd 1 is sent to stderr
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     if world_size > 1:
         # torch first: its bundled HIP runtime must be the one the process loads.  gloo only:
         # no second RCCL instance, no torch CUDA context needed for the bootstrap.
@@ -511,7 +518,8 @@ def main():
     if not multi and args.all_configs:
         line.setdefault("extra", {}).update(other_configs(lib))
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if td is not None:
         barrier()
         lib.mk_comm_destroy()
