@@ -41,9 +41,15 @@ struct CgUpdateR {
     const double *dg;                                     // preconditioner diagonal or null
     double alpha;
     bool bad;
+    MkTotalRegs tr;
+    double ry_in;
+    __device__ void early() {
+        mk_total_issue(part, np, tr);
+        ry_in = scal[S_RY0 + par];
+    }
     __device__ bool prologue(double *s4, bool lead) {
-        const double pAp = mk_total(part, np, s4);
-        const double ry = scal[S_RY0 + par];
+        const double pAp = mk_total_finish(tr, np, s4);
+        const double ry = ry_in;
         bad = check_curv && (pAp <= 0.0);                 // cg.py:119-124
         alpha = ry / pAp;                                 // cg.py:127
         if (lead) {
@@ -94,13 +100,22 @@ struct CgUpdateXP {
     const double *r;
     double *p, *x;
     double alpha, beta;
-    __device__ bool prologue(double *s4, bool lead) {
-        const double ry_next = mk_total(part + MK_MAXP, np, s4);
-        const double ry = scal[S_RY0 + par];
+    MkTotalRegs tr;
+    double ry_in, thresh_in;
+    int64_t nmv_in;
+    __device__ void early() {
+        mk_total_issue(part + MK_MAXP, np, tr);
+        ry_in = scal[S_RY0 + par];
         alpha = scal[S_ALPHA];                            // written by K2 of this pass
+        thresh_in = scal[S_THRESH];
+        nmv_in = st->nMatvec;
+    }
+    __device__ bool prologue(double *s4, bool lead) {
+        const double ry_next = mk_total_finish(tr, np, s4);
+        const double ry = ry_in;
         beta = ry_next / ry;                              // cg.py:149
         const double resid = fabs(__dsqrt_rn(ry_next));   // cg.py:154
-        const bool go = (resid > scal[S_THRESH]) && (st->nMatvec < matvec_max);   // cg.py:113
+        const bool go = (resid > thresh_in) && (nmv_in < matvec_max);   // cg.py:113
         if (lead) {
             scal[S_RY0 + (par ^ 1)] = ry_next;            // cg.py:153
             scal[S_RESID] = resid;

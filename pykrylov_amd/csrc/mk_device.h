@@ -927,6 +927,13 @@ struct MkRegsOf<Op, true> {
     using type = typename Op::Regs;
 };
 
+// optional op hook `void early()`: issue (not consume) the loads of the prologue -- partial sums into MkTotalRegs,
+// scalars into members -- so that they travel together with the halt word instead of after it
+template <class Op, class = void>
+struct MkHasEarly : std::false_type {};
+template <class Op>
+struct MkHasEarly<Op, std::void_t<decltype(std::declval<Op &>().early())>> : std::true_type {};
+
 template <class Op>
 __global__ __launch_bounds__(MK_BLOCK) void mk_stream_kernel(Op op, int64_t n, MkHalt halt,
                                                              double *__restrict__ partials) {
@@ -940,7 +947,9 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_stream_kernel(Op op, int64_t n, M
     if constexpr (split) {
         if (has_first) op.load2(2 * g, first);       // in flight while the prologue runs (barriers pin it here)
     }
-    const bool halted = halt.in();
+    const int hword = halt.flags[halt.parity];
+    if constexpr (MkHasEarly<Op>::value) op.early();
+    const bool halted = hword != 0;
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     if (halted) {
         if (lead) halt.out(true);

@@ -207,6 +207,29 @@ __device__ __forceinline__ double mk_total(const double *part, int np, double *s
     return mk_block_sum(v, s4);
 }
 
+// The same total in two steps, for kernels that issue every load of their prologue (halt word, partial sums, scalars)
+// BEFORE waiting for any of them: a dependent chain of three memory round trips (~0.7 us each: the data was written
+// by other XCDs) becomes one.  Identical arithmetic to mk_total.
+struct MkTotalRegs {
+    double t[MK_MAXP / MK_BLOCK];
+};
+__device__ __forceinline__ void mk_total_issue(const double *part, int np, MkTotalRegs &R) {
+#pragma unroll
+    for (int k = 0; k < MK_MAXP / MK_BLOCK; ++k) {
+        const int i = (int)threadIdx.x + k * MK_BLOCK;
+        R.t[k] = part[i < np ? i : 0];
+    }
+}
+__device__ __forceinline__ double mk_total_finish(const MkTotalRegs &R, int np, double *s4) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < MK_MAXP / MK_BLOCK; ++k) {
+        const int i = (int)threadIdx.x + k * MK_BLOCK;
+        v += (i < np) ? R.t[k] : 0.0;
+    }
+    return mk_block_sum(v, s4);
+}
+
 // Halting protocol.  Kernel number q of a solver reads halt[q & 1] and (one thread) writes
 // halt[(q + 1) & 1] = halt_in | new condition, so no kernel reads the word it writes and a
 // raised flag is carried forward by every later kernel, which then does no work: the solver
