@@ -45,7 +45,9 @@ METRIC = "Krylov iters/sec + SpMV achieved HBM GB/s (% of peak), fp64"
 FMT_NAMES = {0: "csr (int32 columns + fp64 values, x gathered)",
              1: "windowed tiles (x windows in LDS, uint16 slots + fp64 values)",
              2: "windowed tiles + value dictionary (one packed 32-bit word per nonzero: LDS slot + value code)",
-             3: "csr, tile resident in LDS, gathers ordered by column block (x longer than an L2)"}
+             3: "csr, tile resident in LDS, gathers ordered by column block (x longer than an L2)",
+             4: "windowed tiles + value dictionary + row patterns (one byte per ROW: the number of its pattern of "
+                "{LDS slot - lane, value code} words)"}
 
 
 def spmv_bytes(nrows, ncols, nnz):

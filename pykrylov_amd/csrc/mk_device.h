@@ -38,7 +38,8 @@ struct MkCsrView {
     int part;
     // windowed tile format (mk_format.hip); fmt 0: none of this is read
     int fmt;                 // 0 plain CSR (gathers), 1 windows + uint16 LDS slots, 2 windows + slots + value dictionary,
-                             // 3 plain CSR with the tile resident in LDS and the gathers ordered by column block
+                             // 3 plain CSR with the tile resident in LDS and the gathers ordered by column block,
+                             // 4 windows + dictionary + one pattern byte per row instead of a word per nonzero
     int wchunks;             // LDS chunks (128 doubles each) reserved for the x windows of a tile
     int ndict;
     const uint16_t *slots;   // per nonzero: position of its x entry in the tile's LDS window buffer
@@ -46,6 +47,11 @@ struct MkCsrView {
     const uint32_t *wn;      // per tile and wave: half lengths of those chunks, one byte each
     const uint32_t *pk;      // fmt 2, per nonzero: {LDS slot : 16 | index of its value in `dict` : 8}
     const double *dict;
+    // fmt 4: per row the number of its pattern; pattern p = words pat[p * pmax ..] = {slot - lane : 16 | code : 8}
+    const uint8_t *pid;
+    const uint32_t *pat;
+    const uint8_t *plen;
+    int npat, pmax;
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
     // column-blocked products (fmt 0, 3): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
@@ -92,7 +98,7 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         if (g3 >= 8) g3 -= g3 % 8;
         return g3;
     }
-    if (P && P->fmt == 2) cap = mk_xcd_chunks(A) ? 1280 : 1024;
+    if (P && (P->fmt == 2 || P->fmt == 4)) cap = mk_xcd_chunks(A) ? 1280 : 1024;
     else if (P && P->fmt == 1) cap = 1024;
     else if (mk_xcd_chunks(A)) cap = 2 * cap > MK_MAXP ? MK_MAXP : 2 * cap;
     g = (int)(A->ntiles > cap ? cap : (A->ntiles < 1 ? 1 : A->ntiles));
@@ -137,6 +143,11 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.wn = P->d_wn;
         v.pk = P->d_pk;
         v.dict = P->d_dict;
+        v.pid = P->d_pid;
+        v.pat = P->d_pat;
+        v.plen = P->d_plen;
+        v.npat = P->npat;
+        v.pmax = P->pmax;
     }
     return v;
 }
@@ -451,18 +462,31 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             if (r < rend) epi.row(r, sum, acc);
             __syncthreads();                                 // the next tile's copies overwrite this LDS
         }
-    } else if constexpr (FMT == 2) {
+    } else if constexpr (FMT == 2 || FMT == 4) {
+        constexpr bool PAT = (FMT == 4);
         // ---- windowed tiles with a value dictionary: ROW PHASE ONLY.  One 32-bit word per nonzero {slot | code};
         // the words and the x windows of a tile go straight to LDS with global_load_lds (no VGPR round trip, no
         // per-nonzero staging work); after one barrier lane t walks row t left to right: word, x and value from LDS
         // (consecutive rows read consecutive words / x entries: conflict free for the usual odd row lengths).
         // Measured against the product-staging design of fmt 1 with the codes: 512^3 1.50 -> 1.32 ms, 2-D n = 1e6
         // 13.1 -> 9.1 us (tools/ubench/spmv_win2.hip, w3 vs w7).
+        // fmt 4 (PAT) goes one step further: a row is described by ONE BYTE, the number of its pattern -- the sequence
+        // of its words relative to the lane, {slot - t, code} -- and the pattern table (<= 8 KB) sits in LDS for the
+        // whole kernel.  The per-nonzero stream and the row pointers are not read at all: what a tile ingests is its
+        // x windows and 256 bytes.
         const int lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        uint32_t *spk = reinterpret_cast<uint32_t *>(xw + 128 * A.wchunks + 2);
+        // fmt 2: a tile's packed words behind its windows.  fmt 4: the pattern table, which lives as long as the kernel
+        // and therefore sits behind everything the gather path of a tile without windows may overwrite
+        const int wtop = 128 * A.wchunks + 2;
+        uint32_t *spk = reinterpret_cast<uint32_t *>(xw + ((PAT && wtop < MK_PROD_LDS) ? MK_PROD_LDS : wtop));
         __shared__ double sdict[256];
         sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // (read after a barrier below)
+        [[maybe_unused]] __shared__ int splen[PAT ? 256 : 1];
+        if constexpr (PAT) {                                 // spk holds the pattern table instead of a tile's words
+            for (int i = tid; i < A.npat * A.pmax; i += MK_BLOCK) spk[i] = A.pat[i];
+            splen[tid] = (tid < A.npat) ? (int)A.plen[tid] : 0;
+        }
         const double d0 = A.dict[0], d1 = A.dict[A.ndict > 1 ? 1 : 0];
         const bool two = A.ndict <= 2;                       // value picked in registers instead of read from LDS
         // this wave's window descriptor of a tile (scalar loads, issued one tile ahead like the row pointers)
@@ -481,7 +505,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         };
         MkTileMeta cur, nxt;
         Desc dcur, dnxt;
-        load_meta(pos, cur);
+        if constexpr (!PAT) load_meta(pos, cur);
         load_desc(pos, dcur);
         for (; pos < end; pos += stride) {
             const int64_t tile = mk_tile_at(A, pos);
@@ -506,23 +530,40 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                                                          16, 0, 0);
                     }
                 }
-                const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
-                const int base = p_lo & ~3, cnt = p_hi - base;             // 0 < cnt <= MK_SPMV_TILE + 3 (builder)
+                int lo = 0, len = 0;
+                if constexpr (PAT) {
+                    const unsigned id = (r < rend) ? (unsigned)A.pid[r] : 0u;   // one byte per row
+                    load_desc(pos + stride, dnxt);           // next tile's descriptor goes in flight
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    lo = (int)id * A.pmax;
+                    len = (r < rend) ? splen[id] : 0;
+                } else {
+                    const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
+                    const int base = p_lo & ~3, cnt = p_hi - base;         // 0 < cnt <= MK_SPMV_TILE + 3 (builder)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {                                // 256 words per wave-level copy
-                    const int c0 = (wv + 4 * c) * 256;
-                    if (c0 < cnt)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.pk + base + c0 + 4 * lane),
-                                                         (__attribute__((address_space(3))) void *)(spk + c0), 16, 0, 0);
+                    for (int c = 0; c < 3; ++c) {                            // 256 words per wave-level copy
+                        const int c0 = (wv + 4 * c) * 256;
+                        if (c0 < cnt)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.pk + base + c0 + 4 * lane),
+                                                             (__attribute__((address_space(3))) void *)(spk + c0), 16, 0, 0);
+                    }
+                    load_meta(pos + stride, nxt);            // next tile's row pointers and descriptor go in flight
+                    load_desc(pos + stride, dnxt);
+                    sptr[tid] = my_lo;
+                    if (tid == 0) sptr[MK_BLOCK] = p_hi;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    const int my_hi = sptr[tid + 1];
+                    lo = my_lo - base;
+                    len = my_hi - my_lo;
                 }
-                load_meta(pos + stride, nxt);                // next tile's row pointers and descriptor go in flight
-                load_desc(pos + stride, dnxt);
-                sptr[tid] = my_lo;
-                if (tid == 0) sptr[MK_BLOCK] = p_hi;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                const int my_hi = sptr[tid + 1];
-                const int lo = my_lo - base, len = my_hi - my_lo;
+                // the LDS position of entry k's x value: its slot (fmt 2), or this lane plus the pattern's relative
+                // slot (fmt 4; entries past the row's end read position 0 and are masked below)
+                auto slot_of = [&](unsigned w, int k) -> unsigned {
+                    if constexpr (PAT) return (k < len) ? (unsigned)(tid + (int)(short)(w & 0xffffu)) : 0u;
+                    else return w & 0xffffu;
+                };
                 unsigned wk[8];
                 double xk[8], vk[8];
 #pragma unroll
@@ -530,13 +571,13 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                 if (two) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        xk[k] = epi.xin(xw[wk[k] & 0xffffu]);
+                        xk[k] = epi.xin(xw[slot_of(wk[k], k)]);
                         vk[k] = (wk[k] >> 16) ? d1 : d0;
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        xk[k] = epi.xin(xw[wk[k] & 0xffffu]);
+                        xk[k] = epi.xin(xw[slot_of(wk[k], k)]);
                         vk[k] = sdict[wk[k] >> 16];
                     }
                 }
@@ -547,11 +588,12 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                 }
                 for (int k = 8; k < len; ++k) {
                     const unsigned w = spk[lo + k];
-                    sum += sdict[w >> 16] * epi.xin(xw[w & 0xffffu]);
+                    sum += sdict[w >> 16] * epi.xin(xw[slot_of(w, k)]);
                 }
                 __syncthreads();                             // the next tile's copies overwrite this LDS
             } else {
-                load_meta(pos + stride, nxt);
+                if constexpr (PAT) load_meta(pos, cur);      // (tiles without windows are rare: their row pointers now)
+                else load_meta(pos + stride, nxt);
                 load_desc(pos + stride, dnxt);
                 sum = mk_tile_gather(A, x, epi, prod, sptr, cur);
             }
@@ -700,7 +742,7 @@ __global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : 4) void mk_s
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
     extern __shared__ __attribute__((aligned(16))) double mk_smem[];
     double *prod = mk_smem;
-    double *xw = (FMT == 2) ? mk_smem : mk_smem + MK_PROD_LDS;
+    double *xw = (FMT == 2 || FMT == 4) ? mk_smem : mk_smem + MK_PROD_LDS;
     __shared__ double s4[4];
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -757,7 +799,12 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         const size_t w = sizeof(double) * (size_t)(128 * v.wchunks + 2) + sizeof(uint32_t) * (MK_SPMV_TILE + 16);
         lds = w > lds ? w : lds;
     }
-    if (v.fmt == 3) {                                        // the tile's values and columns
+    if (v.fmt == 4) {                                        // windows + pattern table, or the gather path's products
+        const size_t wtop = (size_t)(128 * v.wchunks + 2) > (size_t)MK_PROD_LDS ? (size_t)(128 * v.wchunks + 2) : (size_t)MK_PROD_LDS;
+        lds = sizeof(double) * wtop + sizeof(uint32_t) * (size_t)(v.npat * v.pmax + 16);
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 4>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                           halt, partials);
+    } else if (v.fmt == 3) {                                 // the tile's values and columns
         lds = (size_t)v.rt_cap * 12;
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 3>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                            halt, partials);

@@ -214,6 +214,121 @@ __global__ __launch_bounds__(MK_BLOCK) void dict_encode(int64_t nnz, const doubl
     }
 }
 
+// ------------------------------------------------------------------------------------------------ row patterns
+// fmt 4.  In a dictionary matrix the packed word of a nonzero is {LDS slot, value code}; relative to the row's lane t
+// the word {slot - t, code} is the same for every row of a regular stencil, so a ROW is described by the sequence of
+// its relative words -- its pattern -- and a matrix with few distinct patterns (27 boundary cases of a 7-point
+// stencil, times the few window layouts a tile can have) by ONE BYTE per row instead of one word per nonzero.
+// Patterns are collected as 64-bit hashes in the same open-addressing set as the values, numbered in ascending hash
+// order, written into a table of `pmax` words per pattern and then VERIFIED row by row against the table, so that a
+// hash collision can only make the builder give up, never change a product.
+constexpr int PAT_WORDS = 2048;                              // table capacity in words (npat * pmax)
+
+__device__ inline int pat_row_words(const int32_t *__restrict__ ip, const uint32_t *__restrict__ pk, int64_t r, int t,
+                                    int pmax, uint32_t *w) {
+    const int lo = ip[r], len = ip[r + 1] - lo;
+    if (len > pmax) return -1;
+    for (int k = 0; k < len; ++k) {
+        const uint32_t word = pk[lo + k];
+        w[k] = ((word & 0xffffu) - (uint32_t)t) & 0xffffu;
+        w[k] |= (word >> 16) << 16;
+    }
+    return len;
+}
+
+__device__ inline unsigned long long pat_hash(int len, const uint32_t *w) {
+    unsigned long long h = 0xcbf29ce484222325ULL ^ (unsigned long long)len;
+    for (int k = 0; k < len; ++k) {
+        h ^= (unsigned long long)w[k];
+        h *= 0x100000001b3ULL;
+        h ^= h >> 29;
+    }
+    return h == DICT_EMPTY ? h ^ 1ULL : h;
+}
+
+// state: [0] distinct keys, [1] failure flag
+__device__ inline void set_insert(unsigned long long *table, int *state, unsigned long long key, int limit) {
+    unsigned h = dict_hash(key);
+    for (int probe = 0; probe < DICT_SLOTS; ++probe) {
+        unsigned long long cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == DICT_EMPTY) {
+            cur = atomicCAS(&table[h], DICT_EMPTY, key);
+            if (cur == DICT_EMPTY) {
+                if (atomicAdd(&state[0], 1) + 1 > limit) state[1] = 1;
+                cur = key;
+            }
+        }
+        if (cur == key) return;
+        h = (h + 1) & (DICT_SLOTS - 1);
+    }
+    state[1] = 1;
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void pat_maxlen(int64_t nrows, const int32_t *__restrict__ ip,
+                                                       const int32_t *__restrict__ wg, int *__restrict__ out) {
+    int mx = 0;
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        if (!(wg[(r / MK_ROWS_PER_TILE) * 16] & 1)) continue;          // rows of windowed tiles only
+        const int len = ip[r + 1] - ip[r];
+        mx = len > mx ? len : mx;
+    }
+    atomicMax(out, mx);
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void pat_collect(int64_t nrows, const int32_t *__restrict__ ip,
+                                                        const int32_t *__restrict__ wg, const uint32_t *__restrict__ pk,
+                                                        int pmax, int limit, unsigned long long *table, int *state) {
+    unsigned long long seen = DICT_EMPTY;
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        if (!(wg[(r / MK_ROWS_PER_TILE) * 16] & 1)) continue;
+        if (__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        uint32_t w[32];
+        const int len = pat_row_words(ip, pk, r, (int)(r % MK_ROWS_PER_TILE), pmax, w);
+        if (len < 0) {
+            state[1] = 1;
+            return;
+        }
+        const unsigned long long key = pat_hash(len, w);
+        if (key == seen) continue;
+        set_insert(table, state, key, limit);
+        seen = key;
+    }
+}
+
+// mode 0: number the rows and fill the table (identical writes race benignly); mode 1: compare every row with it
+__global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int32_t *__restrict__ ip,
+                                                       const int32_t *__restrict__ wg, const uint32_t *__restrict__ pk,
+                                                       int pmax, int count, const double *__restrict__ sorted_keys,
+                                                       uint8_t *__restrict__ pid, uint32_t *__restrict__ pat,
+                                                       uint8_t *__restrict__ plen, int mode, int *state) {
+    __shared__ unsigned long long k[256];
+    k[threadIdx.x] = (threadIdx.x < count) ? (unsigned long long)__double_as_longlong(sorted_keys[threadIdx.x]) : ~0ULL;
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        if (!(wg[(r / MK_ROWS_PER_TILE) * 16] & 1)) {
+            if (mode == 0) pid[r] = 0;
+            continue;
+        }
+        uint32_t w[32];
+        const int len = pat_row_words(ip, pk, r, (int)(r % MK_ROWS_PER_TILE), pmax, w);
+        if (mode == 0) {
+            const unsigned long long key = pat_hash(len, w);
+            int lo = 0;
+#pragma unroll
+            for (int step = 128; step >= 1; step >>= 1)
+                if (lo + step < 256 && k[lo + step] <= key) lo += step;
+            pid[r] = (uint8_t)lo;
+            plen[lo] = (uint8_t)len;
+            for (int q = 0; q < pmax; ++q) pat[lo * pmax + q] = (q < len) ? w[q] : 0u;
+        } else {
+            const int id = pid[r];
+            bool same = (plen[id] == len);
+            for (int q = 0; q < len && same; ++q) same = (pat[id * pmax + q] == w[q]);
+            if (!same) state[1] = 1;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ column blocks
 constexpr int CB_MAX = 8;
 struct CbPtrs {
@@ -268,14 +383,17 @@ void plan_free(MkPlan &P) {
     hipFree(P.d_wn);
     hipFree(P.d_pk);
     hipFree(P.d_dict);
+    hipFree(P.d_pid);
+    hipFree(P.d_pat);
+    hipFree(P.d_plen);
     P = MkPlan();
 }
 
 int default_format() {
     static int f = [] {
         const char *e = getenv("MK_SPMV_FORMAT");
-        int v = e ? atoi(e) : 2;
-        return v < 0 ? 0 : (v > 3 ? 3 : v);
+        int v = e ? atoi(e) : 4;
+        return v < 0 ? 0 : (v > 4 ? 4 : v);
     }();
     return f;
 }
@@ -392,6 +510,78 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     return MK_OK;
 }
 
+// fmt 2 -> fmt 4 when every row of every windowed tile follows one of a few patterns (see above).  Any failure leaves
+// the matrix in fmt 2.
+void pattern_plan(const mk_csr *A, MkPlan &P) {
+    if (getenv("MK_NO_PATTERNS")) return;
+    hipStream_t st = mk_ctx().stream;
+    int *d_state = nullptr;
+    unsigned long long *d_table = nullptr;
+    double *d_keys = nullptr;
+    uint8_t *d_pid = nullptr, *d_plen = nullptr;
+    uint32_t *d_pat = nullptr;
+    auto cleanup = [&]() {
+        hipFree(d_state);
+        hipFree(d_table);
+        hipFree(d_keys);
+        hipFree(d_pid);
+        hipFree(d_plen);
+        hipFree(d_pat);
+    };
+    int h_state[2] = {0, 0};
+    int grid = (int)((A->nrows + MK_BLOCK - 1) / MK_BLOCK);
+    grid = grid > 4096 ? 4096 : (grid < 1 ? 1 : grid);
+    if (hipMalloc((void **)&d_state, 2 * sizeof(int)) != hipSuccess) return cleanup();
+    hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
+    hipLaunchKernelGGL(pat_maxlen, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, d_state);
+    if (hipMemcpyAsync(h_state, d_state, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return cleanup();
+    const int maxlen = h_state[0];
+    const int pmax = maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : (maxlen <= 32 ? 32 : 0));
+    if (pmax == 0 || maxlen < 1) return cleanup();
+    const int limit = PAT_WORDS / pmax > 256 ? 256 : PAT_WORDS / pmax;
+    std::vector<unsigned long long> empty(DICT_SLOTS, DICT_EMPTY);
+    if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS) != hipSuccess ||
+        hipMalloc((void **)&d_keys, sizeof(double) * 256) != hipSuccess ||
+        hipMalloc((void **)&d_pid, (size_t)A->nrows + 16) != hipSuccess ||
+        hipMalloc((void **)&d_plen, 256) != hipSuccess ||
+        hipMalloc((void **)&d_pat, sizeof(uint32_t) * PAT_WORDS) != hipSuccess)
+        return cleanup();
+    hipMemcpyAsync(d_table, empty.data(), sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyHostToDevice, st);
+    hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
+    hipMemsetAsync(d_pat, 0, sizeof(uint32_t) * PAT_WORDS, st);
+    hipMemsetAsync(d_plen, 0, 256, st);
+    hipLaunchKernelGGL(pat_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, P.d_pk, pmax, limit,
+                       d_table, d_state);
+    if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess || h_state[1] || h_state[0] < 1 || h_state[0] > limit)
+        return cleanup();
+    const int count = h_state[0];
+    hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_keys);
+    for (int mode = 0; mode < 2; ++mode)
+        hipLaunchKernelGGL(pat_assign, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, P.d_pk, pmax, count,
+                           d_keys, d_pid, d_pat, d_plen, mode, d_state);
+    if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess || h_state[1])
+        return cleanup();
+    P.d_pid = d_pid;
+    P.d_pat = d_pat;
+    P.d_plen = d_plen;
+    d_pid = nullptr;
+    d_pat = nullptr;
+    d_plen = nullptr;
+    P.npat = count;
+    P.pmax = pmax;
+    P.fmt = 4;
+    // the per-nonzero streams are not read any more (tiles without windows gather from the CSR arrays)
+    hipFree(P.d_pk);
+    hipFree(P.d_slots);
+    P.d_pk = nullptr;
+    P.d_slots = nullptr;
+    cleanup();
+}
+
 int plan_build(const mk_csr *A) {
     MkPlan &P = A->plan;
     P.built = true;
@@ -477,8 +667,10 @@ int plan_build(const mk_csr *A) {
                        P.d_pk);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail("dictionary encode");
     hipFree(d_table);
+    d_table = nullptr;
     P.ndict = h_state[0];
     P.fmt = 2;
+    if (want >= 4) pattern_plan(A, P);
     return MK_OK;
 }
 
@@ -496,7 +688,7 @@ void mk_csr_plan_reset(const mk_csr *A) {
 
 extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {
     MK_REQUIRE_INIT();
-    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 3);
+    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 4);
     if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_format: set the format on the matrix a composed operator was built from");
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
@@ -510,8 +702,9 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
     if (fmt) *fmt = P->fmt;
-    if (tiles_windowed) *tiles_windowed = (P->fmt == 1 || P->fmt == 2) ? P->covered : 0;
-    if (lds_chunks) *lds_chunks = (P->fmt == 1 || P->fmt == 2) ? P->wchunks : (P->fmt == 3 ? P->rt_k : 0);
+    const bool windowed = (P->fmt == 1 || P->fmt == 2 || P->fmt == 4);
+    if (tiles_windowed) *tiles_windowed = windowed ? P->covered : 0;
+    if (lds_chunks) *lds_chunks = windowed ? P->wchunks : (P->fmt == 3 ? P->rt_k : 0);
     if (dict_size) *dict_size = P->ndict;
     if (matrix_bytes_per_product) {
         // bytes of matrix data one product streams from HBM (x and y not included): per nonzero 4 + 8 (CSR),
@@ -521,8 +714,10 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
         else {
             // nonzeros of windowed tiles are not kept; the mixed case is bounded by the covered share
             const double share = A->ntiles ? (double)P->covered / (double)A->ntiles : 0.0;
-            const double per = (P->fmt == 2) ? 4.0 : 10.0;
+            // (fmt 4: one byte per ROW and no row pointers for the windowed tiles)
+            const double per = (P->fmt == 4) ? 0.0 : ((P->fmt == 2) ? 4.0 : 10.0);
             b += (int64_t)(A->nnz * (share * per + (1.0 - share) * 12.0)) + 80 * A->ntiles;
+            if (P->fmt == 4) b += (int64_t)(share * (double)A->nrows) - (int64_t)(share * 4.0 * (double)(A->nrows + 1));
         }
         *matrix_bytes_per_product = b;
     }

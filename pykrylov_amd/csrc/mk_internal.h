@@ -95,7 +95,8 @@ constexpr int MK_WCHUNKS_MAX = 16; // chunks per tile (4 per wave): 16 KiB of LD
 struct MkPlan {
     bool built = false;
     int fmt = 0;                   // 0 plain CSR, 1 windows + uint16 slots, 2 windows + slots + value dictionary,
-                                   // 3 plain CSR, tile resident in LDS, gathers ordered by column block
+                                   // 3 plain CSR, tile resident in LDS, gathers ordered by column block,
+                                   // 4 windows + dictionary + row patterns (one byte per row)
     int wchunks = 0;               // max chunks of a tile
     int ndict = 0;
     int64_t covered = 0;           // tiles on the windowed path
@@ -104,6 +105,11 @@ struct MkPlan {
     uint32_t *d_wn = nullptr;
     uint32_t *d_pk = nullptr;      // fmt 2: {slot | code << 16} per nonzero
     double *d_dict = nullptr;
+    // fmt 4 (row patterns): one byte per row, a table of `pmax` words per pattern (mk_format.hip)
+    uint8_t *d_pid = nullptr;
+    uint32_t *d_pat = nullptr;
+    uint8_t *d_plen = nullptr;
+    int npat = 0, pmax = 0;
     // fmt 3 (resident tiles, column phases): plain CSR arrays, only launch parameters
     int rt_cap = 0;                // LDS capacity per tile in nonzeros (max tile stream length rounded up to 256)
     int rt_k = 1;                  // column phases

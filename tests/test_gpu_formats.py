@@ -1,5 +1,5 @@
 """The storage formats of the SpMV (csrc/mk_format.hip, mk_device.h): plain CSR gathers (0), windowed tiles (1),
-windowed tiles + value dictionary (2), LDS-resident tiles with column phases (3).  Whatever format a tile ends up in, the product must be BIT-identical to the
+windowed tiles + value dictionary (2), LDS-resident tiles with column phases (3), row patterns (4).  Whatever format a tile ends up in, the product must be BIT-identical to the
 scalar left-to-right CSR loop of the oracle -- including matrices that mix eligible and ineligible tiles, so that
 both code paths run inside one launch and hand over to each other."""
 import ctypes
@@ -145,6 +145,63 @@ def test_resident_tile_phase_counts(phases, monkeypatch):
     assert "FMT 3 %s" % phases in p.stdout, p.stdout
 
 
+# what the pattern builder (format 4) makes of the test matrices when asked: 4 where every row of every windowed tile
+# has <= 32 entries and the rows fall into <= 256 / 128 / 64 patterns, else the request degrades to the dictionary format
+# (banded_dict: random value codes, 4^5 combinations per offset pattern -- too many)
+PATTERNED = {"banded_dict": 2, "banded_manyvalues": 1, "banded_plus_dense_rows": 1, "banded_plus_scattered_block": None,
+             "rect_odd_cols": None, "empty_rows_and_tiles": None, "random": 0, "distinct_256": None, "distinct_257": 1}
+
+
+@pytest.mark.parametrize("name", sorted(MATS))
+def test_row_pattern_format_bit_exact(name):
+    """Format 4: one pattern byte per row instead of one packed word per nonzero.  Whatever the builder decides
+    (patterns, or falling back to 2 / 1 / 0), the product keeps the scalar loop's bits -- also through the transpose."""
+    A, best = MATS[name]
+    op = op_with_format(A, 4)
+    info = fmt_info(op)
+    assert info["fmt"] in ((4, 2) if best == 2 else (best,)), (name, info)
+    if PATTERNED[name] is not None:
+        assert info["fmt"] == PATTERNED[name], (name, info)
+    rng = np.random.default_rng(3)
+    for x in (np.ones(A.shape[1]), rng.standard_normal(A.shape[1]), 1e200 * rng.standard_normal(A.shape[1])):
+        assert np.array_equal(op * x, A.matvec(x))
+    u = rng.standard_normal(A.shape[0])
+    assert np.array_equal(op.T * u, A.rmatvec(u))
+    op.free()
+
+
+def test_row_patterns_on_stencils():
+    """The matrices the format is made for: 5- and 7-point stencils (all BASELINE configs), shifted, composed,
+    with ragged last tiles; and a matrix with a few longer rows (16-word patterns)."""
+    from pykrylov_amd import CsrOperator, IdentityOperator, gallery
+    rng = np.random.default_rng(0)
+    for A in (csr_ref.poisson2d(150), csr_ref.poisson3d(30), csr_ref.poisson3d(17, 23, 9), csr_ref.poisson1d(70001)):
+        op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
+        info = fmt_info(op)
+        assert info["fmt"] == 4 and info["bytes"] < 4 * A.nnz, info      # (less than the dictionary format streams)
+        x = rng.standard_normal(A.shape[1])
+        assert np.array_equal(op * x, A.matvec(x))
+        sh = op - 1.5 * IdentityOperator(A.shape[0])
+        assert np.array_equal(sh * x, A.matvec(x) - 1.5 * x)
+        op.free()
+    # rows longer than 8 entries use 16-word patterns: a tridiagonal matrix whose every 16th row carries 12 entries
+    n = 20000
+    r, c, v = banded(n, (-1, 0, 1), rng, few_values=True)
+    v[:] = np.where(r == c, 4.0, -1.0)
+    long_rows = np.arange(32, n - 32, 16)
+    offs = np.array([-9, -7, -5, -4, -3, 3, 4, 5, 7], dtype=np.int64)
+    r2 = np.repeat(long_rows, len(offs))
+    c2 = (long_rows[:, None] + offs[None, :]).ravel()
+    L = csr_ref.from_coo(np.concatenate([r, r2]), np.concatenate([c, c2]),
+                         np.concatenate([v, np.full(len(r2), 0.5)]), (n, n))
+    op = CsrOperator(L.indptr, L.indices, L.data, L.shape)
+    info = fmt_info(op)
+    assert info["fmt"] == 4 and int(np.max(np.diff(L.indptr))) == 12, info
+    x = rng.standard_normal(n)
+    assert np.array_equal(op * x, L.matvec(x)) and np.array_equal(op.T * x, L.rmatvec(x))
+    op.free()
+
+
 def test_mixed_tiles_really_mix():
     A, _ = MATS["banded_plus_dense_rows"]
     op = op_with_format(A, 1)
@@ -153,9 +210,9 @@ def test_mixed_tiles_really_mix():
     op.free()
 
 
-@pytest.mark.parametrize("fmt", [0, 1, 2])
+@pytest.mark.parametrize("fmt", [0, 1, 2, 4])
 def test_solver_results_do_not_depend_on_the_format(fmt):
-    """CG on a 2-D Poisson matrix: identical bits (history, iterate) in all three formats."""
+    """CG on a 2-D Poisson matrix: identical bits (history, iterate) in all windowed formats."""
     from pykrylov_amd import CG
     A = csr_ref.poisson2d(150)
     rhs = A.matvec(np.ones(A.shape[0]))
@@ -178,7 +235,7 @@ def test_transpose_and_composed_operators_use_the_format():
     op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
     x = np.random.default_rng(1).standard_normal(A.shape[0])
     assert np.array_equal(op.T * x, A.rmatvec(x))
-    assert fmt_info(op.T)["fmt"] == 2
+    assert fmt_info(op.T)["fmt"] in (2, 4)                          # (4 when the rows follow few enough patterns)
     shifted = op - 1.5 * IdentityOperator(A.shape[0])
     assert np.array_equal(shifted * x, A.matvec(x) - 1.5 * x)
     op.free()
