@@ -52,6 +52,7 @@ struct MkCsrView {
     const uint32_t *pat;
     const uint8_t *plen;
     int npat, pmax;
+    int allwin;              // every tile of the matrix has windows (no tile ever takes the gather path)
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
     // column-blocked products (fmt 0, 3): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
@@ -86,7 +87,9 @@ int mk_host_product(const mk_csr *A, hipStream_t st);   // mk_core.hip: D2H, hos
 // SpMV grid = the workgroups that are resident at once (persistent tiles; a second round only adds a tail).
 // CSR path: 4 per CU at <= 64 registers, twice as many smaller shares while the problem is cache resident.
 // Windowed paths: 4 per CU (1024 workgroups); the dictionary kernel takes 5 per CU while the problem is cache
-// resident -- measured on 512^3 and 2-D n = 1e6 (tools/sweep_fmt.sh): every other count loses 5-25 %.
+// resident -- measured on 512^3 and 2-D n = 1e6 (tools/sweep_fmt.sh): every other count loses 5-25 %.  The pattern
+// kernel (fmt 4) ingests so little per tile that it is bound by the latency of its window copies: 7 per CU
+// (512^3: 1024 / 1536 / 1792 workgroups -> 1.26 / 1.01 / 0.91 ms).
 static inline int mk_grid_spmv_for(const mk_csr *A) {
     if (A->comp_kind) return mk_grid_spmv_for(A->comp_kind == 3 ? A->comp_a : A->comp_b);   // the final launch's matrix
     int g = mk_grid_spmv(A->ntiles);
@@ -98,7 +101,8 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         if (g3 >= 8) g3 -= g3 % 8;
         return g3;
     }
-    if (P && (P->fmt == 2 || P->fmt == 4)) cap = mk_xcd_chunks(A) ? 1280 : 1024;
+    if (P && P->fmt == 4) cap = 1792;                        // 7 per CU: what LDS (<= 22 KB) and registers allow
+    else if (P && P->fmt == 2) cap = mk_xcd_chunks(A) ? 1280 : 1024;
     else if (P && P->fmt == 1) cap = 1024;
     else if (mk_xcd_chunks(A)) cap = 2 * cap > MK_MAXP ? MK_MAXP : 2 * cap;
     g = (int)(A->ntiles > cap ? cap : (A->ntiles < 1 ? 1 : A->ntiles));
@@ -148,6 +152,7 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.plen = P->d_plen;
         v.npat = P->npat;
         v.pmax = P->pmax;
+        v.allwin = (P->covered == A->ntiles) ? 1 : 0;
     }
     return v;
 }
@@ -478,8 +483,9 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         // fmt 2: a tile's packed words behind its windows.  fmt 4: the pattern table, which lives as long as the kernel
         // and therefore sits behind everything the gather path of a tile without windows may overwrite
+        // (unless every tile has windows: then the gather path never runs, A.allwin)
         const int wtop = 128 * A.wchunks + 2;
-        uint32_t *spk = reinterpret_cast<uint32_t *>(xw + ((PAT && wtop < MK_PROD_LDS) ? MK_PROD_LDS : wtop));
+        uint32_t *spk = reinterpret_cast<uint32_t *>(xw + ((PAT && !A.allwin && wtop < MK_PROD_LDS) ? MK_PROD_LDS : wtop));
         __shared__ double sdict[256];
         sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // (read after a barrier below)
         [[maybe_unused]] __shared__ int splen[PAT ? 256 : 1];
@@ -736,7 +742,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : 4) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : (FMT == 4 ? 7 : 4)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
@@ -800,7 +806,8 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         lds = w > lds ? w : lds;
     }
     if (v.fmt == 4) {                                        // windows + pattern table, or the gather path's products
-        const size_t wtop = (size_t)(128 * v.wchunks + 2) > (size_t)MK_PROD_LDS ? (size_t)(128 * v.wchunks + 2) : (size_t)MK_PROD_LDS;
+        size_t wtop = (size_t)(128 * v.wchunks + 2);
+        if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
         lds = sizeof(double) * wtop + sizeof(uint32_t) * (size_t)(v.npat * v.pmax + 16);
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 4>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                            halt, partials);
