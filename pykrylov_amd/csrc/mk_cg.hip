@@ -27,6 +27,12 @@ struct CgSpmvEpi {
         Ap[r] = s;
         acc[0] += pr * s;
     }
+    // p is the product's input vector: where the kernel has p[r] at hand (pattern format: the tile's LDS window) it
+    // passes it instead of `pre` loading it again -- one stream of n doubles less per product
+    __device__ void row_x(int64_t r, double s, double xr, double *acc) {
+        Ap[r] = s;
+        acc[0] += xr * s;
+    }
 };
 
 struct CgUpdateR {

@@ -234,6 +234,14 @@ template <class Epi, class = void>
 struct MkHasPre : std::false_type {};
 template <class Epi>
 struct MkHasPre<Epi, std::void_t<decltype(std::declval<Epi &>().pre((int64_t)0))>> : std::true_type {};
+// optional epilogue hook `void row_x(int64_t r, double s, double xr, double *acc)`: an epilogue whose own vector IS the
+// product's input (CG: <p, Ap>) takes x[r] from the kernel -- in the pattern format it sits in the tile's LDS window --
+// instead of loading it a second time through `pre`
+template <class Epi, class = void>
+struct MkHasRowX : std::false_type {};
+template <class Epi>
+struct MkHasRowX<Epi, std::void_t<decltype(std::declval<Epi &>().row_x((int64_t)0, 0.0, 0.0, (double *)nullptr))>>
+    : std::true_type {};
 
 typedef unsigned mk_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned mk_u4 __attribute__((ext_vector_type(4)));
@@ -491,7 +499,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         [[maybe_unused]] __shared__ int splen[PAT ? 256 : 1];
         if constexpr (PAT) {                                 // spk holds the pattern table instead of a tile's words
             for (int i = tid; i < A.npat * A.pmax; i += MK_BLOCK) spk[i] = A.pat[i];
-            splen[tid] = (tid < A.npat) ? (int)A.plen[tid] : 0;
+            splen[tid] = (tid < A.npat) ? ((int)A.plen[tid] | ((int)A.plen[256 + tid] << 8)) : (255 << 8);
         }
         const double d0 = A.dict[0], d1 = A.dict[A.ndict > 1 ? 1 : 0];
         const bool two = A.ndict <= 2;                       // value picked in registers instead of read from LDS
@@ -518,11 +526,13 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             const int64_t r0 = tile * MK_ROWS_PER_TILE;
             const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
             const int64_t r = r0 + tid;
-            if constexpr (MkHasPre<Epi>::value) {
+            constexpr bool ROWX = PAT && !PROG && MkHasRowX<Epi>::value;
+            if constexpr (MkHasPre<Epi>::value && !ROWX) {
                 if (r < rend) epi.pre(r);
             }
             const mk_i4 g = dcur.g;
             double sum = 0.0;
+            [[maybe_unused]] double xr_cur = 0.0;
             if (g.x & 1) {
                 const unsigned nvw = dcur.nvw;
                 const int gs[4] = {g.x & ~1, g.y, g.z, g.w};
@@ -537,13 +547,15 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                     }
                 }
                 int lo = 0, len = 0;
+                [[maybe_unused]] int kdiag = 255;
                 if constexpr (PAT) {
                     const unsigned id = (r < rend) ? (unsigned)A.pid[r] : 0u;   // one byte per row
                     load_desc(pos + stride, dnxt);           // next tile's descriptor goes in flight
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     lo = (int)id * A.pmax;
-                    len = (r < rend) ? splen[id] : 0;
+                    len = (r < rend) ? (splen[id] & 0xff) : 0;
+                    kdiag = splen[id] >> 8;
                 } else {
                     const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
                     const int base = p_lo & ~3, cnt = p_hi - base;         // 0 < cnt <= MK_SPMV_TILE + 3 (builder)
@@ -596,8 +608,15 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                     const unsigned w = spk[lo + k];
                     sum += sdict[w >> 16] * epi.xin(xw[slot_of(w, k)]);
                 }
+                if constexpr (ROWX) {                        // x[r] for the epilogue: the diagonal entry's LDS slot
+                    if (kdiag < len) xr_cur = epi.xin(xw[(unsigned)(tid + (int)(short)(spk[lo + kdiag] & 0xffffu))]);
+                    else if (r < rend) xr_cur = epi.xin(x[r]);
+                }
                 __syncthreads();                             // the next tile's copies overwrite this LDS
             } else {
+                if constexpr (ROWX) {
+                    if (r < rend) xr_cur = epi.xin(x[r]);
+                }
                 if constexpr (PAT) load_meta(pos, cur);      // (tiles without windows are rare: their row pointers now)
                 else load_meta(pos + stride, nxt);
                 load_desc(pos + stride, dnxt);
@@ -606,7 +625,11 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
             if constexpr (PROG) {
                 if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
             }
-            if (r < rend) epi.row(r, sum, acc);
+            if constexpr (ROWX) {
+                if (r < rend) epi.row_x(r, sum, xr_cur, acc);
+            } else {
+                if (r < rend) epi.row(r, sum, acc);
+            }
             cur = nxt;
             dcur = dnxt;
         }

@@ -296,7 +296,10 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_collect(int64_t nrows, const int
 }
 
 // mode 0: number the rows and fill the table (identical writes race benignly); mode 1: compare every row with it
+// plen[p] = entries of pattern p, plen[256 + p] = position of the DIAGONAL entry in it (255: none) -- the kernel hands
+// x[r] to epilogues that ask for it from the LDS window instead of loading it again
 __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int32_t *__restrict__ ip,
+                                                       const int32_t *__restrict__ ix,
                                                        const int32_t *__restrict__ wg, const uint32_t *__restrict__ pk,
                                                        int pmax, int count, const double *__restrict__ sorted_keys,
                                                        uint8_t *__restrict__ pid, uint32_t *__restrict__ pat,
@@ -311,6 +314,9 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
         }
         uint32_t w[32];
         const int len = pat_row_words(ip, pk, r, (int)(r % MK_ROWS_PER_TILE), pmax, w);
+        int kd = 255;
+        for (int q = 0; q < len; ++q)
+            if ((int64_t)ix[ip[r] + q] == r) kd = q;
         if (mode == 0) {
             const unsigned long long key = pat_hash(len, w);
             int lo = 0;
@@ -319,10 +325,11 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
                 if (lo + step < 256 && k[lo + step] <= key) lo += step;
             pid[r] = (uint8_t)lo;
             plen[lo] = (uint8_t)len;
+            plen[256 + lo] = (uint8_t)kd;
             for (int q = 0; q < pmax; ++q) pat[lo * pmax + q] = (q < len) ? w[q] : 0u;
         } else {
             const int id = pid[r];
-            bool same = (plen[id] == len);
+            bool same = (plen[id] == len) && (plen[256 + id] == kd);
             for (int q = 0; q < len && same; ++q) same = (pat[id * pmax + q] == w[q]);
             if (!same) state[1] = 1;
         }
@@ -545,13 +552,13 @@ void pattern_plan(const mk_csr *A, MkPlan &P) {
     if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS) != hipSuccess ||
         hipMalloc((void **)&d_keys, sizeof(double) * 256) != hipSuccess ||
         hipMalloc((void **)&d_pid, (size_t)A->nrows + 16) != hipSuccess ||
-        hipMalloc((void **)&d_plen, 256) != hipSuccess ||
+        hipMalloc((void **)&d_plen, 512) != hipSuccess ||
         hipMalloc((void **)&d_pat, sizeof(uint32_t) * PAT_WORDS) != hipSuccess)
         return cleanup();
     hipMemcpyAsync(d_table, empty.data(), sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyHostToDevice, st);
     hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
     hipMemsetAsync(d_pat, 0, sizeof(uint32_t) * PAT_WORDS, st);
-    hipMemsetAsync(d_plen, 0, 256, st);
+    hipMemsetAsync(d_plen, 0, 512, st);
     hipLaunchKernelGGL(pat_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, P.d_pk, pmax, limit,
                        d_table, d_state);
     if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -560,7 +567,7 @@ void pattern_plan(const mk_csr *A, MkPlan &P) {
     const int count = h_state[0];
     hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_keys);
     for (int mode = 0; mode < 2; ++mode)
-        hipLaunchKernelGGL(pat_assign, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, P.d_pk, pmax, count,
+        hipLaunchKernelGGL(pat_assign, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, P.d_wg, P.d_pk, pmax, count,
                            d_keys, d_pid, d_pat, d_plen, mode, d_state);
     if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess || h_state[1])
