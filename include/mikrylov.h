@@ -136,12 +136,18 @@ int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn, void *
  *   1  windowed tiles: per 256-row tile the referenced columns are covered by contiguous windows of x that the kernel
  *      stages in LDS with coalesced loads; per nonzero a uint16 LDS slot replaces the column (2 + 8 bytes);
  *   2  format 1 + value dictionary: matrices with <= 256 distinct values store ONE 32-bit word per nonzero
- *      {LDS slot : 16 | dictionary index : 8} and no values (4 bytes); slots, words and windows go to LDS by direct copies.
- * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 2).  A request the matrix does not qualify for
- * degrades silently (2 -> 1 -> 0): tiles with scattered columns always take the gather path of format 0.
+ *      {LDS slot : 16 | dictionary index : 8} and no values (4 bytes); slots, words and windows go to LDS by direct copies;
+ *   4  format 2 + row patterns: when the rows of the windowed tiles follow <= 256 distinct sequences of
+ *      {LDS slot - lane, dictionary index} words (stencils), ONE BYTE per row names its sequence and nothing is read
+ *      per nonzero;
+ *   3  plain CSR for matrices without a window cover whose x is longer than an L2: the tile's stream is held in LDS
+ *      and the gathers of all workgroups walk x slice by slice (same arrays as format 0).
+ * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 4; format 3 is chosen automatically for scattered
+ * matrices with more than 5 MiB of x).  A request the matrix does not qualify for degrades silently
+ * (4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the gather path of format 0.
  * mk_csr_format_info reports what is in use: the format, the number of windowed tiles, the LDS chunks (128
- * doubles each) a workgroup reserves, the dictionary size and the bytes of matrix data (everything except x and y)
- * one product streams. */
+ * doubles each) a workgroup reserves (format 3: the number of column phases), the dictionary size and the bytes of
+ * matrix data (everything except x and y) one product streams. */
 int mk_csr_set_format(mk_csr *A, int fmt);
 int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_windowed, int32_t *lds_chunks,
                        int32_t *dict_size, int64_t *matrix_bytes_per_product);
