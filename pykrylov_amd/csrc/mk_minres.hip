@@ -62,6 +62,15 @@ struct EpiK1 {
         t[i] = tv;
         acc[0] += vv * tv;                                                    // minres.py:245
     }
+    // r2 IS the product's input vector: where the kernel holds xin(r2[i]) = s * r2[i] already (pattern format: the
+    // diagonal entry's LDS slot) it passes it, and r2 is not streamed a second time
+    __device__ void row_x(int64_t i, double sum, double vv, double *acc) {
+        v[i] = vv;
+        double tv = sum - shift * vv;                                         // minres.py:239-240
+        if (!first) tv = tv - c * r1[i];                                      // minres.py:243
+        t[i] = tv;
+        acc[0] += vv * tv;                                                    // minres.py:245
+    }
 };
 
 struct OpK2 {
