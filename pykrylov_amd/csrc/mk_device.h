@@ -110,13 +110,19 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
     return g;
 }
 
-// grid of one of the two launches of an overlapped (halo) product over `ntl` of A's tiles
-static inline int mk_grid_spmv_part(const mk_csr *A, int64_t ntl) {
-    int cap = mk_grid_spmv_for(A);
-    if (cap > MK_MAXP / 2) cap = MK_MAXP / 2;
-    int g = (int)(ntl < 1 ? 1 : (ntl > cap ? cap : ntl));
-    if (g >= 8) g -= g % 8;
-    return g;
+// grids of the two launches of an overlapped (halo) product: the interior tiles (most of the matrix) get what a whole
+// product would get, less the few workgroups kept for the boundary tiles; together at most MK_MAXP (the two launches
+// write disjoint ranges of the partial-sum slots)
+static inline void mk_grid_spmv_parts(const mk_csr *A, int64_t n_int, int64_t n_bnd, int *g_int, int *g_bnd) {
+    const int cap = mk_grid_spmv_for(A);
+    int g2 = (int)(n_bnd < 1 ? 1 : (n_bnd > 256 ? 256 : n_bnd));
+    if (g2 >= 8) g2 -= g2 % 8;
+    int room = MK_MAXP - g2;
+    if (room > cap) room = cap;
+    int g1 = (int)(n_int < 1 ? 1 : (n_int > room ? room : n_int));
+    if (g1 >= 8) g1 -= g1 % 8;
+    *g_int = g1;
+    *g_bnd = g2;
 }
 
 static inline MkCsrView mk_view(const mk_csr *A) {

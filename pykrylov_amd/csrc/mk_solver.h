@@ -222,8 +222,9 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
     if (timed) s->spmv_begin();
     if (A->ex.pending) {
         // halo exchange in flight: rows that need no received entry first, the others once the messages are in
-        // (each part gets at most half of the partial-sum slots: the two launches write disjoint ranges of them)
-        const int g1 = mk_grid_spmv_part(A, A->ex.n_int), g2 = mk_grid_spmv_part(A, A->ex.n_bnd);
+        // (the two launches write disjoint ranges of the partial-sum slots)
+        int g1, g2;
+        mk_grid_spmv_parts(A, A->ex.n_int, A->ex.n_bnd, &g1, &g2);
         mk_spmv_launch_view(mk_view_part(A, 1, 0), g1, s->stream, x, epi, gate, s->next_halt(), s->d_part);
         int rc = mk_exchange_wait(A, s->stream);
         if (rc != MK_OK) return rc;
