@@ -405,3 +405,27 @@ def test_resident_tile_format_under_every_kind_of_launch():
     assert abs(s.itn - ref["itn"]) <= 1 and np.linalg.norm(s.x - ref["x"]) <= 1e-8 * np.linalg.norm(ref["x"])
     for o in (opA, opB, opR):
         o.free()
+
+
+def test_pattern_format_rows_without_a_diagonal_entry(monkeypatch):
+    """MINRES' epilogue takes s * y[i] from the product (row_x hook): in the pattern format that is the diagonal entry's
+    LDS slot -- rows WITHOUT a diagonal entry (here: the adjacency matrix of a path graph plus a few diagonal entries)
+    must fall back to loading it.  Bit equality with the oracle in the device's summation order."""
+    from pykrylov_amd import CsrOperator, Minres
+    from oracle import gpu_order, krylov_ref as kr
+    monkeypatch.setattr(kr, "_sq", lambda a: a * a)
+    n = 6001
+    i = np.arange(n - 1)
+    dg = np.arange(0, n, 7)
+    A = csr_ref.from_coo(np.concatenate([i, i + 1, dg]), np.concatenate([i + 1, i, dg]),
+                         np.concatenate([np.ones(n - 1), np.ones(n - 1), np.full(len(dg), 3.0)]), (n, n))
+    op = CsrOperator(A.indptr, A.indices, A.data, A.shape, symmetric=True)
+    assert fmt_info(op)["fmt"] == 4
+    rhs = A.matvec(np.linspace(1.0, 2.0, n))
+    s = Minres(op)
+    s.solve(rhs, show=False, check=False, etol=0.0, rtol=1e-12, itnlim=60)
+    ref = kr.minres(A, rhs, check=False, etol=0.0, rtol=1e-12, itnlim=60,
+                    red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["minres"], gpu_order.launch_geometry(op))))
+    assert (s.istop, s.itn) == (ref["istop"], ref["itn"]) and s.itn == 60
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
+    op.free()
