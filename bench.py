@@ -34,6 +34,7 @@ import time
 
 # the CPU baseline's headline figure is a one-core number: keep OpenBLAS (np.dot in the oracle) from fanning out
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+os.environ.setdefault("OMP_NUM_THREADS", "1")           # (the oracle's C product is OpenMP-parallel over rows)
 
 import numpy as np  # noqa: E402
 
@@ -132,27 +133,37 @@ def cpu_baseline(name, seconds_budget=20.0):
     dt = time.perf_counter() - t0
     return {"value": out["nMatvec"] / dt * scale, "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": sample % out["nMatvec"], "host_cpus": os.cpu_count(),
-            "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS", "default")}
+            "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS", "default"),
+            "spmv_threads": os.environ.get("OMP_NUM_THREADS", "default")}
 
 
-def cpu_baseline_all_cores(name, seconds_budget=8.0):
-    """The same oracle with OpenBLAS allowed to use every host core (SURVEY.md 8d asks for both figures): only the
-    dots are threaded (SciPy-style CSR products and NumPy element-wise updates are single threaded), so on a
-    many-core host this is usually SLOWER than one pinned thread.  Runs in a child process because OpenBLAS reads
-    its thread count at import."""
+def cpu_baseline_all_cores(name, seconds_budget=9.0):
+    """The same oracle on many host cores (SURVEY.md 8d asks for both figures): the C CSR product runs OpenMP-parallel
+    over the rows (same bits); NumPy's dots and element-wise updates stay on one thread, which bounds the speed-up.
+    8, 32 and all visible cores are tried (containers often see more CPUs than their quota lets them use at once) and
+    the best is reported with the thread count it used.  Child processes: libgomp reads its thread count when it loads."""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    tried = sorted({min(ncpu, 8), min(ncpu, 32), ncpu})
     code = ("import json,sys; sys.path.insert(0, %r); import bench; "
-            "print(json.dumps(bench.cpu_baseline(%r, %r)))" % (ROOT, name, seconds_budget))
-    env = dict(os.environ)
-    env["OPENBLAS_NUM_THREADS"] = str(os.cpu_count())       # (bench.py pins 1 only when the variable is unset)
-    env["BENCH_CHILD"] = "1"
-    try:
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        d = json.loads(out.stdout.strip().splitlines()[-1])
-        d["cores"] = os.cpu_count()
-        d["blas_threads"] = "all (%d)" % os.cpu_count()
-        return d
-    except Exception as e:                                   # a baseline must never take the bench line down
-        return {"value": None, "error": repr(e)[:200]}
+            "print(json.dumps(bench.cpu_baseline(%r, %r)))" % (ROOT, name, seconds_budget / len(tried)))
+    best, err = None, None
+    for threads in tried:
+        env = dict(os.environ)
+        env["OMP_NUM_THREADS"] = str(threads)
+        env["OPENBLAS_NUM_THREADS"] = "1"
+        env["BENCH_CHILD"] = "1"
+        try:
+            out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+            d = json.loads(out.stdout.strip().splitlines()[-1])
+            d["cores"] = threads
+            if best is None or d["value"] > best["value"]:
+                best = d
+        except Exception as e:                               # a baseline must never take the bench line down
+            err = repr(e)[:200]
+    if best is None:
+        return {"value": None, "error": err}
+    best["threads_tried"] = tried
+    return best
 
 
 # ======================================================================================

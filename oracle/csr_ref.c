@@ -16,6 +16,9 @@
 void ref_csr_matvec(int64_t nrows, const int32_t *indptr, const int32_t *indices,
                     const double *data, const double *x, double *y)
 {
+    /* Rows are independent: with OpenMP (OMP_NUM_THREADS > 1; bench.py's all-core baseline) they are split across
+     * threads, each row still summed left to right -- the result does not change by a bit. */
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < nrows; ++i) {
         double sum = 0.0;
         for (int32_t j = indptr[i]; j < indptr[i + 1]; ++j)

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("OMP_NUM_THREADS", "1")   # (the oracle's C product is OpenMP-parallel: keep tests single threaded)
+
 import numpy as np
 import pytest
 
