@@ -81,6 +81,9 @@ static inline int mk_tile_map(const mk_csr *A) {
     return mk_xcd_chunks(A) ? 1 : 0;
 }
 
+constexpr int MK_PROD_LD = MK_BLOCK + 1;             // (product staging buffer of the SpMV kernels, see below)
+constexpr int MK_PROD_LDS = 8 * MK_PROD_LD;          // doubles reserved for products (>= MK_SPMV_TILE of the gather path)
+
 const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
 int mk_host_product(const mk_csr *A, hipStream_t st);   // mk_core.hip: D2H, host callback, H2D of a matrix-free operator
 
@@ -101,7 +104,14 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         if (g3 >= 8) g3 -= g3 % 8;
         return g3;
     }
-    if (P && P->fmt == 4) cap = 1792;                        // 7 per CU: what LDS (<= 22 KB) and registers allow
+    if (P && P->fmt == 4) {                                  // up to 7 per CU (registers), as many as LDS holds
+        int64_t top = 128 * (int64_t)P->wchunks + 2;
+        if (P->covered != A->ntiles && top < MK_PROD_LDS) top = MK_PROD_LDS;
+        const int64_t lds = 8 * (top + MK_BLOCK) + 16 * (int64_t)(P->npat * P->pmax + 1) + 4608;   // + static arrays
+        int64_t per_cu = (160 * 1024) / lds;
+        per_cu = per_cu > 7 ? 7 : (per_cu < 1 ? 1 : per_cu);
+        cap = 256 * per_cu;
+    }
     else if (P && P->fmt == 2) cap = mk_xcd_chunks(A) ? 1280 : 1024;
     else if (P && P->fmt == 1) cap = 1024;
     else if (mk_xcd_chunks(A)) cap = 2 * cap > MK_MAXP ? MK_MAXP : 2 * cap;
@@ -257,8 +267,6 @@ typedef unsigned mk_u4 __attribute__((ext_vector_type(4)));
 // addresses: conflict-free ds_write_b64); column 256 holds zeros, so that pass 2 can mask a read by redirecting its
 // ADDRESS there (one 32-bit select) instead of selecting 64-bit values: adding +0.0 never changes a running sum that
 // started at +0.0 (it can never be -0.0).
-constexpr int MK_PROD_LD = MK_BLOCK + 1;
-constexpr int MK_PROD_LDS = 8 * MK_PROD_LD;          // doubles reserved for products (>= MK_SPMV_TILE of the gather path)
 __device__ __forceinline__ int mk_phys(int idx) { return (idx & 7) * MK_PROD_LD + (idx >> 3); }
 
 // Tile id of position p of a launch's tile list, as a SCALAR: every lane computes the same value, but only an explicit
@@ -503,8 +511,36 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         __shared__ double sdict[256];
         sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // (read after a barrier below)
         [[maybe_unused]] __shared__ int splen[PAT ? 256 : 1];
-        if constexpr (PAT) {                                 // spk holds the pattern table instead of a tile's words
-            for (int i = tid; i < A.npat * A.pmax; i += MK_BLOCK) spk[i] = A.pat[i];
+        // fmt 4: behind the windows (and whatever the gather path may overwrite) 256 zeros, then the pattern table in
+        // the form the row phase consumes with the fewest instructions -- per entry {byte offset of its x value
+        // relative to the lane's own cell, the VALUE itself}: one 16-byte LDS read, one add, one 8-byte LDS read, one
+        // multiply, one add.  Entries past a pattern's end point at the lane's zero cell with value +0.0: their
+        // product is +-0.0 and leaves the running sum (never -0.0, it started at +0.0) unchanged, so nothing is masked.
+        struct PatEntry {
+            int off, pad;
+            double val;
+        };
+        [[maybe_unused]] PatEntry *ftab = nullptr;
+        [[maybe_unused]] int zoff = 0;
+        if constexpr (PAT) {
+            double *zeros = reinterpret_cast<double *>(spk);
+            ftab = reinterpret_cast<PatEntry *>(zeros + MK_BLOCK);
+            zoff = (int)((zeros - xw) * (int)sizeof(double));
+            zeros[tid] = 0.0;
+            for (int e = tid; e < A.npat * A.pmax; e += MK_BLOCK) {
+                const int pnum = e / A.pmax, k = e - pnum * A.pmax;
+                const uint32_t w = A.pat[e];
+                PatEntry en;
+                en.pad = 0;
+                if (k < (int)A.plen[pnum]) {
+                    en.off = 8 * (int)(short)(w & 0xffffu);
+                    en.val = A.dict[w >> 16];
+                } else {
+                    en.off = zoff;
+                    en.val = 0.0;
+                }
+                ftab[e] = en;
+            }
             splen[tid] = (tid < A.npat) ? ((int)A.plen[tid] | ((int)A.plen[256 + tid] << 8)) : (255 << 8);
         }
         const double d0 = A.dict[0], d1 = A.dict[A.ndict > 1 ? 1 : 0];
@@ -562,6 +598,34 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                     lo = (int)id * A.pmax;
                     len = (r < rend) ? (splen[id] & 0xff) : 0;
                     kdiag = splen[id] >> 8;
+                    const char *cell = reinterpret_cast<const char *>(xw + tid);    // this lane's own cell
+                    const PatEntry *pe = ftab + lo;
+                    PatEntry en[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) en[k] = pe[k];
+                    double xk[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) xk[k] = epi.xin(*reinterpret_cast<const double *>(cell + en[k].off));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) sum += en[k].val * xk[k];
+                    for (int k = 8; k < len; ++k)
+                        sum += pe[k].val * epi.xin(*reinterpret_cast<const double *>(cell + pe[k].off));
+                    if constexpr (ROWX) {                    // x[r] for the epilogue: the diagonal entry's cell
+                        if (kdiag < len) xr_cur = epi.xin(*reinterpret_cast<const double *>(cell + pe[kdiag].off));
+                        else if (r < rend) xr_cur = epi.xin(x[r]);
+                    }
+                    __syncthreads();                         // the next tile's copies overwrite this LDS
+                    if constexpr (PROG) {
+                        if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
+                    }
+                    if constexpr (ROWX) {
+                        if (r < rend) epi.row_x(r, sum, xr_cur, acc);
+                    } else {
+                        if (r < rend) epi.row(r, sum, acc);
+                    }
+                    cur = nxt;
+                    dcur = dnxt;
+                    continue;
                 } else {
                     const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
                     const int base = p_lo & ~3, cnt = p_hi - base;         // 0 < cnt <= MK_SPMV_TILE + 3 (builder)
@@ -837,7 +901,7 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
     if (v.fmt == 4) {                                        // windows + pattern table, or the gather path's products
         size_t wtop = (size_t)(128 * v.wchunks + 2);
         if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
-        lds = sizeof(double) * wtop + sizeof(uint32_t) * (size_t)(v.npat * v.pmax + 16);
+        lds = sizeof(double) * (wtop + MK_BLOCK) + 16 * (size_t)(v.npat * v.pmax + 1);   // windows, zeros, table
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 4>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                            halt, partials);
     } else if (v.fmt == 3) {                                 // the tile's values and columns

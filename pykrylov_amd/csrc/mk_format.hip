@@ -217,12 +217,12 @@ __global__ __launch_bounds__(MK_BLOCK) void dict_encode(int64_t nnz, const doubl
 // ------------------------------------------------------------------------------------------------ row patterns
 // fmt 4.  In a dictionary matrix the packed word of a nonzero is {LDS slot, value code}; relative to the row's lane t
 // the word {slot - t, code} is the same for every row of a regular stencil, so a ROW is described by the sequence of
-// its relative words -- its pattern -- and a matrix with few distinct patterns (27 boundary cases of a 7-point
+// its relative words -- its pattern -- and a matrix with few distinct patterns (<= 128 of up to 8 entries; 27 boundary cases of a 7-point
 // stencil, times the few window layouts a tile can have) by ONE BYTE per row instead of one word per nonzero.
 // Patterns are collected as 64-bit hashes in the same open-addressing set as the values, numbered in ascending hash
 // order, written into a table of `pmax` words per pattern and then VERIFIED row by row against the table, so that a
 // hash collision can only make the builder give up, never change a product.
-constexpr int PAT_WORDS = 2048;                              // table capacity in words (npat * pmax)
+constexpr int PAT_WORDS = 1024;                              // table capacity in entries (npat * pmax): <= 16 KB of LDS
 
 __device__ inline int pat_row_words(const int32_t *__restrict__ ip, const uint32_t *__restrict__ pk, int64_t r, int t,
                                     int pmax, uint32_t *w) {
@@ -581,6 +581,7 @@ void pattern_plan(const mk_csr *A, MkPlan &P) {
     P.npat = count;
     P.pmax = pmax;
     P.fmt = 4;
+    if (getenv("MK_DEBUG_PLAN")) fprintf(stderr, "mikrylov: %lld rows, %d row patterns of <= %d entries\n", (long long)A->nrows, count, pmax);
     // the per-nonzero streams are not read any more (tiles without windows gather from the CSR arrays)
     hipFree(P.d_pk);
     hipFree(P.d_slots);

@@ -143,6 +143,9 @@ def test_cg_256cubed_head_matches_oracle():
     s = CG(op)
     s.solve(rhs, matvec_max=25)
     assert s.nMatvec == ref["nMatvec"] == 25
-    assert rel_hist_err(s.residHistory, ref["residHistory"]) <= 1e-12
-    assert np.linalg.norm(s.x - ref["x"]) <= 1e-12 * np.linalg.norm(ref["x"])
+    # np.dot over 16.7 M terms is itself only good to a few 1e-12 and its rounding depends on OpenBLAS' thread count
+    # (one thread: 4.7e-12 from the device's history, many threads: < 1e-12); bit equality with the oracle run in the
+    # device's summation order is pinned in tests/test_gpu_bitexact_full.py
+    assert rel_hist_err(s.residHistory, ref["residHistory"]) <= 1e-11
+    assert np.linalg.norm(s.x - ref["x"]) <= 1e-11 * np.linalg.norm(ref["x"])
     op.free()
