@@ -104,10 +104,11 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         if (g3 >= 8) g3 -= g3 % 8;
         return g3;
     }
-    if (P && P->fmt == 4) {                                  // up to 7 per CU (registers), as many as LDS holds
+    if (P && P->fmt == 4) {                                  // up to 7 per CU, as many as LDS holds (8 per CU: 512^3 +3 %,
+                                                             // 2-D n = 1e6 -4 %, and MINRES' epilogue spills at 64 registers)
         int64_t top = 128 * (int64_t)P->wchunks + 2;
         if (P->covered != A->ntiles && top < MK_PROD_LDS) top = MK_PROD_LDS;
-        const int64_t lds = 8 * (top + MK_BLOCK) + 16 * (int64_t)(P->npat * P->pmax + 1) + 4608;   // + static arrays
+        const int64_t lds = 8 * (top + MK_BLOCK) + 16 * (int64_t)(P->npat * P->pmax + 1) + 2560;   // + static arrays
         int64_t per_cu = (160 * 1024) / lds;
         per_cu = per_cu > 7 ? 7 : (per_cu < 1 ? 1 : per_cu);
         cap = 256 * per_cu;
@@ -508,8 +509,8 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
         // (unless every tile has windows: then the gather path never runs, A.allwin)
         const int wtop = 128 * A.wchunks + 2;
         uint32_t *spk = reinterpret_cast<uint32_t *>(xw + ((PAT && !A.allwin && wtop < MK_PROD_LDS) ? MK_PROD_LDS : wtop));
-        __shared__ double sdict[256];
-        sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // (read after a barrier below)
+        __shared__ double sdict[PAT ? 1 : 256];              // (fmt 4 keeps the values in its pattern table)
+        if constexpr (!PAT) sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // (read after a barrier below)
         [[maybe_unused]] __shared__ int splen[PAT ? 256 : 1];
         // fmt 4: behind the windows (and whatever the gather path may overwrite) 256 zeros, then the pattern table in
         // the form the row phase consumes with the fewest instructions -- per entry {byte offset of its x value
@@ -646,12 +647,8 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                     lo = my_lo - base;
                     len = my_hi - my_lo;
                 }
-                // the LDS position of entry k's x value: its slot (fmt 2), or this lane plus the pattern's relative
-                // slot (fmt 4; entries past the row's end read position 0 and are masked below)
-                auto slot_of = [&](unsigned w, int k) -> unsigned {
-                    if constexpr (PAT) return (k < len) ? (unsigned)(tid + (int)(short)(w & 0xffffu)) : 0u;
-                    else return w & 0xffffu;
-                };
+                if constexpr (!PAT) {
+                auto slot_of = [&](unsigned w, int) -> unsigned { return w & 0xffffu; };
                 unsigned wk[8];
                 double xk[8], vk[8];
 #pragma unroll
@@ -678,11 +675,8 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
                     const unsigned w = spk[lo + k];
                     sum += sdict[w >> 16] * epi.xin(xw[slot_of(w, k)]);
                 }
-                if constexpr (ROWX) {                        // x[r] for the epilogue: the diagonal entry's LDS slot
-                    if (kdiag < len) xr_cur = epi.xin(xw[(unsigned)(tid + (int)(short)(spk[lo + kdiag] & 0xffffu))]);
-                    else if (r < rend) xr_cur = epi.xin(x[r]);
-                }
                 __syncthreads();                             // the next tile's copies overwrite this LDS
+                }
             } else {
                 if constexpr (ROWX) {
                     if (r < rend) xr_cur = epi.xin(x[r]);
