@@ -73,18 +73,23 @@ static inline int mk_xcd_chunks(const mk_csr *A) {
     const int64_t bytes = 12 * A->nnz + 4 * (A->nrows + 1) + 8 * (A->x_len() + A->nrows) * 3;
     return bytes <= (int64_t)200 * 1024 * 1024 ? 1 : 0;
 }
+const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
 static inline int mk_tile_map(const mk_csr *A) {
     if (A->comp_kind) return mk_tile_map(A->comp_kind == 3 ? A->comp_a : A->comp_b);
     if (A->host_fn) return 0;
     static const char *env = getenv("MK_SPMV_MAP");
     if (env) return atoi(env);
-    return mk_xcd_chunks(A) ? 1 : 0;
+    if (mk_xcd_chunks(A)) return 1;
+    // beyond the Infinity Cache: one front (0) -- except for the pattern kernel, which moves so little per tile that it
+    // runs into the fabric on re-fetched x windows: XCD-contiguous blocks within every step of the grid keep neighbouring
+    // tiles' windows in one L2 (512^3: fabric reads 4.4 -> 3.6 GB, 838 -> 790 us)
+    const MkPlan *P = mk_csr_plan(A);
+    return (P && P->fmt == 4) ? 2 : 0;
 }
 
 constexpr int MK_PROD_LD = MK_BLOCK + 1;             // (product staging buffer of the SpMV kernels, see below)
 constexpr int MK_PROD_LDS = 8 * MK_PROD_LD;          // doubles reserved for products (>= MK_SPMV_TILE of the gather path)
 
-const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
 int mk_host_product(const mk_csr *A, hipStream_t st);   // mk_core.hip: D2H, host callback, H2D of a matrix-free operator
 
 // SpMV grid = the workgroups that are resident at once (persistent tiles; a second round only adds a tail).
