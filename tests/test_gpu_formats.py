@@ -434,3 +434,23 @@ def test_pattern_format_rows_without_a_diagonal_entry(monkeypatch):
     assert (s.istop, s.itn) == (ref["istop"], ref["itn"]) and s.itn == 60
     assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
     op.free()
+
+
+def test_pattern_format_fuzz_over_grid_shapes():
+    """Stencil matrices on grids whose lines do not divide the 256-row tiles in every possible way (tile boundaries
+    inside lines and planes, ragged last tiles, tiny grids): whatever format the builder settles on, products and
+    transposed products keep the scalar loop's bits."""
+    from pykrylov_amd import CsrOperator
+    rng = np.random.default_rng(12)
+    shapes = [(int(a), int(b), int(c)) for a, b, c in zip(rng.integers(3, 70, 14), rng.integers(1, 40, 14), rng.integers(1, 30, 14))]
+    shapes += [(256, 3, 2), (255, 2, 2), (257, 2, 1), (512, 2, 2), (1, 1, 300), (2, 129, 5)]
+    seen = set()
+    for mx, my, mz in shapes:
+        A = csr_ref.poisson3d(mx, my, mz)
+        op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
+        seen.add(fmt_info(op)["fmt"])
+        x = rng.standard_normal(A.shape[1])
+        assert np.array_equal(op * x, A.matvec(x)), (mx, my, mz, fmt_info(op))
+        assert np.array_equal(op.T * x, A.rmatvec(x)), (mx, my, mz)
+        op.free()
+    assert 4 in seen
