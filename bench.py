@@ -10,12 +10,23 @@ A "step" is one pass of the CG loop body (reference pykrylov/cg/cg.py:113-158: 1
 K passes run inside the timed region.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json `configs`):
-  poisson3d-512    configs[4]  CG, 3-D 7-point Poisson 512^3 (1.34e8 rows, 9.4e8 nnz) row-partitioned over N GPUs --
-                               the configuration BASELINE.json's target is quoted on.  It fits one GPU (14 GB of
-                               288 GB), so it is the default at EVERY N: the 1/2/4/8 series is one strong-scaling
-                               series over a fixed problem.
-  poisson2d-1000   configs[1]  CG, 2-D 5-point Poisson, n = 1e6, one GPU; also run at N = 1 and reported under
-                               "extra" (value, ms_per_step and its own SpMV roofline), or alone with --workload.
+  poisson3d-512-varcoef  configs[4]  CG, 3-D 7-point Poisson 512^3 (1.34e8 rows, 9.4e8 nnz) with a VARIABLE coefficient
+                               field (-div(k grad u), harmonic-mean face coefficients, SPD, every stored value distinct),
+                               row-partitioned over N GPUs.  The default and the workload `value` and `roofline` are
+                               quoted on: no constant-coefficient compression applies, the product has to stream 8 bytes
+                               per nonzero -- this IS the CSR product north_star names.  It fits one GPU, so the 1/2/4/8
+                               series is one strong-scaling series over a fixed problem.
+  poisson3d-512          configs[4]  the same grid with constant coefficients (diagonal 6, off-diagonals -1): the special
+                               case whose rows and values compress to one byte per row (storage format 4); reported at
+                               N = 1 under "extra", with its own physical roofline.
+  poisson2d-1000         configs[1]  CG, 2-D 5-point Poisson, n = 1e6, one GPU; under "extra".
+  bicgstab-rand1m        configs[2]  BiCGSTAB, random nonsymmetric n = 1e6, ~5 nnz/row, one GPU; under "extra".
+  minres-shifted2d-2000  configs[3]  MINRES, shifted 2-D Laplacian n = 4e6, one GPU; under "extra".
+
+Roofline convention (all figures PHYSICAL): `roofline.achieved` = bytes the kernel has to move in the storage format
+in use (matrix data of the format + x once + y once) / its average duration; `frac` = achieved / 8 TB/s, never above
+1 by construction.  The CSR-priced figure (12 nnz + 4 (n+1) + 8 ncols + 8 nrows over the same time) is
+reported beside it as `csr_equivalent_GBs` -- a throughput in CSR units, not a fraction of anything.
 
 Multi-GPU: one process per GPU.  torch.distributed is used with the gloo backend ONLY, for the bootstrap
 (RCCL unique id, barriers, max over ranks of the elapsed time): the only RCCL instance in a process is the one
@@ -43,12 +54,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s per GPU
 METRIC = "Krylov iters/sec + SpMV achieved HBM GB/s (% of peak), fp64"
+VARCOEF_SEED = 7
 FMT_NAMES = {0: "csr (int32 columns + fp64 values, x gathered)",
              1: "windowed tiles (x windows in LDS, uint16 slots + fp64 values)",
              2: "windowed tiles + value dictionary (one packed 32-bit word per nonzero: LDS slot + value code)",
              3: "csr, tile resident in LDS, gathers ordered by column block (x longer than an L2)",
              4: "windowed tiles + value dictionary + row patterns (one byte per ROW: the number of its pattern of "
-                "{LDS slot - lane, value code} words)"}
+                "{LDS slot - lane, value code} words)",
+             5: "windowed tiles + row patterns for the x positions (one byte per row) + the fp64 values streamed in "
+                "tile-sliced ELL order (8 B per nonzero; no column indices, no row pointers)"}
 
 
 def spmv_bytes(nrows, ncols, nnz):
@@ -59,7 +73,8 @@ def spmv_bytes(nrows, ncols, nnz):
 def kernel_source_sha():
     """Fingerprint of the SpMV kernel sources: PMC traffic figures under profiles/ are only quoted while it matches."""
     h = hashlib.sha256()
-    for f in ("mk_device.h", "mk_format.hip", "mk_internal.h"):
+    for f in ("mk_device.h", "mk_format.hip", "mk_internal.h", "mk_spmv_fmt0.h", "mk_spmv_fmt1.h", "mk_spmv_fmt24.h",
+              "mk_spmv_fmt3.h", "mk_spmv_fmt5.h"):
         with open(os.path.join(ROOT, "pykrylov_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -118,10 +133,10 @@ def cpu_baseline(name, seconds_budget=20.0):
         scale, sample = 1.0, "first %%d CG iterations of %s (n=%d), rhs=A*1" % (name, m * m)
     else:
         ms = min(m, 128)                 # 512^3 does not fit a host-side sample: time 128^3 and scale by rows
-        A = csr_ref.poisson3d(ms)
+        A = csr_ref.poisson3d_varcoef(ms, seed=VARCOEF_SEED) if name.endswith("-varcoef") else csr_ref.poisson3d(ms)
         scale = float(ms ** 3) / float(m ** 3)
-        sample = ("first %%d CG iterations on %d^3 (%d rows), iterations/s scaled by rows ratio %.4g to %s"
-                  % (ms, ms ** 3, scale, name))
+        sample = ("first %%d CG iterations on %d^3 (%d rows, same operator family), measured iterations/s "
+                  "EXTRAPOLATED by the rows ratio %.4g to %s" % (ms, ms ** 3, scale, name))
     n = A.shape[0]
     rhs = A.matvec(np.ones(n))
     t0 = time.perf_counter()
@@ -132,6 +147,7 @@ def cpu_baseline(name, seconds_budget=20.0):
     out = krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=iters)
     dt = time.perf_counter() - t0
     return {"value": out["nMatvec"] / dt * scale, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "extrapolated": scale != 1.0, "measured_on_sample": out["nMatvec"] / dt, "sample_rows": int(n),
             "sample": sample % out["nMatvec"], "host_cpus": os.cpu_count(),
             "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS", "default"),
             "spmv_threads": os.environ.get("OMP_NUM_THREADS", "default")}
@@ -182,10 +198,13 @@ def build_workload(name, world, exchange):
     if name.startswith("poisson3d-"):
         m = int(name.split("-")[1])
         n = m ** 3
+        seed = VARCOEF_SEED if name.endswith("-varcoef") else None
+        meta = {"grid": [m, m, m], "stencil": 7, "coefficients": "variable (seed %d)" % seed if seed is not None
+                else "constant"}
         if world.nranks == 1:
-            return gallery.poisson3d(m), n, {"grid": [m, m, m], "stencil": 7}
-        op, _ = dist.partition_poisson3d(world, m, m, m, mode=exchange)
-        return op, n, {"grid": [m, m, m], "stencil": 7}
+            return (gallery.poisson3d_varcoef(m, seed=seed) if seed is not None else gallery.poisson3d(m)), n, meta
+        op, _ = dist.partition_poisson3d(world, m, m, m, mode=exchange, varcoef_seed=seed)
+        return op, n, meta
     raise SystemExit("unknown workload %r" % name)
 
 
@@ -211,49 +230,61 @@ def colblocks(lib, op):
 
 
 def other_configs(lib, passes=400, warm=20):
-    """BASELINE configs[2] and configs[3] on one GPU (`--all-configs`): loop passes per second with the
-    tolerances at zero so that exactly `passes` passes run, plus the iteration roofline with the
-    reference's op count."""
+    """BASELINE configs[2] and configs[3] on one GPU: loop passes per second with the tolerances at zero so that exactly
+    `passes` passes run, the product kernel timed alone, and PHYSICAL rooflines: bytes the kernels have
+    to move in the storage format in use.  The reference-op-count figures are reported beside them as
+    throughputs in CSR units, not as fractions."""
     from pykrylov_amd import _lib, gallery
     from pykrylov_amd.generic import DeviceRun
     out = {}
 
-    def timed(op, kind, rhs, **params):
-        run = DeviceRun(op, kind, rhs, None, **params)
-        run.setup()
-        assert run.iterate(warm) == warm
-        _lib.check(lib.mk_sync())
-        t0 = time.perf_counter()
-        done = run.iterate(passes)
-        _lib.check(lib.mk_sync())
-        dt = time.perf_counter() - t0
-        assert done == passes, (done, passes)
+    def spmv_time(run, launches=200):
         avg = ctypes.c_double(float("nan"))
-        if kind == _lib.MK_BICGSTAB:                         # (the other solvers' product kernels: see profiles/)
-            _lib.check(lib.mk_solver_time_spmv(run.handle, 200, ctypes.byref(avg)))
-        run.close()
-        return dt, avg.value
+        _lib.check(lib.mk_solver_time_spmv(run.handle, launches, ctypes.byref(avg)))
+        return avg.value
 
-    # configs[2]: BiCGSTAB, random nonsymmetric diagonally dominant CSR, n = 1e6, ~5 nnz/row.  With threshold 0
-    # the residual reaches 0 after ~25 passes and the recurrence then divides 0 by 0 (as the reference would):
-    # the kernels move the same bytes on NaNs, which is what is being timed.
+    # configs[2]: BiCGSTAB, random nonsymmetric diagonally dominant CSR, n = 1e6, ~5 nnz/row.  With threshold 0 the
+    # residual underflows to 0 after ~25 passes and the recurrence then divides 0 by 0 (as the reference would).  To
+    # time FINITE data the run is re-set-up every `seg` passes (setup and the first 2 passes of a segment untimed,
+    # segments timed with HIP events on the solver stream, `device_loop_ms`); the residual is asserted finite and
+    # positive at the end of every segment.
     n = 1000000
     op = gallery.random_diagdom(n, seed=1)
     ones = _lib.DeviceArray.from_numpy(np.ones(n))
     rhs = _lib.DeviceArray(n)
     op.spmv_device(ones.ptr, rhs.ptr)
-    dt, spmv_us = timed(op, _lib.MK_BICGSTAB, rhs, abstol=0.0, reltol=0.0, matvec_max=1 << 60)
-    b_spmv = spmv_bytes(n, n, op.nnz)
-    b_iter = 2 * b_spmv + 224 * n                                          # SURVEY.md 8d
-    out["bicgstab-rand1m@1"] = {"value": passes / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / passes,
-                                "rows": n, "nnz": int(op.nnz), "matvecs_per_iteration": 2,
-                                "format": format_info(lib, op),
-                                "column_blocks": colblocks(lib, op),
-                                "spmv": {"avg_product_us": spmv_us, "achieved_GBs": b_spmv / spmv_us / 1e3,
-                                         "frac": b_spmv / spmv_us / 1e3 / HBM_PEAK_GBS,
-                                         "note": "one product = all column-block launches of the first product's kernel"},
-                                "iteration_roofline": {"algorithmic_bytes_per_iter": b_iter,
-                                                       "frac_of_hbm": b_iter * passes / dt / 1e9 / HBM_PEAK_GBS}}
+    seg, head = 16, 2
+    run = DeviceRun(op, _lib.MK_BICGSTAB, rhs, None, abstol=0.0, reltol=0.0, matvec_max=1 << 60)
+    total_ms, done, resid_min = 0.0, 0, float("inf")
+    run.setup()
+    assert run.iterate(warm) == warm
+    while done < passes:
+        run.setup()
+        assert run.iterate(head) == head
+        assert run.iterate(seg - head) == seg - head
+        total_ms += run.timing()["iterate_ms"]
+        done += seg - head
+        rn = float(run.finish().residNorm)
+        assert np.isfinite(rn) and rn > 0.0, "configs[2] segment ended on non-finite data: %r" % rn
+        resid_min = min(resid_min, rn)
+    spmv_us = spmv_time(run)
+    run.close()
+    dt = total_ms * 1e-3
+    fmt = format_info(lib, op)
+    b_csr = spmv_bytes(n, n, op.nnz)
+    b_fmt = fmt["matrix_bytes_per_product"] + 16 * n
+    out["bicgstab-rand1m@1"] = {
+        "value": done / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / done, "steps": done,
+        "rows": n, "nnz": int(op.nnz), "matvecs_per_iteration": 2, "format": fmt, "column_blocks": colblocks(lib, op),
+        "data": "finite: re-set-up every %d passes, first %d of each segment untimed; smallest residual norm seen %.3e"
+                % (seg, head, resid_min),
+        "spmv": {"avg_product_us": spmv_us, "bytes_per_launch": b_fmt, "achieved_GBs": b_fmt / spmv_us / 1e3,
+                 "frac": b_fmt / spmv_us / 1e3 / HBM_PEAK_GBS, "csr_equivalent_GBs": b_csr / spmv_us / 1e3},
+        "iteration_roofline": {"bytes_per_iter": 2 * b_fmt + 136 * n,
+                               "frac": (2 * b_fmt + 136 * n) * done / dt / 1e9 / HBM_PEAK_GBS,
+                               "note": "2 products in the format in use + the 136 n bytes of the fused update kernels",
+                               "reference_op_count_bytes_per_iter": 2 * b_csr + 224 * n,
+                               "reference_op_count_GBs": (2 * b_csr + 224 * n) * done / dt / 1e9}}
     op.free()
     # configs[3]: MINRES, 2-D Laplacian m = 2000 (n = 4e6) with the keyword shift 1.5 (symmetric indefinite)
     m = 2000
@@ -264,13 +295,34 @@ def other_configs(lib, passes=400, warm=20):
     rhs = _lib.DeviceArray(n)
     op.spmv_device(ones.ptr, rhs.ptr)
     rhs_h[:] = rhs.to_numpy() - 1.5
-    dt, spmv_us = timed(op, _lib.MK_MINRES, rhs_h, shift=1.5, itnlim=1 << 60, rtol=0.0, etol=0.0, window=5)
-    b_spmv = spmv_bytes(n, n, op.nnz)
-    b_iter = b_spmv + 176 * n                                              # SURVEY.md 8d (kwarg shift)
-    out["minres-shifted2d-2000@1"] = {"value": passes / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / passes,
-                                      "rows": n, "nnz": int(op.nnz), "shift": 1.5, "format": format_info(lib, op),
-                                      "iteration_roofline": {"algorithmic_bytes_per_iter": b_iter,
-                                                             "frac_of_hbm": b_iter * passes / dt / 1e9 / HBM_PEAK_GBS}}
+    run = DeviceRun(op, _lib.MK_MINRES, rhs_h, None, shift=1.5, itnlim=1 << 60, rtol=0.0, etol=0.0, window=5)
+    run.setup()
+    assert run.iterate(warm) == warm
+    _lib.check(lib.mk_sync())
+    t0 = time.perf_counter()
+    done = run.iterate(passes)
+    _lib.check(lib.mk_sync())
+    dt = time.perf_counter() - t0
+    assert done == passes, (done, passes)
+    try:
+        spmv_us = spmv_time(run)
+    except Exception:                                        # (not wired for this solver: no kernel-alone figure)
+        spmv_us = None
+    run.close()
+    fmt = format_info(lib, op)
+    b_csr = spmv_bytes(n, n, op.nnz)
+    b_fmt = fmt["matrix_bytes_per_product"] + 16 * n
+    out["minres-shifted2d-2000@1"] = {
+        "value": passes / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / passes, "steps": passes,
+        "rows": n, "nnz": int(op.nnz), "shift": 1.5, "format": fmt,
+        "spmv": None if not spmv_us else {"avg_product_us": spmv_us, "bytes_per_launch": b_fmt + 24 * n,
+                                          "achieved_GBs": (b_fmt + 24 * n) / spmv_us / 1e3,
+                                          "frac": (b_fmt + 24 * n) / spmv_us / 1e3 / HBM_PEAK_GBS,
+                                          "note": "product + fused Lanczos step (reads r1, writes y and v: 24 n more)"},
+        "iteration_roofline": {"bytes_per_iter": b_fmt + 96 * n, "frac": (b_fmt + 96 * n) * passes / dt / 1e9 / HBM_PEAK_GBS,
+                               "note": "product in the format in use + the 96 n bytes of the fused kernels",
+                               "reference_op_count_bytes_per_iter": b_csr + 176 * n,
+                               "reference_op_count_GBs": (b_csr + 176 * n) * passes / dt / 1e9}}
     op.free()
     return out
 
@@ -296,8 +348,8 @@ def main():
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="host: collectives staged through host memory over gloo, all ranks on GPU 0 -- a smoke test "
                          "of the N > 1 path on a single-GPU box, not a measurement")
-    ap.add_argument("--all-configs", action="store_true",
-                    help="also time BASELINE configs[2] (BiCGSTAB, random n=1e6) and configs[3] (MINRES, n=4e6)")
+    ap.add_argument("--all-configs", action="store_true", help="(kept for compatibility: all BASELINE configs are in the "
+                                                               "default line now)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -356,7 +408,7 @@ def main():
 
     name = args.workload
     if name == "auto":
-        name = "poisson3d-512"
+        name = "poisson3d-512-varcoef"
 
     def device_sync():
         _lib.check(lib.mk_sync())
@@ -430,20 +482,22 @@ def main():
         return info
 
     def roofline_of(info, workload):
+        """Physical rooflines of a CG run: the SpMV kernel priced at the bytes it has to move in the storage format in
+        use, the iteration at those plus the 64 n bytes of the two fused update kernels."""
         steps = info["steps"]
         n_g, n_l = info["n_global"], info["n_local"]
-        b_spmv = spmv_bytes(n_l, info["op_shape"][1], info["nnz"])
+        b_csr = spmv_bytes(n_l, info["op_shape"][1], info["nnz"])
         tm = info["timing"]
         spmv_us = tm["spmv_b2b_us"]
-        achieved = b_spmv / (spmv_us * 1e-6) / 1e9 if spmv_us else None
         inloop_us = 1e3 * tm["spmv_ms"] / tm["spmv_launches"] if tm["spmv_launches"] else None
         stencil = info["meta"]["stencil"]
         nnz_global = stencil * n_g - 2 * sum(n_g // g for g in info["meta"]["grid"])
         its = steps / info["elapsed"]
         fmt = info["fmt"]
-        # bytes this kernel actually has to stream: the matrix in its storage format + x once + y (+ nothing for
-        # the fused dot): what an HBM counter would show with perfect reuse of x
-        actual = fmt["matrix_bytes_per_product"] + 8 * info["op_shape"][1] + 8 * n_l
+        # bytes this kernel has to stream: the matrix in its storage format + x once + y once (nothing for the fused
+        # dot: p[r] comes from the LDS window) -- what an HBM counter would show with perfect reuse of x
+        b_fmt = fmt["matrix_bytes_per_product"] + 8 * info["op_shape"][1] + 8 * n_l
+        achieved = b_fmt / (spmv_us * 1e-6) / 1e9 if spmv_us else None
         traffic, tnote = None, "no PMC profile for this kernel build under profiles/spmv_traffic.json"
         tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(tpath):
@@ -453,28 +507,30 @@ def main():
                 traffic, tnote = ent, "measured with rocprofv3 PMC at this kernel build (%s)" % tj.get("measured", "?")
             elif ent:
                 tnote = "profiles/spmv_traffic.json was measured at another kernel build or format: not quoted"
-        roof = {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpi> (CSR SpMV + fused <p,Ap>), " + fmt["format_name"],
+        roof = {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpi> (SpMV + fused <p,Ap>), " + fmt["format_name"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_note": tnote,
-                "bytes_per_launch": b_spmv, "avg_launch_us": spmv_us, "launches_timed": info["launches"],
+                "bytes_per_launch": b_fmt, "avg_launch_us": spmv_us, "launches_timed": info["launches"],
                 "method": "one hipEvent pair around back-to-back launches on the solver stream",
                 "inloop_event_pair_us": inloop_us,
-                "format_bytes_per_launch": actual,
-                "frac_of_format_bytes": (actual / (spmv_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if spmv_us else None,
-                "note": "achieved/frac price the launch at the ALGORITHMIC CSR bytes (12 nnz + 4(n+1) + 8 ncols + 8 nrows); "
-                        "format_bytes_per_launch is what the storage format in use streams, so frac > frac_of_format_bytes "
-                        "(and possibly > 1) when the format is more compact than CSR"}
-        # whole-iteration rooflines: the reference's op count (B_spmv + 104 n per pass) and the bytes
-        # the fused kernels of this implementation move (B_spmv + 64 n; with the format's matrix bytes)
-        n_sum = n_g
-        iter_bytes = spmv_bytes(n_g, n_g, nnz_global) + 104 * n_sum
-        fused = spmv_bytes(n_g, n_g, nnz_global) + 64 * n_sum
-        fused_fmt = (fmt["matrix_bytes_per_product"] * (n_g / float(n_l)) + 16 * n_g) + 64 * n_sum
+                "csr_bytes_per_launch": b_csr,
+                "csr_equivalent_GBs": (b_csr / (spmv_us * 1e-6) / 1e9) if spmv_us else None,
+                "note": "achieved/frac are PHYSICAL: bytes_per_launch = matrix data of the storage format in use + 8 ncols "
+                        "(x once) + 8 nrows (y once); csr_equivalent_GBs prices the same launch at the CSR bytes of "
+                        "SURVEY.md 8d (12 nnz + 4 (n+1) + 8 ncols + 8 nrows) and is a throughput, not a fraction of peak"}
+        # whole iteration: format bytes of the product + the 64 n bytes of the two fused update kernels (r update + dot:
+        # 16 n read, 8 n written; x, p update: 24 n read, 16 n written); beside it the reference's op count in CSR units
+        scale = n_g / float(n_l)
+        it_fmt = (fmt["matrix_bytes_per_product"] * scale + 16 * n_g) + 64 * n_g
+        it_ref = spmv_bytes(n_g, n_g, nnz_global) + 104 * n_g
         agg = HBM_PEAK_GBS * world_size
-        it_roof = {"algorithmic_bytes_per_iter": iter_bytes, "achieved_GBs": iter_bytes * its / 1e9,
-                   "frac_of_aggregate_hbm": iter_bytes * its / 1e9 / agg,
-                   "fused_bytes_per_iter": fused, "frac_fused": fused * its / 1e9 / agg,
-                   "format_fused_bytes_per_iter": int(fused_fmt), "frac_format_fused": fused_fmt * its / 1e9 / agg}
+        it_roof = {"bytes_per_iter": int(it_fmt), "achieved_GBs": it_fmt * its / 1e9,
+                   "frac_of_aggregate_hbm": it_fmt * its / 1e9 / agg,
+                   "note": "physical: product in the storage format in use + 64 n bytes of the fused update kernels",
+                   "reference_op_count_bytes_per_iter": it_ref, "reference_op_count_GBs": it_ref * its / 1e9,
+                   "reference_op_count_note": "SURVEY.md 8d: B_spmv(CSR) + 104 n per pass; a throughput in the "
+                                              "reference's units (for the 60 %% target: %.0f GB/s), not a fraction"
+                                              % (0.6 * agg)}
         return its, nnz_global, roof, it_roof
 
     multi = world_size > 1
@@ -484,6 +540,8 @@ def main():
     tm = info["timing"]
     n_g = info["n_global"]
     its, nnz_global, roof, it_roof = roofline_of(info, name)
+    tkind, tranks, tsplit = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.mk_comm_transport(ctypes.byref(tkind), ctypes.byref(tranks), ctypes.byref(tsplit)))
 
     line = {
         "metric": METRIC,
@@ -492,8 +550,11 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "CG %s (%d rows, %d nnz), rhs=A*1, x0=0, tolerances 0" % (name, n_g, nnz_global),
                    "baseline_config": ("configs[4]: CG on 3-D 7-point Poisson 512^3, the configuration the target is "
-                                       "quoted on (fits one GPU: same problem at every N, strong scaling); configs[1] "
-                                       "is reported under extra") if name == "poisson3d-512" else name,
+                                       "quoted on (fits one GPU: same problem at every N, strong scaling)%s; the other "
+                                       "BASELINE configs are reported under extra"
+                                       % (", here with a variable coefficient field so that no constant-coefficient "
+                                          "compression applies and the product streams 8 B per nonzero"
+                                          if name.endswith("-varcoef") else "")) if name.startswith("poisson3d-512") else name,
                    "solver": "cg", "rows": n_g, "nnz": nnz_global, "storage_format": info["fmt"],
                    "parallelism": "1 GPU" if not multi else "row-partition x%d, %s exchange + allreduce(dots), %s"
                                   % (world_size, first_mode, "RCCL (gloo bootstrap)" if transport_used == "rccl"
@@ -504,6 +565,9 @@ def main():
         "residual": {"first": info["resid_first"], "last": info["resid_last"]},
     }
     if multi:
+        # what actually carried the collectives (a silent host-staged fallback must not pass for an RCCL number)
+        line["transport"] = {"kind": {0: "none", 1: "rccl", 2: "host-staged"}[tkind.value],
+                             "rccl_ranks_seen": tranks.value, "halo_communicator_split": bool(tsplit.value)}
         ex = {first_mode: {"value": its, "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
                            "comm": info["comm"]}}
         if args.exchange == "both":
@@ -520,16 +584,25 @@ def main():
                                           "exchange); see iteration_roofline and exchange.*.comm")
     if rank == 0 and not multi and not args.no_cpu and not os.environ.get("BENCH_CHILD"):
         line["cpu_baseline"] = cpu_baseline(name)
-        line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(name)
-    if not multi and name == "poisson3d-512" and not args.no_extra:
-        # BASELINE configs[1] (CG, 2-D Poisson n = 1e6, one GPU): same measurement, reported beside the headline
-        exi = run_cg("poisson2d-1000", 2000, 200, 0)
-        e_its, e_nnz, e_roof, e_it = roofline_of(exi, "poisson2d-1000")
-        line["extra"] = {"poisson2d-1000@1": {"value": e_its, "unit": "iterations/s", "steps": 2000, "warmup": 200,
-                                              "ms_per_step": 1e3 * exi["elapsed"] / 2000, "roofline": e_roof,
-                                              "iteration_roofline": e_it, "storage_format": exi["fmt"]}}
-    if not multi and args.all_configs:
-        line.setdefault("extra", {}).update(other_configs(lib))
+        line["cpu_baseline_all_cores_extrapolated"] = cpu_baseline_all_cores(name)
+    if not multi and name.startswith("poisson3d-512") and not args.no_extra:
+        # the other BASELINE configs on one GPU, same measurement, reported beside the headline
+        extra = {}
+        others = [("poisson2d-1000", 2000, 200)]
+        if name.endswith("-varcoef"):
+            others.insert(0, ("poisson3d-512", max(100, args.steps // 2), max(10, args.warmup // 2)))
+        for wname, st, wu in others:
+            exi = run_cg(wname, st, wu, 0)
+            e_its, e_nnz, e_roof, e_it = roofline_of(exi, wname)
+            extra[wname + "@1"] = {"value": e_its, "unit": "iterations/s", "steps": st, "warmup": wu,
+                                   "ms_per_step": 1e3 * exi["elapsed"] / st, "roofline": e_roof,
+                                   "iteration_roofline": e_it, "storage_format": exi["fmt"]}
+        if "poisson3d-512@1" in extra:
+            extra["poisson3d-512@1"]["note"] = ("constant-coefficient special case of the headline workload: rows AND "
+                                                "values compress to one byte per row (format 4), so the product moves "
+                                                "a fraction of the CSR bytes; its roofline is priced at those bytes")
+        extra.update(other_configs(lib))
+        line["extra"] = extra
     if rank == 0:
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()

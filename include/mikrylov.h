@@ -90,6 +90,13 @@ int mk_csr_transpose(const mk_csr *A, mk_csr **out);
  * poisson3d: 7-point, nx x ny x nz grid, x fastest. */
 int mk_csr_poisson2d(int64_t m, int64_t row_begin, int64_t row_end, mk_csr **out);
 int mk_csr_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t row_begin, int64_t row_end, mk_csr **out);
+/* poisson3d_varcoef: -div(k grad u) on the same grid with the same sparsity (integer arrays identical to poisson3d),
+ * k a positive cell field hashed from `seed`; entries are minus the harmonic means of neighbouring cells, the diagonal
+ * their sum plus k itself per missing neighbour (Dirichlet).  SPD, practically all stored values distinct: the workload
+ * on which no constant-coefficient compression applies (bench.py `poisson3d-512-varcoef`; the matrix class a user's
+ * `matvec` brings to linop/linop.py:271-298). */
+int mk_csr_poisson3d_varcoef(int64_t nx, int64_t ny, int64_t nz, uint64_t seed, int64_t row_begin, int64_t row_end,
+                             mk_csr **out);
 
 /* Operator algebra that stays on the device (linop.py:307-330 `alpha * op`, :375-398 `op + other`, :403-426
  * `op - other`, :400-401 `-op`, with `other` a DiagonalOperator (:473-516), an IdentityOperator (:455-470) or a scalar
@@ -202,6 +209,10 @@ int mk_comm_init_host(int nranks, int rank, mk_host_allreduce_fn allreduce, mk_h
                       mk_host_allgather_fn allgather);
 int mk_comm_destroy(void);
 int mk_comm_info(int *nranks, int *rank);
+/* Which transport carries the collectives: *kind = 0 none, 1 RCCL, 2 host-staged callbacks; *rccl_ranks = what
+ * ncclCommCount reports for the communicator (0 without RCCL) -- bench.py prints it so that a host-staged fallback can
+ * never be mistaken for an RCCL measurement; *halo_comm_split = 1 if the halo messages have their own communicator. */
+int mk_comm_transport(int *kind, int *rccl_ranks, int *halo_comm_split);
 /* Attach an exchange plan to a local matrix whose columns are already remapped to
  * [local rows | halo]: before each SpMV the `send_count[r]` entries `send_idx`
  * (local indices, grouped by destination rank) go to rank r and `recv_count[r]` entries

@@ -162,6 +162,40 @@ def poisson3d(mx, my=None, mz=None):
     return from_coo(*[np.concatenate(c) for c in zip(*parts)], shape=(n, n))
 
 
+def cell_field(cells, seed):
+    """k(c) = 0.5 + u(c), u a 53-bit uniform from a splitmix64 hash of the cell number (twin of mk_cell_field,
+    pykrylov_amd/csrc/mk_core.hip)."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(cells).astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return 0.5 + (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+
+
+def poisson3d_varcoef(mx, my=None, mz=None, seed=7):
+    """Variable-coefficient 7-point operator -div(k grad u), Dirichlet: the sparsity of `poisson3d`; off-diagonal
+    entries are minus the harmonic means ((2 ka) kb) / (ka + kb) of the two cells' coefficients, the diagonal the
+    left-to-right sum over the directions (-z, -y, -x, +x, +y, +z) of that mean, or of k(c) where the neighbour is
+    missing.  Twin of gen_poisson3d_varcoef (bit-identical arrays)."""
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    n = mx * my * mz
+    idx = np.arange(n, dtype=np.int64)
+    gx, gy, gz = idx % mx, (idx // mx) % my, idx // (mx * my)
+    kc = cell_field(idx, seed)
+    dirs = ((gz > 0, -mx * my), (gy > 0, -mx), (gx > 0, -1), (gx < mx - 1, 1), (gy < my - 1, mx), (gz < mz - 1, mx * my))
+    terms = []
+    for ok, off in dirs:
+        kb = cell_field(np.where(ok, idx + off, idx), seed)
+        terms.append(np.where(ok, ((2.0 * kc) * kb) / (kc + kb), kc))
+    diag = ((((terms[0] + terms[1]) + terms[2]) + terms[3]) + terms[4]) + terms[5]
+    parts = [(idx, idx, diag)]
+    for (ok, off), t in zip(dirs, terms):
+        parts.append((idx[ok], idx[ok] + off, -t[ok]))
+    return from_coo(*[np.concatenate(c) for c in zip(*parts)], shape=(n, n))
+
+
 def random_diagdom(n, seed=1, k=4):
     """k random off-diagonals per row (duplicates summed,
     accidental diagonal hits dropped), diagonal = sum|offdiag| + 1."""

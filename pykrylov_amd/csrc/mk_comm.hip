@@ -27,6 +27,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *) = nullptr;   // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;                               // optional
 };
 
 Rccl g_rccl;
@@ -83,6 +84,7 @@ int load_rccl() {
     MK_SYM(GetErrorString, "ncclGetErrorString");
 #undef MK_SYM
     g_rccl.CommSplit = (decltype(g_rccl.CommSplit))dlsym(h, "ncclCommSplit");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
     g_rccl.handle = h;
     return MK_OK;
 }
@@ -234,6 +236,19 @@ extern "C" int mk_comm_destroy(void) {
 extern "C" int mk_comm_info(int *nranks, int *rank) {
     if (nranks) *nranks = g_nranks;
     if (rank) *rank = g_rank;
+    return MK_OK;
+}
+
+extern "C" int mk_comm_transport(int *kind, int *rccl_ranks, int *halo_comm_split) {
+    if (kind) *kind = g_host.active ? 2 : (g_comm ? 1 : 0);
+    if (rccl_ranks) {
+        *rccl_ranks = 0;
+        if (g_comm && g_rccl.CommCount) {
+            int c = 0;
+            if (g_rccl.CommCount(g_comm, &c) == ncclSuccess) *rccl_ranks = c;
+        }
+    }
+    if (halo_comm_split) *halo_comm_split = g_comm_halo ? 1 : 0;
     return MK_OK;
 }
 

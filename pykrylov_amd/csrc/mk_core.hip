@@ -561,6 +561,75 @@ extern "C" int mk_csr_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t row_
     return MK_OK;
 }
 
+// Variable-coefficient 7-point operator  -div(k grad u)  on the same grid, same sparsity (integer arrays identical to
+// gen_poisson3d), Dirichlet boundary.  Cell field k(c) = 0.5 + u(c), u(c) a 53-bit uniform from a splitmix64 hash of
+// the cell number; the entry between cells a and b is minus the harmonic mean h = ((2 ka) kb) / (ka + kb) (symmetric
+// bit for bit), the diagonal is the sum over the six directions, in storage order (-z, -y, -x, +x, +y, +z), of h where
+// the neighbour exists and of k(c) itself where it does not (the coefficient of the boundary face): strictly
+// diagonally dominant on boundary rows, SPD, and practically every stored value distinct -- no value dictionary, no
+// constant-coefficient shortcut applies: this is the matrix that exercises the CSR product proper.  NumPy twin in
+// the test infrastructure: csr_ref.poisson3d_varcoef (bit-identical arrays, tests/test_gpu_varcoef.py).
+__host__ __device__ static inline double mk_cell_field(int64_t c, uint64_t seed) {
+    uint64_t z = ((uint64_t)c + 1ULL) * 0x9E3779B97F4A7C15ULL + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return 0.5 + (double)(z >> 11) * 0x1.0p-53;
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void gen_poisson3d_varcoef(int64_t nx, int64_t ny, int64_t nz, uint64_t seed,
+                                                                  int64_t r_begin, int64_t r_end, int32_t *indptr,
+                                                                  int32_t *indices, double *data) {
+    const int64_t pl = nx * ny;
+    const int64_t base = p3d_prefix(r_begin, nx, ny, nz);
+    for (int64_t r = r_begin + (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r <= r_end;
+         r += (int64_t)gridDim.x * MK_BLOCK) {
+        int64_t p = p3d_prefix(r, nx, ny, nz) - base;
+        indptr[r - r_begin] = (int32_t)p;
+        if (r == r_end) break;
+        const int64_t gx = r % nx, gy = (r / nx) % ny, gz = r / pl;
+        const double kc = mk_cell_field(r, seed);
+        const bool have[6] = {gz > 0, gy > 0, gx > 0, gx < nx - 1, gy < ny - 1, gz < nz - 1};
+        const int64_t off[6] = {-pl, -nx, -1, 1, nx, pl};
+        double t[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            t[d] = kc;
+            if (have[d]) {
+                const double kb = mk_cell_field(r + off[d], seed);
+                t[d] = ((2.0 * kc) * kb) / (kc + kb);
+            }
+        }
+        const double diag = ((((t[0] + t[1]) + t[2]) + t[3]) + t[4]) + t[5];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (have[d]) { indices[p] = (int32_t)(r + off[d]); data[p++] = -t[d]; }
+        indices[p] = (int32_t)r; data[p++] = diag;
+#pragma unroll
+        for (int d = 3; d < 6; ++d)
+            if (have[d]) { indices[p] = (int32_t)(r + off[d]); data[p++] = -t[d]; }
+    }
+}
+
+extern "C" int mk_csr_poisson3d_varcoef(int64_t nx, int64_t ny, int64_t nz, uint64_t seed, int64_t row_begin,
+                                        int64_t row_end, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(nx >= 1 && ny >= 1 && nz >= 1 && row_begin >= 0 && row_begin <= row_end && row_end <= nx * ny * nz);
+    const int64_t nnz = p3d_prefix(row_end, nx, ny, nz) - p3d_prefix(row_begin, nx, ny, nz);
+    mk_csr *A = nullptr;
+    int rc = mk_csr_alloc(row_end - row_begin, nx * ny * nz, nnz, &A);
+    if (rc != MK_OK) return rc;
+    const int64_t rows = row_end - row_begin + 1;
+    int grid = (int)((rows + MK_BLOCK - 1) / MK_BLOCK);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(gen_poisson3d_varcoef, dim3(grid), dim3(MK_BLOCK), 0, mk_ctx().stream, nx, ny, nz, seed, row_begin,
+                       row_end, A->d_indptr, A->d_indices, A->d_data);
+    MK_HIP(hipGetLastError());
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    *out = A;
+    return MK_OK;
+}
+
 // ======================================================================================
 // transpose (K1T support): B = A^T with rows of B sorted by original row index
 // ======================================================================================

@@ -39,7 +39,8 @@ struct MkCsrView {
     // windowed tile format (mk_format.hip); fmt 0: none of this is read
     int fmt;                 // 0 plain CSR (gathers), 1 windows + uint16 LDS slots, 2 windows + slots + value dictionary,
                              // 3 plain CSR with the tile resident in LDS and the gathers ordered by column block,
-                             // 4 windows + dictionary + one pattern byte per row instead of a word per nonzero
+                             // 4 windows + dictionary + one pattern byte per row instead of a word per nonzero,
+                             // 5 windows + pattern byte per row + the raw values streamed in tile-sliced ELL order
     int wchunks;             // LDS chunks (128 doubles each) reserved for the x windows of a tile
     int ndict;
     const uint16_t *slots;   // per nonzero: position of its x entry in the tile's LDS window buffer
@@ -52,6 +53,9 @@ struct MkCsrView {
     const uint32_t *pat;
     const uint8_t *plen;
     int npat, pmax;
+    // fmt 5: the values in tile-sliced ELL order and per tile {start of its block / 256, width} (mk_spmv_fmt5.h)
+    const double *sval;
+    const int32_t *sdesc;
     int allwin;              // every tile of the matrix has windows (no tile ever takes the gather path)
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
@@ -84,7 +88,7 @@ static inline int mk_tile_map(const mk_csr *A) {
     // runs into the fabric on re-fetched x windows: XCD-contiguous blocks within every step of the grid keep neighbouring
     // tiles' windows in one L2 (512^3: fabric reads 4.4 -> 3.6 GB, 838 -> 790 us)
     const MkPlan *P = mk_csr_plan(A);
-    return (P && P->fmt == 4) ? 2 : 0;
+    return (P && (P->fmt == 4 || P->fmt == 5)) ? 2 : 0;
 }
 
 constexpr int MK_PROD_LD = MK_BLOCK + 1;             // (product staging buffer of the SpMV kernels, see below)
@@ -109,11 +113,11 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         if (g3 >= 8) g3 -= g3 % 8;
         return g3;
     }
-    if (P && P->fmt == 4) {                                  // up to 7 per CU, as many as LDS holds (8 per CU: 512^3 +3 %,
+    if (P && (P->fmt == 4 || P->fmt == 5)) {                 // up to 7 per CU, as many as LDS holds (8 per CU: 512^3 +3 %,
                                                              // 2-D n = 1e6 -4 %, and MINRES' epilogue spills at 64 registers)
         int64_t top = 128 * (int64_t)P->wchunks + 2;
         if (P->covered != A->ntiles && top < MK_PROD_LDS) top = MK_PROD_LDS;
-        const int64_t lds = 8 * (top + MK_BLOCK) + 16 * (int64_t)(P->npat * P->pmax + 1) + 2560;   // + static arrays
+        const int64_t lds = 8 * (top + MK_BLOCK) + (P->fmt == 4 ? 16 : 4) * (int64_t)(P->npat * P->pmax + 4) + 2560;   // + static arrays
         int64_t per_cu = (160 * 1024) / lds;
         per_cu = per_cu > 7 ? 7 : (per_cu < 1 ? 1 : per_cu);
         cap = 256 * per_cu;
@@ -174,6 +178,8 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.plen = P->d_plen;
         v.npat = P->npat;
         v.pmax = P->pmax;
+        v.sval = P->d_sval;
+        v.sdesc = P->d_sdesc;
         v.allwin = (P->covered == A->ntiles) ? 1 : 0;
     }
     return v;
@@ -370,460 +376,61 @@ __device__ __forceinline__ double mk_tile_gather(const MkCsrView &A, const doubl
     return sum;
 }
 
+// Tile order of a launch.  Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md) and each XCD has its
+// own 4 MiB L2; the order only affects speed (and which rows a workgroup's partial sums cover).
+struct MkTileRange {
+    int64_t pos, stride, end;
+};
+__device__ __forceinline__ MkTileRange mk_tile_range(const MkCsrView &A) {
+    const int G = gridDim.x;
+    const bool x8 = (G % 8 == 0);
+    MkTileRange t;
+    if (A.map == 1 && x8) {                                  // XCD b % 8 sweeps its own contiguous eighth
+        const int64_t chunk = (A.ntl + 7) / 8, c0 = (int64_t)(blockIdx.x % 8) * chunk;
+        t.pos = c0 + blockIdx.x / 8;
+        t.stride = G / 8;
+        t.end = (c0 + chunk < A.ntl) ? c0 + chunk : A.ntl;
+    } else if (A.map == 2 && x8) {                           // every step of the grid: eight XCD-contiguous blocks
+        t.pos = (int64_t)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
+        t.stride = G;
+        t.end = A.ntl;
+    } else {
+        t.pos = blockIdx.x;
+        t.stride = G;
+        t.end = A.ntl;
+    }
+    return t;
+}
+
+// Row pointers of a tile (one load per lane: a row's end is its neighbour's start and travels through LDS);
+// fetched ahead so that their latency is not on the critical path.  p: position in the tile list of this launch.
+__device__ __forceinline__ void mk_load_meta(const MkCsrView &A, int64_t p, int64_t end, MkTileMeta &m) {
+    m.p_lo = m.p_hi = m.my_lo = 0;
+    if (p < end) {
+        const int64_t tile = mk_tile_at(A, p);
+        const int64_t r0 = tile * MK_ROWS_PER_TILE;
+        const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
+        const int64_t r = r0 + (int)threadIdx.x;
+        m.p_lo = mk_sload(A.indptr + r0);
+        m.p_hi = mk_sload(A.indptr + rend);
+        m.my_lo = A.indptr[(r < rend) ? r : rend];          // rows past the end start (and end) at p_hi
+    }
+}
+
+#include "mk_spmv_fmt0.h"
+#include "mk_spmv_fmt1.h"
+#include "mk_spmv_fmt24.h"
+#include "mk_spmv_fmt3.h"
+#include "mk_spmv_fmt5.h"
+
 template <int FMT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
                                               double *prod, double *xw, double (&acc)[NACC]) {
-    const int tid = threadIdx.x;
-    // Tile order.  Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md) and each XCD has its own
-    // 4 MiB L2; the order only affects speed (and which rows a workgroup's partial sums cover).
-    const int G = gridDim.x;
-    const bool x8 = (G % 8 == 0);
-    int64_t pos, stride, end;
-    if (A.map == 1 && x8) {                                  // XCD b % 8 sweeps its own contiguous eighth
-        const int64_t chunk = (A.ntl + 7) / 8, c0 = (int64_t)(blockIdx.x % 8) * chunk;
-        pos = c0 + blockIdx.x / 8;
-        stride = G / 8;
-        end = (c0 + chunk < A.ntl) ? c0 + chunk : A.ntl;
-    } else if (A.map == 2 && x8) {                           // every step of the grid: eight XCD-contiguous blocks
-        pos = (int64_t)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
-        stride = G;
-        end = A.ntl;
-    } else {
-        pos = blockIdx.x;
-        stride = G;
-        end = A.ntl;
-    }
-    __shared__ int sptr[MK_BLOCK + 1];
-    // Row pointers of a tile (one load per lane: a row's end is its neighbour's start and travels through LDS);
-    // fetched ahead so that their latency is not on the critical path.
-    auto load_meta = [&](int64_t p, MkTileMeta &m) {         // p: position in the tile list of this launch
-        m.p_lo = m.p_hi = m.my_lo = 0;
-        if (p < end) {
-            const int64_t tile = mk_tile_at(A, p);
-            const int64_t r0 = tile * MK_ROWS_PER_TILE;
-            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
-            const int64_t r = r0 + tid;
-            m.p_lo = mk_sload(A.indptr + r0);
-            m.p_hi = mk_sload(A.indptr + rend);
-            m.my_lo = A.indptr[(r < rend) ? r : rend];      // rows past the end start (and end) at p_hi
-        }
-    };
-    if constexpr (FMT == 0) {
-        MkTileMeta cur, nxt;
-        load_meta(pos, cur);
-        for (; pos < end; pos += stride) {
-            const int64_t tile = mk_tile_at(A, pos);
-            const int64_t r0 = tile * MK_ROWS_PER_TILE;
-            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
-            const int64_t r = r0 + tid;
-            if constexpr (MkHasPre<Epi>::value) {
-                if (r < rend) epi.pre(r);
-            }
-            load_meta(pos + stride, nxt);                    // next tile's row pointers go in flight now
-            const double sum0 = (A.sum_in && r < rend) ? A.sum_in[r] : 0.0;   // (column-blocked product: carried sums)
-            double sum = mk_tile_gather(A, x, epi, prod, sptr, cur, sum0);
-            if constexpr (PROG) {                            // composed operators only (separate instantiation)
-                if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
-            }
-            if (r < rend) epi.row(r, sum, acc);
-            cur = nxt;
-        }
-    } else if constexpr (FMT == 3) {
-        // ---- resident tiles with column phases: for matrices whose x is too long for an XCD's L2 and whose columns no
-        // window covers (BASELINE config 3).  The tile's (column, value) stream goes to LDS once (global_load_lds);
-        // then lane t walks row t with a cursor, left to right as everywhere, but in rt_k PHASES: phase k takes the
-        // row's entries whose column lies in block k (columns ascend within a row, so a phase is a contiguous run).
-        // All workgroups of the grid are resident and start their tiles together, so at any moment the whole chip
-        // gathers from ONE slice of x that an L2 holds, instead of pulling a 64-byte sector through the fabric per
-        // nonzero (rocprof on the gather path: 371 MB of fabric reads for 80 MB of algorithmic bytes; the raw cost of
-        // 5 M scattered 8-byte gathers from 8 MB alone is 40 us, tools/ubench/spmv_cb.hip).  No barrier and no
-        // global load other than the gathers inside the phases.
-        const int lane = tid & 63;
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int cap = A.rt_cap;
-        double *lv = prod;                                   // [cap] values, then [cap] columns
-        int *lc = reinterpret_cast<int *>(prod + cap);
-        for (; pos < end; pos += stride) {
-            const int64_t tile = mk_tile_at(A, pos);
-            const int64_t r0 = tile * MK_ROWS_PER_TILE;
-            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
-            const int64_t r = r0 + tid;
-            const int p_lo = mk_sload(A.indptr + r0), p_hi = mk_sload(A.indptr + rend);
-            const int base = p_lo & ~3, cnt = p_hi - base;   // cnt <= cap (builder)
-            const int last = (cnt > 0) ? ((cnt - 1) & ~3) : 0;
-            for (int c0 = wv * 256; c0 < cnt; c0 += 4 * 256) {                  // 256 columns per wave-level copy
-                int j = c0 + 4 * lane;
-                j = j < last ? j : last;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.indices + base + j),
-                                                 (__attribute__((address_space(3))) void *)(lc + c0), 16, 0, 0);
-            }
-            const int lastv = (cnt > 0) ? ((cnt - 1) & ~1) : 0;
-            for (int c0 = wv * 128; c0 < cnt; c0 += 4 * 128) {                  // 128 values per wave-level copy
-                int j = c0 + 2 * lane;
-                j = j < lastv ? j : lastv;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.data + base + j),
-                                                 (__attribute__((address_space(3))) void *)(lv + c0), 16, 0, 0);
-            }
-            int cur = 0, fin = 0;
-            if (r < rend) {
-                cur = A.indptr[r] - base;
-                fin = A.indptr[r + 1] - base;
-            }
-            if constexpr (MkHasPre<Epi>::value) {
-                if (r < rend) epi.pre(r);
-            }
-            double sum = (A.sum_in && r < rend) ? A.sum_in[r] : 0.0;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int k = 0; k < A.rt_k; ++k) {
-                const int c1 = (k + 1 < A.rt_k) ? (k + 1) * A.rt_w : 0x7fffffff;
-                for (;;) {
-                    int ca = 0x7fffffff;
-                    if (cur < fin) ca = lc[cur];
-                    const bool oa = ca < c1;
-                    if (oa) {
-                        const double xa = x[ca];
-                        sum += lv[cur] * epi.xin(xa);
-                        cur += 1;
-                    }
-                    if (!__any(oa)) break;                   // (wave level: no lane of this wave has more in phase k)
-                }
-            }
-            if constexpr (PROG) {
-                if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
-            }
-            if (r < rend) epi.row(r, sum, acc);
-            __syncthreads();                                 // the next tile's copies overwrite this LDS
-        }
-    } else if constexpr (FMT == 2 || FMT == 4) {
-        constexpr bool PAT = (FMT == 4);
-        // ---- windowed tiles with a value dictionary: ROW PHASE ONLY.  One 32-bit word per nonzero {slot | code};
-        // the words and the x windows of a tile go straight to LDS with global_load_lds (no VGPR round trip, no
-        // per-nonzero staging work); after one barrier lane t walks row t left to right: word, x and value from LDS
-        // (consecutive rows read consecutive words / x entries: conflict free for the usual odd row lengths).
-        // Measured against the product-staging design of fmt 1 with the codes: 512^3 1.50 -> 1.32 ms, 2-D n = 1e6
-        // 13.1 -> 9.1 us (tools/ubench/spmv_win2.hip, w3 vs w7).
-        // fmt 4 (PAT) goes one step further: a row is described by ONE BYTE, the number of its pattern -- the sequence
-        // of its words relative to the lane, {slot - t, code} -- and the pattern table (<= 8 KB) sits in LDS for the
-        // whole kernel.  The per-nonzero stream and the row pointers are not read at all: what a tile ingests is its
-        // x windows and 256 bytes.
-        const int lane = tid & 63;
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        // fmt 2: a tile's packed words behind its windows.  fmt 4: the pattern table, which lives as long as the kernel
-        // and therefore sits behind everything the gather path of a tile without windows may overwrite
-        // (unless every tile has windows: then the gather path never runs, A.allwin)
-        const int wtop = 128 * A.wchunks + 2;
-        uint32_t *spk = reinterpret_cast<uint32_t *>(xw + ((PAT && !A.allwin && wtop < MK_PROD_LDS) ? MK_PROD_LDS : wtop));
-        __shared__ double sdict[PAT ? 1 : 256];              // (fmt 4 keeps the values in its pattern table)
-        if constexpr (!PAT) sdict[tid] = (tid < A.ndict) ? A.dict[tid] : 0.0;   // (read after a barrier below)
-        [[maybe_unused]] __shared__ int splen[PAT ? 256 : 1];
-        // fmt 4: behind the windows (and whatever the gather path may overwrite) 256 zeros, then the pattern table in
-        // the form the row phase consumes with the fewest instructions -- per entry {byte offset of its x value
-        // relative to the lane's own cell, the VALUE itself}: one 16-byte LDS read, one add, one 8-byte LDS read, one
-        // multiply, one add.  Entries past a pattern's end point at the lane's zero cell with value +0.0: their
-        // product is +-0.0 and leaves the running sum (never -0.0, it started at +0.0) unchanged, so nothing is masked.
-        struct PatEntry {
-            int off, pad;
-            double val;
-        };
-        [[maybe_unused]] PatEntry *ftab = nullptr;
-        [[maybe_unused]] int zoff = 0;
-        if constexpr (PAT) {
-            double *zeros = reinterpret_cast<double *>(spk);
-            ftab = reinterpret_cast<PatEntry *>(zeros + MK_BLOCK);
-            zoff = (int)((zeros - xw) * (int)sizeof(double));
-            zeros[tid] = 0.0;
-            for (int e = tid; e < A.npat * A.pmax; e += MK_BLOCK) {
-                const int pnum = e / A.pmax, k = e - pnum * A.pmax;
-                const uint32_t w = A.pat[e];
-                PatEntry en;
-                en.pad = 0;
-                if (k < (int)A.plen[pnum]) {
-                    en.off = 8 * (int)(short)(w & 0xffffu);
-                    en.val = A.dict[w >> 16];
-                } else {
-                    en.off = zoff;
-                    en.val = 0.0;
-                }
-                ftab[e] = en;
-            }
-            splen[tid] = (tid < A.npat) ? ((int)A.plen[tid] | ((int)A.plen[256 + tid] << 8)) : (255 << 8);
-        }
-        const double d0 = A.dict[0], d1 = A.dict[A.ndict > 1 ? 1 : 0];
-        const bool two = A.ndict <= 2;                       // value picked in registers instead of read from LDS
-        // this wave's window descriptor of a tile (scalar loads, issued one tile ahead like the row pointers)
-        struct Desc {
-            mk_i4 g;
-            unsigned nvw;
-        };
-        auto load_desc = [&](int64_t p, Desc &d) {
-            d.g = mk_i4{0, 0, 0, 0};
-            d.nvw = 0;
-            if (p < end) {
-                const int64_t t = mk_tile_at(A, p);
-                d.g = mk_sload(reinterpret_cast<const mk_i4 *>(A.wg + (t * 4 + wv) * 4));
-                d.nvw = mk_sload(A.wn + t * 4 + wv);
-            }
-        };
-        MkTileMeta cur, nxt;
-        Desc dcur, dnxt;
-        if constexpr (!PAT) load_meta(pos, cur);
-        load_desc(pos, dcur);
-        for (; pos < end; pos += stride) {
-            const int64_t tile = mk_tile_at(A, pos);
-            const int64_t r0 = tile * MK_ROWS_PER_TILE;
-            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
-            const int64_t r = r0 + tid;
-            constexpr bool ROWX = PAT && !PROG && MkHasRowX<Epi>::value;
-            if constexpr (MkHasPre<Epi>::value && !ROWX) {
-                if (r < rend) epi.pre(r);
-            }
-            const mk_i4 g = dcur.g;
-            double sum = 0.0;
-            [[maybe_unused]] double xr_cur = 0.0;
-            if (g.x & 1) {
-                const unsigned nvw = dcur.nvw;
-                const int gs[4] = {g.x & ~1, g.y, g.z, g.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int hc = (int)((nvw >> (8 * i)) & 0xffu);
-                    if (hc > 0) {
-                        const int l2 = (lane < hc) ? lane : hc - 1;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + gs[i] + 2 * l2),
-                                                         (__attribute__((address_space(3))) void *)(xw + (wv + 4 * i) * 128),
-                                                         16, 0, 0);
-                    }
-                }
-                int lo = 0, len = 0;
-                [[maybe_unused]] int kdiag = 255;
-                if constexpr (PAT) {
-                    const unsigned id = (r < rend) ? (unsigned)A.pid[r] : 0u;   // one byte per row
-                    load_desc(pos + stride, dnxt);           // next tile's descriptor goes in flight
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    lo = (int)id * A.pmax;
-                    len = (r < rend) ? (splen[id] & 0xff) : 0;
-                    kdiag = splen[id] >> 8;
-                    const char *cell = reinterpret_cast<const char *>(xw + tid);    // this lane's own cell
-                    const PatEntry *pe = ftab + lo;
-                    PatEntry en[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) en[k] = pe[k];
-                    double xk[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) xk[k] = epi.xin(*reinterpret_cast<const double *>(cell + en[k].off));
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) sum += en[k].val * xk[k];
-                    for (int k = 8; k < len; ++k)
-                        sum += pe[k].val * epi.xin(*reinterpret_cast<const double *>(cell + pe[k].off));
-                    if constexpr (ROWX) {                    // x[r] for the epilogue: the diagonal entry's cell
-                        if (kdiag < len) xr_cur = epi.xin(*reinterpret_cast<const double *>(cell + pe[kdiag].off));
-                        else if (r < rend) xr_cur = epi.xin(x[r]);
-                    }
-                    __syncthreads();                         // the next tile's copies overwrite this LDS
-                    if constexpr (PROG) {
-                        if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
-                    }
-                    if constexpr (ROWX) {
-                        if (r < rend) epi.row_x(r, sum, xr_cur, acc);
-                    } else {
-                        if (r < rend) epi.row(r, sum, acc);
-                    }
-                    cur = nxt;
-                    dcur = dnxt;
-                    continue;
-                } else {
-                    const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
-                    const int base = p_lo & ~3, cnt = p_hi - base;         // 0 < cnt <= MK_SPMV_TILE + 3 (builder)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {                            // 256 words per wave-level copy
-                        const int c0 = (wv + 4 * c) * 256;
-                        if (c0 < cnt)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.pk + base + c0 + 4 * lane),
-                                                             (__attribute__((address_space(3))) void *)(spk + c0), 16, 0, 0);
-                    }
-                    load_meta(pos + stride, nxt);            // next tile's row pointers and descriptor go in flight
-                    load_desc(pos + stride, dnxt);
-                    sptr[tid] = my_lo;
-                    if (tid == 0) sptr[MK_BLOCK] = p_hi;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    const int my_hi = sptr[tid + 1];
-                    lo = my_lo - base;
-                    len = my_hi - my_lo;
-                }
-                if constexpr (!PAT) {
-                auto slot_of = [&](unsigned w, int) -> unsigned { return w & 0xffffu; };
-                unsigned wk[8];
-                double xk[8], vk[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) wk[k] = spk[lo + k];
-                if (two) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        xk[k] = epi.xin(xw[slot_of(wk[k], k)]);
-                        vk[k] = (wk[k] >> 16) ? d1 : d0;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        xk[k] = epi.xin(xw[slot_of(wk[k], k)]);
-                        vk[k] = sdict[wk[k] >> 16];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const double t = vk[k] * xk[k];
-                    sum += (k < len) ? t : 0.0;              // (+0.0 never changes a running sum that started at +0.0)
-                }
-                for (int k = 8; k < len; ++k) {
-                    const unsigned w = spk[lo + k];
-                    sum += sdict[w >> 16] * epi.xin(xw[slot_of(w, k)]);
-                }
-                __syncthreads();                             // the next tile's copies overwrite this LDS
-                }
-            } else {
-                if constexpr (ROWX) {
-                    if (r < rend) xr_cur = epi.xin(x[r]);
-                }
-                if constexpr (PAT) load_meta(pos, cur);      // (tiles without windows are rare: their row pointers now)
-                else load_meta(pos + stride, nxt);
-                load_desc(pos + stride, dnxt);
-                sum = mk_tile_gather(A, x, epi, prod, sptr, cur);
-            }
-            if constexpr (PROG) {
-                if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
-            }
-            if constexpr (ROWX) {
-                if (r < rend) epi.row_x(r, sum, xr_cur, acc);
-            } else {
-                if (r < rend) epi.row(r, sum, acc);
-            }
-            cur = nxt;
-            dcur = dnxt;
-        }
-    } else {
-        const int lane = tid & 63;
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        struct WRegs {
-            mk_u4 s;
-            mk_d2 val[4];
-            mk_d2 w[4];
-            unsigned nvw;
-            bool valid;
-        };
-        // everything a windowed tile needs from memory, into registers (no use of the values here)
-        auto issue = [&](int64_t p, const MkTileMeta &m, WRegs &R) {
-            R.valid = false;
-            R.nvw = 0;
-            if (p >= end) return;
-            const int64_t tile = mk_tile_at(A, p);
-            const mk_i4 g = mk_sload(reinterpret_cast<const mk_i4 *>(A.wg + (tile * 4 + wv) * 4));
-            const unsigned nvw = mk_sload(A.wn + tile * 4 + wv);
-            if (!(g.x & 1)) return;                          // the builder could not cover this tile: gather path
-            R.valid = true;
-            R.nvw = nvw;
-            const int gs[4] = {g.x & ~1, g.y, g.z, g.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int hc = (int)((R.nvw >> (8 * i)) & 0xffu);
-                if (hc > 0) {
-                    const int l2 = (lane < hc) ? lane : hc - 1;
-                    R.w[i] = *reinterpret_cast<const mk_d2 *>(x + gs[i] + 2 * l2);
-                }
-            }
-            const int base = m.p_lo & ~7, cnt = m.p_hi - base;           // 0 < cnt <= MK_SPMV_TILE (builder)
-            int j = 8 * tid;
-            j = (j < cnt) ? j : ((cnt - 1) & ~7);
-            R.s = *reinterpret_cast<const mk_u4 *>(A.slots + base + j);
-#pragma unroll
-            for (int h = 0; h < 4; ++h) R.val[h] = *reinterpret_cast<const mk_d2 *>(A.data + base + j + 2 * h);
-        };
-        MkTileMeta cur, nxt, nx2;
-        WRegs R;
-        load_meta(pos, cur);
-        load_meta(pos + stride, nxt);
-        issue(pos, cur, R);
-        bool lds_busy = false;                               // products of a windowed tile may still be read by slower waves
-        bool zero_ok = false;                                // the zero column of the staging buffer is in place
-        for (; pos < end; pos += stride) {
-            const int64_t tile = mk_tile_at(A, pos);
-            const int64_t r0 = tile * MK_ROWS_PER_TILE;
-            const int64_t rend = (r0 + MK_ROWS_PER_TILE < A.nrows) ? r0 + MK_ROWS_PER_TILE : A.nrows;
-            const int64_t r = r0 + tid;
-            if constexpr (MkHasPre<Epi>::value) {
-                if (r < rend) epi.pre(r);
-            }
-            double sum = 0.0;
-            if (R.valid) {
-                const int p_lo = cur.p_lo, p_hi = cur.p_hi, my_lo = cur.my_lo;
-                const int base = p_lo & ~7;
-                // windows -> LDS (the epilogue's on-the-fly scaling of x is applied here, once per entry)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int hc = (int)((R.nvw >> (8 * i)) & 0xffu);
-                    if (hc > 0) {
-                        mk_d2 v;
-                        v.x = epi.xin(R.w[i].x);
-                        v.y = epi.xin(R.w[i].y);
-                        *reinterpret_cast<mk_d2 *>(xw + (wv + 4 * i) * 128 + 2 * lane) = v;
-                    }
-                }
-                sptr[tid] = my_lo;
-                if (tid == 0) sptr[MK_BLOCK] = p_hi;
-                __syncthreads();
-                const int my_hi = sptr[tid + 1];
-                // ---- pass 1: products of this lane's 8 nonzeros against the LDS windows
-                const unsigned sw[4] = {R.s.x, R.s.y, R.s.z, R.s.w};
-                double pr[8];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const double x0 = xw[sw[h] & 0xffffu], x1 = xw[sw[h] >> 16];
-                    pr[2 * h] = R.val[h].x * x0;
-                    pr[2 * h + 1] = R.val[h].y * x1;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) prod[i * MK_PROD_LD + tid] = pr[i];
-                if (!zero_ok) {                              // (a gather tile overwrote the zero column)
-                    if (tid < 8) prod[tid * MK_PROD_LD + MK_BLOCK] = 0.0;
-                    zero_ok = true;
-                }
-                // the registers are free: the next tile's input goes in flight and lands during pass 2
-                load_meta(pos + 2 * stride, nx2);
-                issue(pos + stride, nxt, R);
-                __syncthreads();
-                // ---- pass 2: one lane per row, left-to-right sum of its segment.  Entry lo + k sits at
-                // [(a + k) & 7][b + carry]: one of two precomputed bases plus a compile-time offset.
-                const int lo = my_lo - base, len = my_hi - my_lo;
-                const int a = lo & 7;
-                const int adA = a * MK_PROD_LD + (lo >> 3), adB = adA - (8 * MK_PROD_LD - 1);
-                double t[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    int ad = (a + k >= 8) ? adB : adA;
-                    ad = (k < len) ? ad : MK_BLOCK;          // past the row: the zero column
-                    t[k] = prod[ad + k * MK_PROD_LD];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) sum += t[k];
-                for (int k = 8; k < len; ++k) sum += prod[mk_phys(lo + k)];
-                lds_busy = true;
-            } else {
-                if (lds_busy) __syncthreads();               // slower waves may still read the previous tile's products
-                load_meta(pos + 2 * stride, nx2);
-                sum = mk_tile_gather(A, x, epi, prod, sptr, cur);
-                issue(pos + stride, nxt, R);
-                lds_busy = false;
-                zero_ok = false;
-            }
-            if constexpr (PROG) {
-                if (r < rend) sum = mk_rowprog(A, sum, x, r, epi);
-            }
-            if (r < rend) epi.row(r, sum, acc);
-            cur = nxt;
-            nxt = nx2;
-        }
-    }
+    if constexpr (FMT == 0) mk_spmv_tiles_fmt0<PROG>(A, x, epi, prod, xw, acc);
+    else if constexpr (FMT == 1) mk_spmv_tiles_fmt1<PROG>(A, x, epi, prod, xw, acc);
+    else if constexpr (FMT == 3) mk_spmv_tiles_fmt3<PROG>(A, x, epi, prod, xw, acc);
+    else if constexpr (FMT == 5) mk_spmv_tiles_fmt5<PROG>(A, x, epi, prod, xw, acc);
+    else mk_spmv_tiles_fmt24<FMT, PROG>(A, x, epi, prod, xw, acc);
 }
 
 // Gate: a test on a global sum that must be settled before the product may start (e.g. the loop
@@ -834,13 +441,13 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : (FMT == 4 ? 7 : 4)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : ((FMT == 4 || FMT == 5) ? 7 : 4)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
     extern __shared__ __attribute__((aligned(16))) double mk_smem[];
     double *prod = mk_smem;
-    double *xw = (FMT == 2 || FMT == 4) ? mk_smem : mk_smem + MK_PROD_LDS;
+    double *xw = (FMT == 2 || FMT == 4 || FMT == 5) ? mk_smem : mk_smem + MK_PROD_LDS;
     __shared__ double s4[4];
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -902,6 +509,12 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
         lds = sizeof(double) * (wtop + MK_BLOCK) + 16 * (size_t)(v.npat * v.pmax + 1);   // windows, zeros, table
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 4>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                           halt, partials);
+    } else if (v.fmt == 5) {                                 // windows + zeros + offset table, or the gather path's products
+        size_t wtop = (size_t)(128 * v.wchunks + 2);
+        if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
+        lds = sizeof(double) * (wtop + MK_BLOCK) + 4 * (size_t)(v.npat * v.pmax + 4);
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 5>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                            halt, partials);
     } else if (v.fmt == 3) {                                 // the tile's values and columns
         lds = (size_t)v.rt_cap * 12;

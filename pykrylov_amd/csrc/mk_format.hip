@@ -224,12 +224,13 @@ __global__ __launch_bounds__(MK_BLOCK) void dict_encode(int64_t nnz, const doubl
 // hash collision can only make the builder give up, never change a product.
 constexpr int PAT_WORDS = 1024;                              // table capacity in entries (npat * pmax): <= 16 KB of LDS
 
-__device__ inline int pat_row_words(const int32_t *__restrict__ ip, const uint32_t *__restrict__ pk, int64_t r, int t,
-                                    int pmax, uint32_t *w) {
+// (pk == null: a matrix without a value dictionary -- the words are the bare LDS slots, fmt 5)
+__device__ inline int pat_row_words(const int32_t *__restrict__ ip, const uint32_t *__restrict__ pk,
+                                    const uint16_t *__restrict__ sl, int64_t r, int t, int pmax, uint32_t *w) {
     const int lo = ip[r], len = ip[r + 1] - lo;
     if (len > pmax) return -1;
     for (int k = 0; k < len; ++k) {
-        const uint32_t word = pk[lo + k];
+        const uint32_t word = pk ? pk[lo + k] : (uint32_t)sl[lo + k];
         w[k] = ((word & 0xffffu) - (uint32_t)t) & 0xffffu;
         w[k] |= (word >> 16) << 16;
     }
@@ -277,13 +278,14 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_maxlen(int64_t nrows, const int3
 
 __global__ __launch_bounds__(MK_BLOCK) void pat_collect(int64_t nrows, const int32_t *__restrict__ ip,
                                                         const int32_t *__restrict__ wg, const uint32_t *__restrict__ pk,
+                                                        const uint16_t *__restrict__ sl,
                                                         int pmax, int limit, unsigned long long *table, int *state) {
     unsigned long long seen = DICT_EMPTY;
     for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
         if (!(wg[(r / MK_ROWS_PER_TILE) * 16] & 1)) continue;
         if (__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         uint32_t w[32];
-        const int len = pat_row_words(ip, pk, r, (int)(r % MK_ROWS_PER_TILE), pmax, w);
+        const int len = pat_row_words(ip, pk, sl, r, (int)(r % MK_ROWS_PER_TILE), pmax, w);
         if (len < 0) {
             state[1] = 1;
             return;
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_collect(int64_t nrows, const int
 __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int32_t *__restrict__ ip,
                                                        const int32_t *__restrict__ ix,
                                                        const int32_t *__restrict__ wg, const uint32_t *__restrict__ pk,
+                                                       const uint16_t *__restrict__ sl,
                                                        int pmax, int count, const double *__restrict__ sorted_keys,
                                                        uint8_t *__restrict__ pid, uint32_t *__restrict__ pat,
                                                        uint8_t *__restrict__ plen, int mode, int *state) {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
             continue;
         }
         uint32_t w[32];
-        const int len = pat_row_words(ip, pk, r, (int)(r % MK_ROWS_PER_TILE), pmax, w);
+        const int len = pat_row_words(ip, pk, sl, r, (int)(r % MK_ROWS_PER_TILE), pmax, w);
         int kd = 255;
         for (int q = 0; q < len; ++q)
             if ((int64_t)ix[ip[r] + q] == r) kd = q;
@@ -332,6 +335,42 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
             bool same = (plen[id] == len) && (plen[256 + id] == kd);
             for (int q = 0; q < len && same; ++q) same = (pat[id * pmax + q] == w[q]);
             if (!same) state[1] = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sliced ELL values
+// fmt 5: the values of every windowed tile in the order the pattern kernel's lanes consume them (mk_spmv_fmt5.h).
+// width[T] = longest row of tile T (0 for a tile without windows: it keeps the CSR gather path)
+__global__ __launch_bounds__(MK_BLOCK) void sell_width(int64_t nrows, int64_t ntiles, const int32_t *__restrict__ ip,
+                                                       const int32_t *__restrict__ wg, int32_t *__restrict__ width) {
+    __shared__ int mx;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) mx = 0;
+        __syncthreads();
+        const int64_t r = tile * MK_ROWS_PER_TILE + threadIdx.x;
+        if ((wg[tile * 16] & 1) && r < nrows) atomicMax(&mx, ip[r + 1] - ip[r]);
+        __syncthreads();
+        if (threadIdx.x == 0) width[tile] = mx;
+    }
+}
+
+// sdesc[2 T] = start of tile T's block in units of 256 doubles, sdesc[2 T + 1] = its width
+__global__ __launch_bounds__(MK_BLOCK) void sell_fill(int64_t nrows, int64_t ntiles, const int32_t *__restrict__ ip,
+                                                      const double *__restrict__ dv, const int32_t *__restrict__ sdesc,
+                                                      double *__restrict__ sval) {
+    const int t = threadIdx.x;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int w = sdesc[2 * tile + 1];
+        if (w == 0) continue;
+        double *vb = sval + (int64_t)sdesc[2 * tile] * MK_ROWS_PER_TILE;
+        const int64_t r = tile * MK_ROWS_PER_TILE + t;
+        const int lo = (r < nrows) ? ip[r] : 0, len = (r < nrows) ? ip[r + 1] - lo : 0;
+        for (int k = 0; k < w; ++k) {
+            const double v = (k < len) ? dv[lo + k] : 0.0;
+            const int64_t at = (k < (w & ~1)) ? (int64_t)(k >> 1) * 512 + 2 * t + (k & 1) : (int64_t)k * 256 + t;
+            vb[at] = v;
         }
     }
 }
@@ -393,14 +432,16 @@ void plan_free(MkPlan &P) {
     hipFree(P.d_pid);
     hipFree(P.d_pat);
     hipFree(P.d_plen);
+    hipFree(P.d_sval);
+    hipFree(P.d_sdesc);
     P = MkPlan();
 }
 
 int default_format() {
     static int f = [] {
         const char *e = getenv("MK_SPMV_FORMAT");
-        int v = e ? atoi(e) : 4;
-        return v < 0 ? 0 : (v > 4 ? 4 : v);
+        int v = e ? atoi(e) : 5;
+        return v < 0 ? 0 : (v > 5 ? 5 : v);
     }();
     return f;
 }
@@ -518,9 +559,11 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
 }
 
 // fmt 2 -> fmt 4 when every row of every windowed tile follows one of a few patterns (see above).  Any failure leaves
-// the matrix in fmt 2.
-void pattern_plan(const mk_csr *A, MkPlan &P) {
+// the matrix in fmt 2.  `raw`: fmt 1 -> fmt 5, the same for a matrix without a value dictionary -- patterns of the bare
+// slots, and the values copied into tile-sliced ELL order (any failure, or more than 12.5 % of padding: stays fmt 1).
+void pattern_plan(const mk_csr *A, MkPlan &P, bool raw) {
     if (getenv("MK_NO_PATTERNS")) return;
+    const uint32_t *words = raw ? nullptr : P.d_pk;
     hipStream_t st = mk_ctx().stream;
     int *d_state = nullptr;
     unsigned long long *d_table = nullptr;
@@ -547,6 +590,7 @@ void pattern_plan(const mk_csr *A, MkPlan &P) {
     const int maxlen = h_state[0];
     const int pmax = maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : (maxlen <= 32 ? 32 : 0));
     if (pmax == 0 || maxlen < 1) return cleanup();
+    if (raw && pmax != 8) return cleanup();                  // (the fmt 5 kernel keeps a row's values in 8 registers)
     const int limit = PAT_WORDS / pmax > 256 ? 256 : PAT_WORDS / pmax;
     std::vector<unsigned long long> empty(DICT_SLOTS, DICT_EMPTY);
     if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS) != hipSuccess ||
@@ -559,19 +603,56 @@ void pattern_plan(const mk_csr *A, MkPlan &P) {
     hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
     hipMemsetAsync(d_pat, 0, sizeof(uint32_t) * PAT_WORDS, st);
     hipMemsetAsync(d_plen, 0, 512, st);
-    hipLaunchKernelGGL(pat_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, P.d_pk, pmax, limit,
-                       d_table, d_state);
+    hipLaunchKernelGGL(pat_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, words, P.d_slots,
+                       pmax, limit, d_table, d_state);
     if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess || h_state[1] || h_state[0] < 1 || h_state[0] > limit)
         return cleanup();
     const int count = h_state[0];
     hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_keys);
     for (int mode = 0; mode < 2; ++mode)
-        hipLaunchKernelGGL(pat_assign, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, P.d_wg, P.d_pk, pmax, count,
-                           d_keys, d_pid, d_pat, d_plen, mode, d_state);
+        hipLaunchKernelGGL(pat_assign, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, P.d_wg, words,
+                           P.d_slots, pmax, count, d_keys, d_pid, d_pat, d_plen, mode, d_state);
     if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess || h_state[1])
         return cleanup();
+    if (raw) {
+        // the values in the order the lanes consume them: widths -> host scan -> block starts -> fill
+        int32_t *d_sdesc = nullptr;
+        double *d_sval = nullptr;
+        std::vector<int32_t> wd((size_t)A->ntiles), sd(2 * (size_t)A->ntiles);
+        int tg = (int)(A->ntiles < 16384 ? A->ntiles : 16384);
+        bool ok = hipMalloc((void **)&d_sdesc, sizeof(int32_t) * 2 * (size_t)A->ntiles) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(sell_width, dim3(tg), dim3(MK_BLOCK), 0, st, A->nrows, A->ntiles, A->d_indptr, P.d_wg, d_sdesc);
+            ok = hipMemcpyAsync(wd.data(), d_sdesc, sizeof(int32_t) * wd.size(), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipStreamSynchronize(st) == hipSuccess;
+        }
+        int64_t blocks = 0, nnz_win = 0;
+        if (ok) {
+            for (int64_t t = 0; t < A->ntiles; ++t) {
+                sd[2 * t] = (int32_t)blocks;
+                sd[2 * t + 1] = wd[t];
+                blocks += wd[t];
+            }
+            nnz_win = A->nnz;                                 // (upper bound of the nonzeros the blocks hold)
+            ok = blocks > 0 && blocks < (int64_t)0x7fffffff && 8 * blocks * MK_ROWS_PER_TILE <= 9 * nnz_win + 8 * 2048;
+        }
+        ok = ok && hipMalloc((void **)&d_sval, sizeof(double) * (size_t)(blocks * MK_ROWS_PER_TILE + 2)) == hipSuccess;
+        if (ok) {
+            ok = hipMemcpyAsync(d_sdesc, sd.data(), sizeof(int32_t) * sd.size(), hipMemcpyHostToDevice, st) == hipSuccess;
+            hipLaunchKernelGGL(sell_fill, dim3(tg), dim3(MK_BLOCK), 0, st, A->nrows, A->ntiles, A->d_indptr, A->d_data, d_sdesc, d_sval);
+            ok = ok && hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+        }
+        if (!ok) {
+            hipFree(d_sdesc);
+            hipFree(d_sval);
+            return cleanup();
+        }
+        P.d_sdesc = d_sdesc;
+        P.d_sval = d_sval;
+        P.sell_entries = blocks * MK_ROWS_PER_TILE;
+    }
     P.d_pid = d_pid;
     P.d_pat = d_pat;
     P.d_plen = d_plen;
@@ -580,7 +661,7 @@ void pattern_plan(const mk_csr *A, MkPlan &P) {
     d_plen = nullptr;
     P.npat = count;
     P.pmax = pmax;
-    P.fmt = 4;
+    P.fmt = raw ? 5 : 4;
     if (getenv("MK_DEBUG_PLAN")) fprintf(stderr, "mikrylov: %lld rows, %d row patterns of <= %d entries\n", (long long)A->nrows, count, pmax);
     // the per-nonzero streams are not read any more (tiles without windows gather from the CSR arrays)
     hipFree(P.d_pk);
@@ -664,6 +745,7 @@ int plan_build(const mk_csr *A) {
         hipFree(d_table);
         hipFree(P.d_dict);
         P.d_dict = nullptr;
+        if (want >= 5) pattern_plan(A, P, true);             // ... in pattern order when the rows follow patterns (fmt 5)
         return MK_OK;
     }
     // (the kernel copies whole 1 KiB pieces of the word stream: room for one piece behind the last nonzero)
@@ -678,7 +760,7 @@ int plan_build(const mk_csr *A) {
     d_table = nullptr;
     P.ndict = h_state[0];
     P.fmt = 2;
-    if (want >= 4) pattern_plan(A, P);
+    if (want >= 4) pattern_plan(A, P, false);
     return MK_OK;
 }
 
@@ -696,7 +778,7 @@ void mk_csr_plan_reset(const mk_csr *A) {
 
 extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {
     MK_REQUIRE_INIT();
-    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 4);
+    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 5);
     if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_format: set the format on the matrix a composed operator was built from");
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
@@ -710,7 +792,7 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
     if (fmt) *fmt = P->fmt;
-    const bool windowed = (P->fmt == 1 || P->fmt == 2 || P->fmt == 4);
+    const bool windowed = (P->fmt == 1 || P->fmt == 2 || P->fmt == 4 || P->fmt == 5);
     if (tiles_windowed) *tiles_windowed = windowed ? P->covered : 0;
     if (lds_chunks) *lds_chunks = windowed ? P->wchunks : (P->fmt == 3 ? P->rt_k : 0);
     if (dict_size) *dict_size = P->ndict;
@@ -723,9 +805,12 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
             // nonzeros of windowed tiles are not kept; the mixed case is bounded by the covered share
             const double share = A->ntiles ? (double)P->covered / (double)A->ntiles : 0.0;
             // (fmt 4: one byte per ROW and no row pointers for the windowed tiles)
-            const double per = (P->fmt == 4) ? 0.0 : ((P->fmt == 2) ? 4.0 : 10.0);
+            // (fmt 5: the same byte per row, the padded values of the windowed tiles and 8 bytes per tile for their blocks)
+            const double per = (P->fmt == 4 || P->fmt == 5) ? 0.0 : ((P->fmt == 2) ? 4.0 : 10.0);
             b += (int64_t)(A->nnz * (share * per + (1.0 - share) * 12.0)) + 80 * A->ntiles;
-            if (P->fmt == 4) b += (int64_t)(share * (double)A->nrows) - (int64_t)(share * 4.0 * (double)(A->nrows + 1));
+            if (P->fmt == 4 || P->fmt == 5)
+                b += (int64_t)(share * (double)A->nrows) - (int64_t)(share * 4.0 * (double)(A->nrows + 1));
+            if (P->fmt == 5) b += 8 * P->sell_entries + 8 * A->ntiles;
         }
         *matrix_bytes_per_product = b;
     }

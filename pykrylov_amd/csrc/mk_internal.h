@@ -97,6 +97,7 @@ struct MkPlan {
     int fmt = 0;                   // 0 plain CSR, 1 windows + uint16 slots, 2 windows + slots + value dictionary,
                                    // 3 plain CSR, tile resident in LDS, gathers ordered by column block,
                                    // 4 windows + dictionary + row patterns (one byte per row)
+                                   // 5 windows + row patterns + raw values in tile-sliced ELL order
     int wchunks = 0;               // max chunks of a tile
     int ndict = 0;
     int64_t covered = 0;           // tiles on the windowed path
@@ -110,6 +111,10 @@ struct MkPlan {
     uint32_t *d_pat = nullptr;
     uint8_t *d_plen = nullptr;
     int npat = 0, pmax = 0;
+    // fmt 5 (row patterns + streamed values): the values in tile-sliced ELL order, per tile {block start / 256, width}
+    double *d_sval = nullptr;
+    int32_t *d_sdesc = nullptr;
+    int64_t sell_entries = 0;      // doubles in d_sval (256 * sum of the tile widths)
     // fmt 3 (resident tiles, column phases): plain CSR arrays, only launch parameters
     int rt_cap = 0;                // LDS capacity per tile in nonzeros (max tile stream length rounded up to 256)
     int rt_k = 1;                  // column phases

@@ -156,6 +156,9 @@ int mk_solver::iterate(int64_t max_iters, int64_t *done) {
         if (todo > batch) todo = batch;
         for (int64_t k = 0; k < todo; ++k) {
             int rc = enqueue_pass();
+            // a host operator / preconditioner callback failed inside this pass: stop enqueueing at once -- the
+            // caller's operator must not be called again on vectors that no longer mean anything
+            if (rc == MK_OK && mk_ctx().pending_rc != MK_OK) rc = mk_ctx().pending_rc;
             if (rc != MK_OK) {
                 mk_ctx().pending_rc = MK_OK;                 // (reported here: must not resurface in a later call)
                 return rc;

@@ -270,9 +270,10 @@ def partition_row_blocks(world, indptr, indices, data, shape):
     return op, ranges
 
 
-def partition_poisson3d(world, nx, ny, nz, mode="halo"):
+def partition_poisson3d(world, nx, ny, nz, mode="halo", varcoef_seed=None):
     """7-point Poisson matrix on an nx x ny x nz grid, slab-partitioned in z, generated per rank in
-    HBM (BASELINE config 5: 512^3 never exists on the host)."""
+    HBM (BASELINE config 5: 512^3 never exists on the host).  `varcoef_seed`: the variable-coefficient
+    operator of gallery.poisson3d_varcoef instead (same sparsity, same partition)."""
     from .linop import CsrOperator
     lib = _lib.init()
     n = nx * ny * nz
@@ -282,7 +283,10 @@ def partition_poisson3d(world, nx, ny, nz, mode="halo"):
         ranges = row_ranges(n, world.nranks, align=nx * ny)
     c0, c1 = ranges[world.rank]
     h = ctypes.c_void_p()
-    _lib.check(lib.mk_csr_poisson3d(nx, ny, nz, c0, c1, ctypes.byref(h)))
+    if varcoef_seed is None:
+        _lib.check(lib.mk_csr_poisson3d(nx, ny, nz, c0, c1, ctypes.byref(h)))
+    else:
+        _lib.check(lib.mk_csr_poisson3d_varcoef(nx, ny, nz, int(varcoef_seed), c0, c1, ctypes.byref(h)))
     lo, hi = ctypes.c_int64(), ctypes.c_int64()
     n_local = c1 - c0
     if mode == "allgather":

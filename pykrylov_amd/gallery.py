@@ -122,6 +122,17 @@ def poisson3d(nx, ny=None, nz=None, on_device=True):
     return CsrOperator.from_handle(h.value, symmetric=True)
 
 
+def poisson3d_varcoef(nx, ny=None, nz=None, seed=7):
+    """-div(k grad u) on the 7-point grid with a hashed positive cell field k (harmonic-mean face coefficients,
+    Dirichlet): the sparsity of `poisson3d`, practically all values distinct.  Generated in HBM."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    lib = _lib.init()
+    h = ctypes.c_void_p()
+    _lib.check(lib.mk_csr_poisson3d_varcoef(nx, ny, nz, seed, 0, nx * ny * nz, ctypes.byref(h)))
+    return CsrOperator.from_handle(h.value, symmetric=True)
+
+
 def random_diagdom(n, seed=1, k=4):
     indptr, indices, data, shape = random_diagdom_csr(n, seed, k)
     return CsrOperator(indptr, indices, data, shape)

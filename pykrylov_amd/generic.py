@@ -161,7 +161,8 @@ class DeviceRun(object):
                     hp.calls += 1
                     return 0
                 except BaseException as exc:                # noqa: B902  (must not propagate through the C frames)
-                    hp.error = exc
+                    if hp.error is None:                    # (keep the root cause, not a follow-up failure)
+                        hp.error = exc
                     return 1
             self._precon_cb = _lib.PRECON_FN(call)          # keep the thunk alive
             _lib.check(self.lib.mk_solver_set_precon_callback(self.handle, self._precon_cb, None))

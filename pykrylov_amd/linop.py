@@ -735,6 +735,9 @@ class HostOperatorShell(object):
     def __init__(self, op):
         self.host_op = op
         self.error = None
+        dt = getattr(op, 'dtype', None)
+        if dt is not None and _is_complex(np.dtype(dt)):     # (found here, not at the first callback)
+            raise TypeError('complex operators are not supported on the device path (fp64 only)')
         nargout, nargin = op.shape
         self.shape = (int(nargout), int(nargin))
         self.symmetric = bool(getattr(op, 'symmetric', False))
@@ -755,7 +758,8 @@ class HostOperatorShell(object):
                 np.ctypeslib.as_array(ctypes.cast(yp, ctypes.POINTER(ctypes.c_double)), shape=(nrows,))[:] = y
                 return 0
             except BaseException as exc:                    # noqa: B902  (must not propagate through the C frames)
-                self.error = exc
+                if self.error is None:                      # (keep the root cause, not a follow-up failure)
+                    self.error = exc
                 return 1
         self._cb = _lib.MATVEC_FN(call)                     # keep the thunk alive
         h = ctypes.c_void_p()
@@ -770,7 +774,11 @@ class HostOperatorShell(object):
         if self.symmetric:
             return self
         if self._T is None:
-            self._T = HostOperatorShell(self.host_op.T)
+            t = getattr(self.host_op, 'T', None)
+            if t is None:                                    # (LinearOperator built without matvec_transp: linop.py:148-171)
+                raise ValueError('the operator has no transpose (build it with matvec_transp=...): the least-squares '
+                                 'solvers need A.T * u')
+            self._T = HostOperatorShell(t)
             self._T._T = self
         return self._T
 
