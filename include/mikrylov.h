@@ -165,6 +165,14 @@ int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_windowed, i
  * Measured slower than the single launch on 5-nonzero rows: an option, not the default.
  * mk_csr_colblocks reports K (0: not blocked). */
 int mk_csr_set_colblocks(mk_csr *A, int32_t block_kb);
+/* Tile order of the SpMV launches (speed only; it also fixes which rows a workgroup's partial sums of a fused dot
+ * cover): 0 round robin, 1 each XCD sweeps its own contiguous eighth, 2 every step of the grid is cut into eight
+ * XCD-contiguous blocks, 3 stripes of `stripe` tiles dealt round-robin to the XCDs, 4 as 3 but an XCD walks its strip
+ * through all planes (`plane` tiles apart) before it takes its next strip; -1 = library default.  `nontemporal`: load
+ * matrix data that is read once per product past the L2 (1 / 0 / -1 = default).  mk_csr_tile_order reports what a
+ * launch would use now. */
+int mk_csr_set_tile_order(mk_csr *A, int32_t order, int32_t stripe, int32_t plane, int32_t nontemporal);
+int mk_csr_tile_order(const mk_csr *A, int32_t *order, int32_t *stripe, int32_t *plane, int32_t *nontemporal);
 int mk_csr_colblocks(const mk_csr *A, int32_t *nblocks);
 /* Launch geometry of A's product kernels (what fixes the summation order of the dots fused into them): the grid,
  * and the tile order (0 round robin; 1 each XCD sweeps a contiguous eighth; 2 XCD-contiguous blocks per step). */

@@ -90,7 +90,9 @@ def spmv_tile_order(ntiles, grid=None, tile_map=1):
     """For every workgroup the list of tiles it processes, in order (csrc/mk_device.h `mk_spmv_tiles`).
     tile_map 0: round robin.  1: XCD b % 8 owns a contiguous eighth of the tiles, dealt round-robin to its
     workgroups (cache-resident matrices).  2: every step of the grid is cut into eight XCD-contiguous blocks.
-    Maps 1 and 2 fall back to 0 when the grid is not a multiple of 8."""
+    (3, S, _): stripes of S consecutive tiles dealt round-robin to the XCDs, each XCD's tiles dealt to its workgroups.
+    (4, S, P): as 3, but an XCD walks its strip through all ntiles / P planes (P tiles apart) before its next strip.
+    Maps 1 to 4 fall back to 0 when the grid is not a multiple of 8."""
     if grid is None:
         grid = grid_spmv(ntiles)
     x8 = grid % 8 == 0
@@ -103,6 +105,17 @@ def spmv_tile_order(ntiles, grid=None, tile_map=1):
             order.append(range(c0 + b // 8, min(c0 + chunk, ntiles), per))
         elif tile_map == 2 and x8:
             order.append(range((b % 8) * (grid // 8) + b // 8, ntiles, grid))
+        elif isinstance(tile_map, tuple) and tile_map[0] == 3 and x8:   # stripes of S tiles dealt round-robin to the XCDs
+            S, e = tile_map[1], b % 8
+            nst = (ntiles + S - 1) // S
+            cnt = (nst - e + 7) // 8 if nst > e else 0
+            end = cnt * S - ((nst * S - ntiles) if (cnt > 0 and (nst - 1) % 8 == e) else 0)
+            order.append([((p // S) * 8 + e) * S + p % S for p in range(b // 8, end, grid // 8)])
+        elif isinstance(tile_map, tuple) and tile_map[0] == 4 and x8:   # ... an XCD walks a strip through all planes first
+            S, P, e = tile_map[1], tile_map[2], b % 8
+            NP = ntiles // P
+            order.append([((p // S) % NP) * P + (((p // S) // NP) * 8 + e) * S + p % S
+                          for p in range(b // 8, ntiles // 8, grid // 8)])
         else:
             order.append(range(b, ntiles, grid))
     return order
@@ -132,6 +145,10 @@ def launch_geometry(op):
     from pykrylov_amd import _lib
     g, m = ctypes.c_int32(), ctypes.c_int32()
     _lib.check(_lib.init().mk_csr_launch_info(op.handle, ctypes.byref(g), ctypes.byref(m)))
+    if m.value in (3, 4):                                     # (these orders have parameters)
+        o, s, p = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(_lib.init().mk_csr_tile_order(op.handle, ctypes.byref(o), ctypes.byref(s), ctypes.byref(p), None))
+        return g.value, (o.value, s.value, p.value)
     return g.value, m.value
 
 

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmikrylov.so")
+# (MIKRYLOV_LIB: an experiment build of the same library, `python -m pykrylov_amd.build --tag X -DY`)
+LIB_PATH = os.environ.get("MIKRYLOV_LIB") or os.path.join(_HERE, "libmikrylov.so")
 
 c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
@@ -87,6 +88,8 @@ PROTOTYPES = {
     "mk_csr_format_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i64), P(c_i32), P(c_i32), P(c_i64)]),
     "mk_csr_launch_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
     "mk_csr_colblocks": (ctypes.c_int, [c_vp, P(c_i32)]),
+    "mk_csr_set_tile_order": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32]),
+    "mk_csr_tile_order": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
     "mk_csr_set_colblocks": (ctypes.c_int, [c_vp, c_i32]),
     "mk_spmv": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mk_dot": (ctypes.c_int, [c_i64, c_vp, c_vp, P(c_f64)]),

@@ -29,7 +29,14 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, tag=None, defines=()):
+    """`tag` / `defines`: an experiment build beside the product -- libmikrylov_<tag>.so compiled with -D<define> ...,
+    loaded instead of the product when MIKRYLOV_LIB points at it (tools/variants.sh)."""
+    global OUT, OBJDIR
+    if tag:
+        OUT = os.path.join(HERE, "libmikrylov_%s.so" % tag)
+        OBJDIR = os.path.join(HERE, "build_" + tag)
+        FLAGS[:0] = ["-D" + d for d in defines]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "mikrylov.h")]
@@ -66,4 +73,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    _tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else None
+    _defs = [a[2:] for a in sys.argv if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, tag=_tag, defines=_defs))

@@ -26,7 +26,17 @@ struct MkCsrView {
     int64_t nrows;
     int64_t ntiles;
     int map;                 // tile order: 0 round robin; 1 each XCD sweeps its own contiguous eighth of the tiles
-                             // (cache-resident problems); 2 every step of the grid is split into eight XCD-contiguous blocks
+                             // (cache-resident problems); 2 every step of the grid is split into eight XCD-contiguous blocks;
+                             // 3 stripes of `stripe` consecutive tiles dealt round-robin to the XCDs (banded matrices:
+                             // an XCD marches through ITS stripe of every plane, so the x windows of the far
+                             // off-diagonals -- one plane back, one plane ahead -- are still in its own L2)
+                             // 4 as 3, but an XCD finishes a narrow strip of every plane -- all `nplanes` planes, `plane`
+                             // tiles apart -- before it moves to its next strip: the reuse distance of a window (one and
+                             // two planes) shrinks from plane/8 tiles to `stripe` tiles and fits the L2 beside the
+                             // streamed matrix data
+    int stripe;              // maps 3, 4: tiles per stripe (map 3: a power of two)
+    int plane, nplanes;      // map 4: tiles per plane (the far off-diagonals' distance), planes (ntl = plane * nplanes)
+    int nt;                  // fmt 5: the value stream is loaded non-temporally (read once: must not push x out of the L2)
     int nops;                // row program of a composed operator (mk_csr_compose); 0 for a plain matrix
     mk_rowop ops[MK_ROWPROG_MAX];
     // a launch may cover a subset of the tiles (overlap of the halo exchange, mk_comm.hip): `tiles` lists them
@@ -78,11 +88,41 @@ static inline int mk_xcd_chunks(const mk_csr *A) {
     return bytes <= (int64_t)200 * 1024 * 1024 ? 1 : 0;
 }
 const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
+// stripe length (tiles, a power of two) of tile order 3; 0 = the matrix does not use it
+static inline const mk_csr *mk_owner(const mk_csr *A) { return A->base ? A->base : A; }
+static inline int mk_tile_stripe(const mk_csr *A) {
+    static const char *env = getenv("MK_SPMV_STRIPE");
+    int s = mk_owner(A)->want_stripe > 0 ? mk_owner(A)->want_stripe : (env ? atoi(env) : 0);
+    if (s <= 0) s = 32;
+    int p2 = 1;
+    while (2 * p2 <= s) p2 *= 2;
+    return p2;
+}
+// plane period (tiles) of tile order 4
+static inline int mk_tile_plane(const mk_csr *A) {
+    static const char *env = getenv("MK_SPMV_PLANE");
+    if (mk_owner(A)->want_plane > 0) return mk_owner(A)->want_plane;
+    return env ? atoi(env) : 0;
+}
+// order 4 needs whole planes and whole strips per XCD
+static inline bool mk_tile_map4_ok(const mk_csr *A) {
+    const int P = mk_tile_plane(A), S = mk_tile_stripe(A);
+    return P > 0 && S > 0 && A->ntiles % P == 0 && P % (8 * S) == 0;
+}
+static inline int mk_stream_nt(const mk_csr *A) {
+    static const char *env = getenv("MK_SPMV_NT");
+    if (mk_owner(A)->want_nt >= 0) return mk_owner(A)->want_nt;
+    return env ? atoi(env) : 0;
+}
 static inline int mk_tile_map(const mk_csr *A) {
     if (A->comp_kind) return mk_tile_map(A->comp_kind == 3 ? A->comp_a : A->comp_b);
     if (A->host_fn) return 0;
     static const char *env = getenv("MK_SPMV_MAP");
-    if (env) return atoi(env);
+    if (mk_owner(A)->want_map >= 0 || env) {
+        int m = mk_owner(A)->want_map >= 0 ? mk_owner(A)->want_map : atoi(env);
+        if (m == 4 && !mk_tile_map4_ok(A)) m = 2;
+        return m;
+    }
     if (mk_xcd_chunks(A)) return 1;
     // beyond the Infinity Cache: one front (0) -- except for the pattern kernel, which moves so little per tile that it
     // runs into the fabric on re-fetched x windows: XCD-contiguous blocks within every step of the grid keep neighbouring
@@ -153,6 +193,13 @@ static inline MkCsrView mk_view(const mk_csr *A) {
     v.nrows = A->nrows;
     v.ntiles = A->ntiles;
     v.map = mk_tile_map(A);
+    v.stripe = (v.map == 3) ? mk_tile_stripe(A) : 0;
+    if (v.map == 4) {
+        v.stripe = mk_tile_stripe(A);
+        v.plane = mk_tile_plane(A);
+        v.nplanes = (int)(A->ntiles / v.plane);
+    }
+    v.nt = mk_stream_nt(A);
     v.nops = A->nops;
     for (int k = 0; k < A->nops; ++k) v.ops[k] = A->ops[k];
     v.tiles = nullptr;
@@ -295,7 +342,14 @@ __device__ __forceinline__ T mk_sload(const T *p) {
 }
 
 __device__ __forceinline__ int64_t mk_tile_at(const MkCsrView &A, int64_t p) {
-    const int t = A.tiles ? mk_sload(A.tiles + p) : (int)p;
+    int t = A.tiles ? mk_sload(A.tiles + p) : (int)p;
+    if (A.map == 3 && !A.tiles && gridDim.x % 8 == 0) {      // p counts the tiles of this XCD's stripes
+        const int S = A.stripe, e = (int)(blockIdx.x % 8);
+        t = (((int)p / S) * 8 + e) * S + ((int)p & (S - 1));
+    } else if (A.map == 4 && !A.tiles && gridDim.x % 8 == 0) {   // p = ((strip * nplanes) + plane) * S + position in the strip
+        const unsigned S = A.stripe, e = blockIdx.x % 8, q = (unsigned)p / S;
+        t = (int)((q % (unsigned)A.nplanes) * (unsigned)A.plane + ((q / (unsigned)A.nplanes) * 8 + e) * S + (unsigned)p % S);
+    }
     return (int64_t)__builtin_amdgcn_readfirstlane(t);
 }
 
@@ -394,6 +448,17 @@ __device__ __forceinline__ MkTileRange mk_tile_range(const MkCsrView &A) {
         t.pos = (int64_t)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
         t.stride = G;
         t.end = A.ntl;
+    } else if (A.map == 3 && x8 && !A.tiles) {               // XCD b % 8 takes stripes b % 8, b % 8 + 8, ... of S tiles
+        const int64_t S = A.stripe, e = blockIdx.x % 8;
+        const int64_t nst = (A.ntl + S - 1) / S;             // stripes in all; the last one may be short
+        const int64_t cnt = (nst > e) ? (nst - e + 7) / 8 : 0;
+        t.pos = blockIdx.x / 8;
+        t.stride = G / 8;
+        t.end = cnt * S - ((cnt > 0 && (nst - 1) % 8 == e) ? nst * S - A.ntl : 0);
+    } else if (A.map == 4 && x8 && !A.tiles) {               // (the host guarantees ntl = plane * nplanes, plane % (8 S) == 0)
+        t.pos = blockIdx.x / 8;
+        t.stride = G / 8;
+        t.end = A.ntl / 8;
     } else {
         t.pos = blockIdx.x;
         t.stride = G;
@@ -429,7 +494,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     if constexpr (FMT == 0) mk_spmv_tiles_fmt0<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 1) mk_spmv_tiles_fmt1<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 3) mk_spmv_tiles_fmt3<PROG>(A, x, epi, prod, xw, acc);
-    else if constexpr (FMT == 5) mk_spmv_tiles_fmt5<PROG>(A, x, epi, prod, xw, acc);
+    else if constexpr (FMT >= 5) mk_spmv_tiles_fmt5<PROG, FMT == 6>(A, x, epi, prod, xw, acc);
     else mk_spmv_tiles_fmt24<FMT, PROG>(A, x, epi, prod, xw, acc);
 }
 
@@ -441,13 +506,13 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : ((FMT == 4 || FMT == 5) ? 7 : 4)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : ((FMT >= 4) ? 7 : 4)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
     extern __shared__ __attribute__((aligned(16))) double mk_smem[];
     double *prod = mk_smem;
-    double *xw = (FMT == 2 || FMT == 4 || FMT == 5) ? mk_smem : mk_smem + MK_PROD_LDS;
+    double *xw = (FMT == 2 || FMT >= 4) ? mk_smem : mk_smem + MK_PROD_LDS;
     __shared__ double s4[4];
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -514,8 +579,12 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         size_t wtop = (size_t)(128 * v.wchunks + 2);
         if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
         lds = sizeof(double) * (wtop + MK_BLOCK) + 4 * (size_t)(v.npat * v.pmax + 4);
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 5>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
-                           halt, partials);
+        if (v.nt)                                       // (template value 6 = format 5 with non-temporal value loads)
+            hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 6>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                               halt, partials);
+        else
+            hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 5>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                               halt, partials);
     } else if (v.fmt == 3) {                                 // the tile's values and columns
         lds = (size_t)v.rt_cap * 12;
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 3>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,

@@ -820,7 +820,27 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
 extern "C" int mk_csr_launch_info(const mk_csr *A, int32_t *grid, int32_t *tile_map) {
     MK_ARG(A != nullptr);
     if (grid) *grid = mk_grid_spmv_for(A);
-    if (tile_map) *tile_map = mk_tile_map(A);
+    if (tile_map) *tile_map = mk_tile_map(A);                // (orders 3, 4: parameters through mk_csr_tile_order)
+    return MK_OK;
+}
+
+extern "C" int mk_csr_set_tile_order(mk_csr *A, int32_t order, int32_t stripe, int32_t plane, int32_t nontemporal) {
+    MK_ARG(A != nullptr && order >= -1 && order <= 4 && stripe >= 0 && plane >= 0 && nontemporal >= -1 && nontemporal <= 1);
+    if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_tile_order: set it on the matrix a composed operator was built from");
+    A->want_map = order;
+    A->want_stripe = stripe;
+    A->want_plane = plane;
+    A->want_nt = nontemporal;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_tile_order(const mk_csr *A, int32_t *order, int32_t *stripe, int32_t *plane, int32_t *nontemporal) {
+    MK_ARG(A != nullptr);
+    const int m = mk_tile_map(A);
+    if (order) *order = m;
+    if (stripe) *stripe = (m == 3 || m == 4) ? mk_tile_stripe(A) : 0;
+    if (plane) *plane = (m == 4) ? mk_tile_plane(A) : 0;
+    if (nontemporal) *nontemporal = mk_stream_nt(A);
     return MK_OK;
 }
 

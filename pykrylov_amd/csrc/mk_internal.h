@@ -137,6 +137,8 @@ struct mk_csr {
     mutable MkPlan plan;
     int want_fmt = -1;             // mk_csr_set_format: -1 = library default (MK_SPMV_FORMAT or 2)
     int want_cb_kb = -1;           // mk_csr_set_colblocks: -1 = library default (MK_COLBLOCK_KB or off)
+    int want_map = -1, want_stripe = 0, want_plane = 0;   // mk_csr_set_tile_order: -1 = library default
+    int want_nt = -1;              // mk_csr_set_tile_order: non-temporal loads of the streamed matrix data (-1 = default)
     // sum / difference / product of two device matrices (mk_csr_create_sum / _product): no arrays of its own
     int comp_kind = 0;             // 0 none, 1 A + B, 2 A - B, 3 A * B
     const mk_csr *comp_a = nullptr, *comp_b = nullptr;

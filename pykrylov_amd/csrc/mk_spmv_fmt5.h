@@ -12,7 +12,7 @@
 // 256 pattern bytes and 256 * w_T values straight into registers -- no column indices, no row pointers, no slots, no
 // product staging: 8 B per nonzero + 1 B per row instead of CSR's 12 B per nonzero + 4 B per row.  The row phase is
 // fmt 4's: lane t walks row t LEFT TO RIGHT (same products, same order, same bits as every other format).
-template <bool PROG, class Epi, int NACC>
+template <bool PROG, bool NT, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles_fmt5(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
         double *prod, double *xw, double (&acc)[NACC]) {
     const int tid = threadIdx.x;
@@ -52,9 +52,32 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt5(const MkCsrView &A, const dou
             d.sd = mk_sload(reinterpret_cast<const mk_i2 *>(A.sdesc + 2 * t));
         }
     };
+    // a row's values: registers, (w >> 1) 16-byte loads + one 8-byte load for an odd width (w is tile uniform: scalar
+    // branches).  NT: non-temporal loads -- the values are read once per product and should not push the x windows out
+    // of the L2 (with tile order 4 the fabric reads of a 512^3 product fall from 10.4 to 9.3 GB, 1.06 x the format's
+    // bytes; the kernel is not faster for it, profiles/r03_*).  Prefetching the next tile's values into a second set of
+    // registers while the rows are walked was tried too (87 registers, 5 workgroups per CU): +1 %, not kept.
+    auto load_vals = [&](const mk_i2 sd, double (&v)[8]) {
+        const int w = sd.y;
+        const double *vb = A.sval + (int64_t)sd.x * MK_ROWS_PER_TILE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[2 * q] = 0.0;
+            v[2 * q + 1] = 0.0;
+            if (2 * q + 1 < w) {
+                const mk_d2 pr = NT ? __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(vb + q * 512 + 2 * tid))
+                                    : *reinterpret_cast<const mk_d2 *>(vb + q * 512 + 2 * tid);
+                v[2 * q] = pr.x;
+                v[2 * q + 1] = pr.y;
+            } else if (2 * q < w) {
+                v[2 * q] = NT ? __builtin_nontemporal_load(vb + 2 * q * 256 + tid) : vb[2 * q * 256 + tid];
+            }
+        }
+    };
     MkTileMeta cur;
     Desc dcur, dnxt;
     load_desc(pos, dcur);
+
     for (; pos < end; pos += stride) {
         const int64_t tile = mk_tile_at(A, pos);
         const int64_t r0 = tile * MK_ROWS_PER_TILE;
@@ -81,26 +104,13 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt5(const MkCsrView &A, const dou
                 }
             }
             const unsigned id = (r < rend) ? (unsigned)A.pid[r] : 0u;       // one byte per row
-            // the row's values: registers, (w >> 1) 16-byte loads + one 8-byte load for an odd width (w is tile
-            // uniform: scalar branches)
             const int w = dcur.sd.y;
-            const double *vb = A.sval + (int64_t)dcur.sd.x * MK_ROWS_PER_TILE;
             double v[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[2 * q] = 0.0;
-                v[2 * q + 1] = 0.0;
-                if (2 * q + 1 < w) {
-                    const mk_d2 pr = *reinterpret_cast<const mk_d2 *>(vb + q * 512 + 2 * tid);
-                    v[2 * q] = pr.x;
-                    v[2 * q + 1] = pr.y;
-                } else if (2 * q < w) {
-                    v[2 * q] = vb[2 * q * 256 + tid];
-                }
-            }
+            load_vals(dcur.sd, v);
             load_desc(pos + stride, dnxt);                   // next tile's descriptors go in flight
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+
             const int lo = (int)id * A.pmax;
             const int len = (r < rend) ? (splen[id] & 0xff) : 0;
             const int kdiag = splen[id] >> 8;
