@@ -350,6 +350,8 @@ def main():
                          "of the N > 1 path on a single-GPU box, not a measurement")
     ap.add_argument("--all-configs", action="store_true", help="(kept for compatibility: all BASELINE configs are in the "
                                                                "default line now)")
+    ap.add_argument("--only-other-configs", action="store_true",
+                    help="profiling aid: run only configs[2] and configs[3] (BiCGSTAB random, MINRES shifted) and print them")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -406,6 +408,9 @@ def main():
             if rank == 0:
                 sys.stderr.write("bench.py: " + transport_note + "\n")
 
+    if args.only_other_configs:
+        json_out.write(json.dumps(other_configs(lib)) + "\n")
+        return
     name = args.workload
     if name == "auto":
         name = "poisson3d-512-varcoef"
