@@ -168,6 +168,23 @@ class GpuDots(object):
         return stream_dot(a, b)
 
 
+class ExactDots(object):
+    """`dot_impl` for krylov_ref.Reductions with ORDER-INDEPENDENT inner products: products and sums are formed in
+    extended precision (x87 long double, 64-bit significand; NumPy's pairwise summation) and rounded to double once.
+    The result is within 1e-18 (relative, for sums of like-signed terms; ~1e-18 x condition otherwise) of the exactly
+    rounded inner product -- four orders of magnitude below the 1e-12 parity bar -- so a history computed with it is
+    the anchor both the device's tree order and np.dot's BLAS order can be measured against."""
+
+    def __init__(self):
+        assert np.finfo(np.longdouble).nmant >= 63, "needs x87 extended precision"
+
+    def __call__(self, a, b, site):
+        a = np.asarray(a, dtype=np.float64).astype(np.longdouble)
+        if b is a:
+            return float(np.sum(a * a))
+        return float(np.sum(a * np.asarray(b, dtype=np.float64).astype(np.longdouble)))
+
+
 SPMV_SITES = {
     "cg": ["cg.pAp"],
     "bicgstab": ["bicgstab.r0v", "bicgstab.ts", "bicgstab.tt", "bicgstab.r0t"],
