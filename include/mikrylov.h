@@ -121,11 +121,20 @@ int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops, mk_csr **
  * -- two complete products and one element-wise operation -- and so does the device: the first product's row sums go
  * to a temporary, the second product's kernel combines them with its own row sums (or multiplies the temporary)
  * and feeds the result to the fused epilogue of whatever solver kernel asked for the product.  Same bits as the
- * reference's closures.  A and B are borrowed (they must outlive the result); they may carry a row program
+ * reference's closures.  A and B are borrowed (destroying one while the result is alive is deferred until the result is destroyed); they may carry a row program
  * (mk_csr_compose) but must not be composites, matrix-free or partitioned.  sign = +1 / -1. */
 int mk_csr_create_sum(const mk_csr *A, const mk_csr *B, int sign, mk_csr **out);
 int mk_csr_create_product(const mk_csr *A, const mk_csr *B, mk_csr **out);
 
+/* A grid of device matrices as ONE operator (reference linop/blkop.py:8-152 BlockLinearOperator, :154-257
+ * BlockDiagonalLinearOperator): `blocks` lists nbr x nbc handles row by row (NULL = zero block), block (i, j) being
+ * heights[i] x widths[j].  A product evaluates every block product completely and adds the results to the block row's
+ * accumulator one block at a time, starting from +0.0 -- the reference's `y_i += B_ij * x_j` (blkop.py:86-96) -- so
+ * results carry the same roundings, and the operator is accepted wherever a device matrix is (solver product sites
+ * with their fused epilogues included).  The blocks are borrowed: destroying one while the block operator is alive is
+ * deferred until the block operator is destroyed.  Device matrices with or without a row program; not composites. */
+int mk_csr_create_block(int32_t nbr, int32_t nbc, const mk_csr *const *blocks, const int64_t *heights,
+                        const int64_t *widths, mk_csr **out);
 /* Matrix-free operator: the products of the returned handle are computed by a HOST callback -- the reference's own
  * operator protocol, `LinearOperator(nargin, nargout, matvec=callable)` (linop/linop.py:114,271-298), e.g. the gallery
  * operators its CG test runs on (cg/tests/test_diagdom.py:38-40).  Everything else of a solver loop (dots, updates,

@@ -89,6 +89,25 @@ class BlockLinearOperator(LinearOperator):
                 out[:] += blk * x[c[j]:c[j + 1]]              # (blkop.py:94: in this order, one block at a time)
         return y
 
+    def _device_view(self):
+        """The block operator as ONE device operator (linop._BlockCsrOperator) when every block is a device matrix or
+        a plain diagonal / identity operator; None otherwise (the device solvers then call the host composition back).
+        Rebuilt when blocks were replaced."""
+        from .linop import _BlockCsrOperator, device_block
+        grid = self._blocks
+        key = tuple(id(b) for row in grid for b in row)
+        cached = self.__dict__.get('_dev_view')
+        if cached is not None and cached[0] == key and cached[1].handle:
+            return cached[1]
+        dev = [[device_block(b) for b in row] for row in grid]
+        if any(d is None for row in dev for d in row):
+            return None
+        heights, widths = _grid_sizes(grid)
+        view = _BlockCsrOperator.build(self, dev, heights, widths)
+        if view is not None:
+            self.__dict__['_dev_view'] = (key, view)
+        return view
+
     @property
     def blocks(self):
         "The list of lists of blocks."
@@ -174,6 +193,23 @@ class BlockDiagonalLinearOperator(LinearOperator):
         for k, blk in enumerate(blks):
             y[r[k]:r[k + 1]] = blk * x[c[k]:c[k + 1]]
         return y
+
+    def _device_view(self):
+        "As `BlockLinearOperator._device_view`: diag(A, B, ...) of device matrices as one device operator, or None."
+        from .linop import _BlockCsrOperator, device_block
+        blks = self._blocks
+        key = tuple(id(b) for b in blks)
+        cached = self.__dict__.get('_dev_view')
+        if cached is not None and cached[0] == key and cached[1].handle:
+            return cached[1]
+        dev = [device_block(b) for b in blks]
+        if any(d is None for d in dev):
+            return None
+        grid = [[dev[i] if i == j else None for j in range(len(dev))] for i in range(len(dev))]
+        view = _BlockCsrOperator.build(self, grid, [b.shape[0] for b in blks], [b.shape[1] for b in blks])
+        if view is not None:
+            self.__dict__['_dev_view'] = (key, view)
+        return view
 
     @property
     def blocks(self):

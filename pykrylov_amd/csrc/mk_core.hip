@@ -216,6 +216,9 @@ extern "C" int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops
     B->alias = true;
     B->base = A->base ? A->base : A;
     B->plan = MkPlan();
+    B->dependents = 0;
+    B->doomed = false;
+    B->base->dependents += 1;
     for (int k = 0; k < nops; ++k) B->ops[B->nops++] = ops[k];
     *out = B;
     return MK_OK;
@@ -225,8 +228,9 @@ static int pair_create(const mk_csr *A, const mk_csr *B, int kind, mk_csr **out)
     MK_REQUIRE_INIT();
     MK_ARG(A && B && out);
     if (!A->is_plain() || !B->is_plain())
-        return mk_fail(MK_ERR_UNSUPPORTED, "operands of a device sum / product must be plain device matrices "
-                                           "(not composites, matrix-free or partitioned operators)");
+        return mk_fail(MK_ERR_UNSUPPORTED, "operands of a device sum / product must be device matrices, with or without "
+                                           "a row program (not sums / products / block operators, matrix-free or "
+                                           "partitioned operators)");
     if (kind == 3) MK_ARG(A->ncols == B->nrows);
     else MK_ARG(A->nrows == B->nrows && A->ncols == B->ncols);
     mk_csr *C = new mk_csr();
@@ -239,11 +243,73 @@ static int pair_create(const mk_csr *A, const mk_csr *B, int kind, mk_csr **out)
     C->comp_b = B;
     C->plan.built = true;
     const int64_t tlen = (kind == 3) ? B->nrows : A->nrows;
-    if (hipMalloc((void **)&C->d_comp_tmp, sizeof(double) * (size_t)(tlen > 0 ? tlen : 1) + 16) != hipSuccess) {
+    if (hipMalloc((void **)&C->d_comp_tmp, sizeof(double) * (size_t)(tlen > 0 ? tlen : 1) + 16) != hipSuccess ||
+        hipMemsetAsync(C->d_comp_tmp, 0, sizeof(double) * (size_t)(tlen > 0 ? tlen : 1) + 16, mk_ctx().stream) != hipSuccess) {
+        hipFree(C->d_comp_tmp);
         delete C;
-        return mk_fail(MK_ERR_HIP, "device sum / product: hipMalloc failed");
+        return mk_fail(MK_ERR_HIP, "device sum / product: allocation failed");
     }
-    MK_HIP(hipMemsetAsync(C->d_comp_tmp, 0, sizeof(double) * (size_t)(tlen > 0 ? tlen : 1) + 16, mk_ctx().stream));
+    A->dependents += 1;
+    B->dependents += 1;
+    *out = C;
+    return MK_OK;
+}
+
+// Block operators on the device.  The reference evaluates a block row as  y_i = 0 ; y_i += B_i0 * x_0 ; y_i += B_i1 * x_1 ...
+// (blkop.py:86-96): every block product is a complete product of its own, and the results are added to the row's
+// accumulator one block at a time.  Same here: one launch per block, whose row epilogue adds the finished row sum to the
+// accumulator (the first block of a row adds to +0.0), then one launch that feeds the accumulated rows to the real
+// epilogue of the calling kernel site (mk_device.h).  Blocks are borrowed handles of plain device matrices.
+extern "C" int mk_csr_create_block(int32_t nbr, int32_t nbc, const mk_csr *const *blocks, const int64_t *heights,
+                                   const int64_t *widths, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(nbr >= 1 && nbc >= 1 && blocks && heights && widths && out);
+    MkBlockGrid *G = new MkBlockGrid();
+    G->nbr = nbr;
+    G->nbc = nbc;
+    G->roff.assign(nbr + 1, 0);
+    G->coff.assign(nbc + 1, 0);
+    for (int i = 0; i < nbr; ++i) G->roff[i + 1] = G->roff[i] + heights[i];
+    for (int j = 0; j < nbc; ++j) G->coff[j + 1] = G->coff[j] + widths[j];
+    int64_t nnz = 0, wmax = 1;
+    bool ok = true, plain = true;
+    for (int i = 0; i < nbr && ok; ++i)
+        for (int j = 0; j < nbc && ok; ++j) {
+            const mk_csr *B = blocks[i * nbc + j];
+            G->blk.push_back(B);
+            if (!B) continue;
+            plain = plain && B->is_plain();
+            ok = heights[i] >= 0 && widths[j] >= 0 && B->nrows == heights[i] && B->ncols == widths[j];
+            nnz += B->nnz;
+            wmax = B->ncols > wmax ? B->ncols : wmax;
+        }
+    if (!ok || !plain || G->roff[nbr] > 2147483647LL || G->coff[nbc] > 2147483647LL) {
+        delete G;
+        if (!plain)
+            return mk_fail(MK_ERR_UNSUPPORTED, "blocks of a device block operator must be device matrices, with or without "
+                                               "a row program (not composites, matrix-free or partitioned operators)");
+        return mk_fail(MK_ERR_ARG, "mk_csr_create_block: block shapes do not fit the grid");
+    }
+    mk_csr *C = new mk_csr();
+    C->nrows = G->roff[nbr];
+    C->ncols = G->coff[nbc];
+    C->nnz = nnz;
+    C->ntiles = (C->nrows + MK_ROWS_PER_TILE - 1) / MK_ROWS_PER_TILE;
+    C->comp_kind = 4;
+    C->grid = G;
+    C->plan.built = true;
+    const size_t ybytes = sizeof(double) * (size_t)(C->nrows > 0 ? C->nrows : 1) + 16;
+    if (hipMalloc((void **)&C->d_comp_tmp, ybytes) != hipSuccess ||
+        hipMalloc((void **)&G->d_xtmp, sizeof(double) * (size_t)wmax + 16) != hipSuccess ||
+        hipMemsetAsync(C->d_comp_tmp, 0, ybytes, mk_ctx().stream) != hipSuccess) {
+        hipFree(C->d_comp_tmp);
+        hipFree(G->d_xtmp);
+        delete G;
+        delete C;
+        return mk_fail(MK_ERR_HIP, "mk_csr_create_block: allocation failed");
+    }
+    for (const mk_csr *B : G->blk)
+        if (B) B->dependents += 1;
     *out = C;
     return MK_OK;
 }
@@ -303,16 +369,38 @@ int mk_host_product(const mk_csr *A, hipStream_t st) {
     return MK_OK;
 }
 
+// an operand loses one dependent; if its owner has destroyed it in the meantime, it goes now
+static void mk_release_operand(const mk_csr *B) {
+    if (!B) return;
+    B->dependents -= 1;
+    if (B->dependents <= 0 && B->doomed) mk_csr_destroy(const_cast<mk_csr *>(B));
+}
+
 extern "C" int mk_csr_destroy(mk_csr *A) {
     if (!A) return MK_OK;
+    if (A->dependents > 0) {                                 // composites still borrow its arrays: destroyed with the last
+        A->doomed = true;
+        return MK_OK;
+    }
     if (A->alias) {
+        const mk_csr *base = A->base;
         delete A;
+        mk_release_operand(base);
         return MK_OK;
     }
     if (A->comp_kind) {
         if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
         hipFree(A->d_comp_tmp);
+        const mk_csr *a = A->comp_a, *b = A->comp_b;
+        MkBlockGrid *G = A->grid;
         delete A;
+        mk_release_operand(a);
+        mk_release_operand(b);
+        if (G) {
+            hipFree(G->d_xtmp);
+            for (const mk_csr *B : G->blk) mk_release_operand(B);
+            delete G;
+        }
         return MK_OK;
     }
     if (A->host_fn) {

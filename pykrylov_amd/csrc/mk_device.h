@@ -115,6 +115,7 @@ static inline int mk_stream_nt(const mk_csr *A) {
     return env ? atoi(env) : 0;
 }
 static inline int mk_tile_map(const mk_csr *A) {
+    if (A->comp_kind == 4) return 0;
     if (A->comp_kind) return mk_tile_map(A->comp_kind == 3 ? A->comp_a : A->comp_b);
     if (A->host_fn) return 0;
     static const char *env = getenv("MK_SPMV_MAP");
@@ -143,6 +144,7 @@ int mk_host_product(const mk_csr *A, hipStream_t st);   // mk_core.hip: D2H, hos
 // kernel (fmt 4) ingests so little per tile that it is bound by the latency of its window copies: 7 per CU
 // (512^3: 1024 / 1536 / 1792 workgroups -> 1.26 / 1.01 / 0.91 ms).
 static inline int mk_grid_spmv_for(const mk_csr *A) {
+    if (A->comp_kind == 4) return mk_grid_spmv(A->ntiles);   // (the final launch walks the accumulated rows)
     if (A->comp_kind) return mk_grid_spmv_for(A->comp_kind == 3 ? A->comp_a : A->comp_b);   // the final launch's matrix
     int g = mk_grid_spmv(A->ntiles);
     if (getenv("MK_GRID_SPMV") || A->host_fn) return g;
@@ -622,6 +624,19 @@ struct MkPartialOf {
     __device__ void row(int64_t r, double s, double *) { ysum[r] = s; }
 };
 
+// Block operators (mk_csr_create_block): a block's finished row sums are added to the block row's accumulator,
+// `y_i += B_ij * x_j` (blkop.py:94); the first block of a row adds to the +0.0 the reference's np.zeros holds.
+template <class Epi>
+struct MkAccumOf {
+    static constexpr int NACC = 0, SLOT0 = 0;
+    Epi e;
+    double *ysum;
+    int first;
+    __device__ void prologue(double *s4) { e.prologue(s4); }
+    __device__ double xin(double v) const { return e.xin(v); }
+    __device__ void row(int64_t r, double s, double *) { ysum[r] = (first ? 0.0 : ysum[r]) + s; }
+};
+
 // Pair operators (mk_csr_create_sum / _product): the second launch's epilogue wrappers.  (The wrapped epilogue's
 // optional `pre` hook is forwarded through a base class so that MkHasPre sees it exactly when the epilogue has one.)
 template <class Epi, bool = MkHasPre<Epi>::value>
@@ -653,6 +668,39 @@ struct MkNoXin : MkWrapBase<Epi> {   // the outer product of `A*(B*x)`: its inpu
 template <class Epi, class Gate, class HaltSrc>
 static inline void mk_spmv_launch_blocks(const mk_csr *A, int grid, hipStream_t st, const double *x, const Epi &epi,
                                          const Gate &gate, HaltSrc &&next, double *partials) {
+    if (A->comp_kind == 4) {
+        // Grid of device matrices: one launch per block into the rows' accumulators (the first launch evaluates the
+        // gate with its side effects, the others repeat its decision), then the accumulated rows go through the real
+        // epilogue exactly as a matrix-free operator's result does.
+        const MkBlockGrid &G = *A->grid;
+        bool any = false;
+        for (int i = 0; i < G.nbr; ++i) {
+            bool first_in_row = true;
+            for (int j = 0; j < G.nbc; ++j) {
+                const mk_csr *B = G.blk[(size_t)i * G.nbc + j];
+                if (!B) continue;
+                const double *xs = x + G.coff[j];
+                if (G.coff[j] & 1) {                         // (the kernels read x in 16-byte pairs)
+                    hipMemcpyAsync(G.d_xtmp, xs, sizeof(double) * (size_t)B->ncols, hipMemcpyDeviceToDevice, st);
+                    xs = G.d_xtmp;
+                }
+                MkCsrView v = mk_view(B);
+                v.part = any ? 2 : 1;
+                mk_spmv_launch_view(v, mk_grid_spmv_for(B), st, xs,
+                                    MkAccumOf<Epi>{epi, A->d_comp_tmp + G.roff[i], first_in_row ? 1 : 0}, gate, next(), partials);
+                any = true;
+                first_in_row = false;
+            }
+            if (first_in_row && G.roff[i + 1] > G.roff[i])   // a block row without blocks: zeros
+                hipMemsetAsync(A->d_comp_tmp + G.roff[i], 0, sizeof(double) * (size_t)(G.roff[i + 1] - G.roff[i]), st);
+        }
+        MkCsrView v = mk_view(A);
+        v.cb_mode = 2;
+        v.y_ext = A->d_comp_tmp;
+        v.part = any ? 2 : 0;
+        mk_spmv_launch_view(v, grid, st, x, epi, gate, next(), partials);
+        return;
+    }
     if (A->comp_kind) {
         // Two device matrices as one operator: first product into the temporary (gate with its side effects), second
         // product with the combining wrapper around the real epilogue (gate's decision repeated).

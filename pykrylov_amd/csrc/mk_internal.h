@@ -125,6 +125,14 @@ struct MkPlan {
     double *d_cbsum = nullptr;     // nrows running sums
 };
 
+// grid of device matrices seen as one operator (mk_csr_create_block; reference linop/blkop.py:8-152, :154-257)
+struct MkBlockGrid {
+    int nbr = 0, nbc = 0;
+    std::vector<const struct mk_csr *> blk;    // row major; null = zero block
+    std::vector<int64_t> roff, coff;           // nbr + 1 / nbc + 1 offsets into y / x
+    double *d_xtmp = nullptr;                  // aligned copy of an x slice that starts at an odd offset
+};
+
 struct mk_csr {
     int64_t nrows = 0, ncols = 0, nnz = 0;
     int32_t *d_indptr = nullptr;
@@ -140,8 +148,13 @@ struct mk_csr {
     int want_map = -1, want_stripe = 0, want_plane = 0;   // mk_csr_set_tile_order: -1 = library default
     int want_nt = -1;              // mk_csr_set_tile_order: non-temporal loads of the streamed matrix data (-1 = default)
     // sum / difference / product of two device matrices (mk_csr_create_sum / _product): no arrays of its own
-    int comp_kind = 0;             // 0 none, 1 A + B, 2 A - B, 3 A * B
+    int comp_kind = 0;             // 0 none, 1 A + B, 2 A - B, 3 A * B, 4 block grid
     const mk_csr *comp_a = nullptr, *comp_b = nullptr;
+    MkBlockGrid *grid = nullptr;   // comp_kind 4
+    // operands of composites are borrowed: they count their dependents, and a matrix destroyed while composites still
+    // use it lives on until the last of them goes (mk_csr_destroy)
+    mutable int dependents = 0;
+    mutable bool doomed = false;
     double *d_comp_tmp = nullptr;  // first product's row sums (sum / difference) or B x (product)
     // matrix-free operator (mk_csr_create_callback): no arrays; products come from a host callback
     mk_matvec_fn host_fn = nullptr;

@@ -66,6 +66,11 @@ class KrylovMethod(object):
         from .linop import CsrOperator, HostOperatorShell
         if isinstance(self.op, CsrOperator):
             return self.op
+        view = getattr(self.op, '_device_view', None)        # block operators whose blocks all live on the device
+        if view is not None:
+            dev = view()
+            if dev is not None:
+                return dev
         sh = getattr(self, '_host_shell', None)
         if sh is None or sh.host_op is not self.op:
             if not hasattr(self.op, 'shape') or not hasattr(self.op, '__mul__'):

@@ -724,6 +724,81 @@ class _PairCsrOperator(CsrOperator):
         raise NotImplementedError('a device sum / product has no matrix of its own; use its operands')
 
 
+class _BlockCsrOperator(CsrOperator):
+    """A grid of device matrices as ONE device operator (mk_csr_create_block) -- what the device solvers see of a
+    `blkop.BlockLinearOperator` / `BlockDiagonalLinearOperator` whose blocks all live on the device.  A product runs
+    one launch per block and adds the block products to each block row one at a time, `y_i += B_ij * x_j`
+    (reference blkop.py:86-96): the reference's roundings, no host round trip.  Products are counted on the block
+    operator it was built from and on every block, as the reference's closures do."""
+
+    @classmethod
+    def build(cls, owner, grid, heights, widths):
+        "`grid`: rows of CsrOperator / None (zero block).  Returns None if the library refuses (e.g. a composite block)."
+        lib = _lib.init()
+        nbr, nbc = len(grid), len(grid[0])
+        flat = [blk for row in grid for blk in row]
+        arr = (ctypes.c_void_p * len(flat))(*[None if b is None else b.handle for b in flat])
+        hs = (ctypes.c_int64 * nbr)(*[int(h) for h in heights])
+        ws = (ctypes.c_int64 * nbc)(*[int(w) for w in widths])
+        h = ctypes.c_void_p()
+        if lib.mk_csr_create_block(nbr, nbc, arr, hs, ws, ctypes.byref(h)) != 0:
+            return None
+        self = cls.from_handle(h.value, symmetric=bool(getattr(owner, 'symmetric', False)))
+        self._owner = owner
+        self._parts = [b for b in flat if b is not None]      # keeps the blocks alive
+        return self
+
+    def _pair_ok(self):
+        return False
+
+    def _compose(self, steps, diag_bufs=()):
+        return None
+
+    def _get_count(self):
+        return self.__dict__.get('_count', 0)
+
+    def _set_count(self, v):
+        delta = v - self.__dict__.get('_count', 0)
+        self.__dict__['_count'] = v
+        if delta and self.__dict__.get('_owner') is not None:
+            self._owner._nMatvec += delta
+            for b in self.__dict__.get('_parts', ()):
+                b._nMatvec += delta
+
+    _nMatvec = property(_get_count, _set_count)
+
+    @property
+    def T(self):
+        if self.symmetric:
+            return self
+        raise NotImplementedError('transpose the block operator itself (its transpose has its own device view)')
+
+    H = T
+
+    def to_csr_arrays(self):
+        raise NotImplementedError('a device block operator has no matrix of its own; use its blocks')
+
+
+def device_block(blk):
+    """A block of a block operator as a device matrix, if it is one or has an exact device form: a CsrOperator as it
+    is; a DiagonalOperator / IdentityOperator as the CSR matrix of its diagonal (`diag * x`, linop.py:503 -- one
+    product per row either way; cached on the operator).  None for anything else."""
+    if isinstance(blk, CsrOperator):
+        return blk if (blk._pair_ok() and blk.handle) else None
+    term = getattr(blk, '_mk_term', None)
+    if term is None or term[1] is not None or not isinstance(blk, BaseLinearOperator) or blk.nargin != blk.nargout:
+        return None                                           # (scaled diagonals round twice in the reference: host)
+    cached = blk.__dict__.get('_device_diag_csr')
+    if cached is None or not cached.handle:
+        n = blk.nargin
+        diag = np.ones(n) if term[0] is None else np.ascontiguousarray(term[0], dtype=np.float64)
+        if _is_complex(np.asarray(diag).dtype):
+            return None
+        cached = CsrOperator(np.arange(n + 1), np.arange(n), diag, (n, n), symmetric=True)
+        blk.__dict__['_device_diag_csr'] = cached
+    return cached
+
+
 class HostOperatorShell(object):
     """What the device solvers see of an operator that is NOT a CsrOperator: any object following the reference's
     protocol, ``op * ndarray -> ndarray`` (linop.py:271-298, e.g. ``LinearOperator(n, n, matvec=callable)`` or the
