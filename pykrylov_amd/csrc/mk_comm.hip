@@ -21,6 +21,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -77,6 +78,7 @@ int load_rccl() {
     MK_SYM(CommDestroy, "ncclCommDestroy");
     MK_SYM(AllReduce, "ncclAllReduce");
     MK_SYM(AllGather, "ncclAllGather");
+    MK_SYM(ReduceScatter, "ncclReduceScatter");
     MK_SYM(Send, "ncclSend");
     MK_SYM(Recv, "ncclRecv");
     MK_SYM(GroupStart, "ncclGroupStart");
@@ -167,6 +169,43 @@ int mk_comm_allreduce_sum(double *buf, int64_t count, hipStream_t stream) {
     }
     if (!g_comm) return mk_fail(MK_ERR_COMM, "all-reduce without a communicator");
     MK_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_comm, stream));
+    return MK_OK;
+}
+
+// mine = this rank's block of `count` entries of the element-wise sum over the ranks of `full` (count * nranks entries)
+int mk_comm_reduce_scatter_sum(const double *full, double *mine, int64_t count, hipStream_t stream) {
+    if (g_host.active) {                                     // host transport: all-reduce on the host, keep one block
+        const size_t tot = (size_t)count * (size_t)g_nranks;
+        int rc = g_host.reserve(&g_host.send, &g_host.send_cap, tot ? tot : 1);
+        if (rc != MK_OK) return rc;
+        MK_HIP(hipMemcpyAsync(g_host.send, full, sizeof(double) * tot, hipMemcpyDeviceToHost, stream));
+        MK_HIP(hipStreamSynchronize(stream));
+        if (g_host.allreduce(g_host.send, (int64_t)tot) != 0) return mk_fail(MK_ERR_COMM, "host all-reduce callback failed");
+        MK_HIP(hipMemcpyAsync(mine, g_host.send + (size_t)g_rank * (size_t)count, sizeof(double) * (size_t)count,
+                              hipMemcpyHostToDevice, stream));
+        MK_HIP(hipStreamSynchronize(stream));
+        return MK_OK;
+    }
+    if (!g_comm) return mk_fail(MK_ERR_COMM, "reduce-scatter without a communicator");
+    MK_NCCL(g_rccl.ReduceScatter(full, mine, (size_t)count, ncclDouble, ncclSum, g_comm, stream));
+    return MK_OK;
+}
+
+// full = the ranks' blocks of `count` entries one after the other (mine may be full + rank * count: in place)
+int mk_comm_allgather(const double *mine, double *full, int64_t count, hipStream_t stream) {
+    if (g_host.active) {
+        int rc = g_host.reserve(&g_host.send, &g_host.send_cap, (size_t)(count ? count : 1));
+        if (rc == MK_OK) rc = g_host.reserve(&g_host.recv, &g_host.recv_cap, (size_t)count * (size_t)g_nranks + 1);
+        if (rc != MK_OK) return rc;
+        MK_HIP(hipMemcpyAsync(g_host.send, mine, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, stream));
+        MK_HIP(hipStreamSynchronize(stream));
+        if (g_host.allgather(g_host.send, count, g_host.recv) != 0) return mk_fail(MK_ERR_COMM, "host all-gather callback failed");
+        MK_HIP(hipMemcpyAsync(full, g_host.recv, sizeof(double) * (size_t)count * (size_t)g_nranks, hipMemcpyHostToDevice, stream));
+        MK_HIP(hipStreamSynchronize(stream));
+        return MK_OK;
+    }
+    if (!g_comm) return mk_fail(MK_ERR_COMM, "all-gather without a communicator");
+    MK_NCCL(g_rccl.AllGather(mine, full, (size_t)count, ncclDouble, g_comm, stream));
     return MK_OK;
 }
 

@@ -165,7 +165,7 @@ struct mk_csr {
     int *d_cb_go = nullptr;                            // device flag: the gate let this product through
     // mk_csr_set_row_block: this matrix is one rank's block of ROWS of a taller operator whose column space is
     // replicated on every rank (least-squares solvers: u sliced, v whole, A' u summed over the ranks)
-    bool row_block = false;
+    int row_block = 0;             // 1: n-space vectors whole on every rank; 2: sliced like the ranks' column blocks
     int32_t nops = 0;              // row program (mk_csr_compose)
     mk_rowop ops[MK_ROWPROG_MAX] = {};
     // length of the vector an SpMV reads (ncols, or n_local + n_halo with a halo plan)

@@ -969,7 +969,7 @@ __global__ __launch_bounds__(MK_BLOCK) void lls_fill_kernel(double *v, int64_t n
 
 struct LlsSolver : mk_solver {
     int kind;
-    int64_t m = 0, nn = 0;
+    int64_t m = 0, nn = 0, nF = 0;
     double *d_u = nullptr, *d_v = nullptr, *d_x = nullptr;
     double *d_a = nullptr, *d_b = nullptr;      // LSQR: w ; LSMR: h, hbar ; CRAIG: w, wbar
     double *d_d = nullptr, *d_r = nullptr, *d_dbar = nullptr;
@@ -1064,10 +1064,21 @@ struct LlsSolver : mk_solver {
         return MK_OK;
     }
 
-    // several GPUs, A = this rank's row block (mk_csr_set_row_block): m-space vectors are slices, n-space vectors
-    // whole and identical on every rank
-    bool dist = false;
+    // several GPUs, A = this rank's row block (mk_csr_set_row_block): m-space vectors are slices; n-space vectors are
+    // either whole and identical on every rank (mode 1: A' u is all-reduced, all n-space work replicated -- fine for
+    // m >> n) or SLICED (mode 2): rank r owns entries [r cnt, (r + 1) cnt) of every n-space vector, A' u is
+    // reduce-scattered, the n-space updates and their inner products run on the slices (partial sums all-reduced like
+    // the m-space ones) and only v -- which the next A v reads whole -- is all-gathered after its update.  Same bytes
+    // on the wire as the all-reduce (reduce-scatter + all-gather), 1 / nranks of the n-space arithmetic and memory.
+    bool dist = false, sliced = false;
     double *d_t = nullptr;                       // A' u of the local block, then its sum over the ranks
+    double *d_tl = nullptr, *d_xfull = nullptr;  // sliced: this rank's block of the sum; x gathered for the caller
+    int64_t cnt = 0, off = 0, nl = 0;            // sliced: entries per rank, this rank's offset, its real entries
+    // n-space operands as the kernels see them: the whole vector, or this rank's slice
+    double *vL() const { return d_v + off; }
+    const double *dnL() const { return d_dn ? d_dn + off : nullptr; }
+    int gather_v() { return sliced ? mk_comm_allgather(vL(), d_v, cnt, stream) : (int)MK_OK; }
+    int sum_x() { return sliced ? allreduce(SLOT_X, 1) : (int)MK_OK; }
 
     // <u, Mu> is an m-space inner product: its partial sums are added across the ranks
     int sum_uu() { return dist ? allreduce(SLOT_UU, 1) : (int)MK_OK; }
@@ -1078,6 +1089,12 @@ struct LlsSolver : mk_solver {
             return apply_N(in_setup);
         }
         mk_launch_spmv_on(this, At, d_u, MkPlainEpi{d_t}, GateV{d_scal});
+        if (sliced) {
+            int rc = mk_comm_reduce_scatter_sum(d_t, d_tl, cnt, stream);
+            if (rc != MK_OK) return rc;
+            mk_launch_stream(this, OpVt{d_scal, d_tl, vL(), dnL(), d_Nv, 0.0}, nl);
+            return allreduce(SLOT_VV, 1);
+        }
         int rc = mk_comm_allreduce_sum(d_t, nn, stream);   // (a skipped product leaves old data: OpVt skips as well)
         if (rc != MK_OK) return rc;
         mk_launch_stream(this, OpVt{d_scal, d_t, d_v, d_dn, d_Nv, 0.0}, nn);
@@ -1093,6 +1110,7 @@ struct LlsSolver : mk_solver {
             return mk_fail(MK_ERR_UNSUPPORTED, "least-squares solvers: partition A by row blocks (mk_csr_set_row_block), "
                            "not with a halo / all-gather exchange plan");
         dist = A->row_block && mk_comm_active();
+        sliced = dist && A->row_block == 2;
         if (dist && (A->host_fn || At->host_fn || fn_m || fn_n))
             return mk_fail(MK_ERR_UNSUPPORTED, "least-squares solvers: matrix-free operators and M / N callbacks are "
                            "single-GPU");
@@ -1108,22 +1126,39 @@ struct LlsSolver : mk_solver {
         // (row blocks: all-reduced slots mean the same on every rank only if all MK_MAXP entries are added; the
         //  producers clear what their grids leave unused, MkHalt::clear_tail)
         if (dist) np_A = np_At = np_n = np_m = MK_MAXP;
+        // n-space lengths: nA = what this rank holds of a, b, x, Nv; nF = v and A' u, which the products see whole
+        cnt = nn;
+        off = 0;
+        nl = nn;
+        if (sliced) {
+            int P = 1, rk = 0;
+            mk_comm_info(&P, &rk);
+            cnt = (((nn + P - 1) / P) + 1) & ~(int64_t)1;    // (even: the stream kernels work on 16-byte pairs)
+            off = (int64_t)rk * cnt;
+            nl = nn - off < 0 ? 0 : (nn - off < cnt ? nn - off : cnt);
+            nF = cnt * P;
+        } else {
+            nF = nn;
+        }
+        const int64_t nA = sliced ? cnt : nn;
         if (!d_u) {
             int rc;
-            if ((rc = alloc_vec(&d_u, m)) || (rc = alloc_vec(&d_v, nn)) ||
-                (rc = alloc_vec(&d_x, kind == MK_CRAIGMR ? m : nn)) || (rc = alloc_vec(&d_a, nn)) ||
-                (rc = alloc_vec(&d_b, nn)) || (rc = alloc_vec(&d_d, m)) || (rc = alloc_vec(&d_r, m)) ||
+            if ((rc = alloc_vec(&d_u, m)) || (rc = alloc_vec(&d_v, nF)) ||
+                (rc = alloc_vec(&d_x, kind == MK_CRAIGMR ? m : nA)) || (rc = alloc_vec(&d_a, nA)) ||
+                (rc = alloc_vec(&d_b, nA)) || (rc = alloc_vec(&d_d, m)) || (rc = alloc_vec(&d_r, m)) ||
                 (rc = alloc_vec(&d_dbar, m)))
                 return rc;
         }
-        for (double *p : {d_v, d_a, d_b}) MK_HIP(hipMemsetAsync(p, 0, sizeof(double) * (size_t)nn, stream));
+        MK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)nF, stream));
+        for (double *p : {d_a, d_b}) MK_HIP(hipMemsetAsync(p, 0, sizeof(double) * (size_t)nA, stream));
         for (double *p : {d_d, d_r, d_dbar}) MK_HIP(hipMemsetAsync(p, 0, sizeof(double) * (size_t)m, stream));
-        MK_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)(kind == MK_CRAIGMR ? m : nn), stream));
+        MK_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)(kind == MK_CRAIGMR ? m : nA), stream));
         int rc2;
         if (d_dm && !d_Mu && (rc2 = alloc_vec(&d_Mu, m))) return rc2;
-        if (d_dn && !d_Nv && (rc2 = alloc_vec(&d_Nv, nn))) return rc2;
-        if (dist && !d_t && (rc2 = alloc_vec(&d_t, nn))) return rc2;
-        if (d_Nv) MK_HIP(hipMemsetAsync(d_Nv, 0, sizeof(double) * (size_t)nn, stream));
+        if (d_dn && !d_Nv && (rc2 = alloc_vec(&d_Nv, nA))) return rc2;
+        if (dist && !d_t && (rc2 = alloc_vec(&d_t, nF))) return rc2;          // (entries past nn stay zero)
+        if (sliced && !d_tl && ((rc2 = alloc_vec(&d_tl, cnt)) || (rc2 = alloc_vec(&d_xfull, nF)))) return rc2;
+        if (d_Nv) MK_HIP(hipMemsetAsync(d_Nv, 0, sizeof(double) * (size_t)nA, stream));
         if (d_dm) {
             mk_launch_stream(this, MkOpCopy{rhs, d_Mu}, m);                            // Mu = rhs.copy()   lsqr.py:188
             mk_launch_stream(this, MkOpMul{d_dm, d_Mu, d_u}, m);                       // u = M(Mu)         lsqr.py:190
@@ -1139,8 +1174,9 @@ struct LlsSolver : mk_solver {
         if ((rc2 = product_At(true)) != MK_OK) return rc2;
         hipLaunchKernelGGL(lls_init_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_vv(), d_scal, d_status,
                            next_halt(), kind, itnlim);
-        mk_launch_stream(this, OpInitN{d_scal, kind, d_v, d_a, d_b, d_x, 0, 0, 0, 0}, nn);
-        if (d_dn) mk_launch_stream(this, OpScaleNv{d_scal, d_scal + S_BLK, 0, d_Nv, 0.0, false}, nn);   // lsqr.py:209
+        mk_launch_stream(this, OpInitN{d_scal, kind, vL(), d_a, d_b, d_x, 0, 0, 0, 0}, nl);
+        if ((rc2 = gather_v()) != MK_OK) return rc2;
+        if (d_dn) mk_launch_stream(this, OpScaleNv{d_scal, d_scal + S_BLK, 0, d_Nv, 0.0, false}, nl);   // lsqr.py:209
         if (kind == MK_CRAIG || kind == MK_CRAIGMR)
             mk_launch_stream(this, OpInitM{d_scal, kind, d_u, d_d, d_r, 0, 0}, m);
         return MK_OK;
@@ -1168,21 +1204,22 @@ struct LlsSolver : mk_solver {
         if ((rc = product_At(false)) != MK_OK) return rc;                                                // G3
         if (kind == MK_LSQR) {
             mk_launch_stream(this, lsqr::OpN{d_part, np_vv(), d_scal, d_status, d_hist, par, itn, prm.window, prm.damp,
-                                             prm.atol, prm.btol, prm.etol, d_v, d_a, d_x, 0, 0, 0, 0, false}, nn);
+                                             prm.atol, prm.btol, prm.etol, vL(), d_a, d_x, 0, 0, 0, 0, false}, nl);
         } else if (kind == MK_LSMR) {
             mk_launch_stream(this, lsmr::OpN{d_part, np_vv(), d_scal, d_status, d_hist, par, itn, prm.window, prm.damp,
-                                             prm.etol, d_v, d_a, d_b, d_x, 0, 0, 0, 0, false}, nn);
+                                             prm.etol, vL(), d_a, d_b, d_x, 0, 0, 0, 0, false}, nl);
         } else if (kind == MK_CRAIG) {
             mk_launch_stream(this, craig::OpN{d_part, np_vv(), d_scal, d_status, d_hist, par, itn, itnlim, prm.window,
-                                              prm.btol, prm.etol, d_v, d_a, d_b, d_x, 0, 0, 0, 0, 0, false}, nn);
+                                              prm.btol, prm.etol, vL(), d_a, d_b, d_x, 0, 0, 0, 0, 0, false}, nl);
             mk_launch_stream(this, craig::OpM{blk_next, d_u, d_d, d_r, 0, 0, 0}, m);
         } else {
             mk_launch_stream(this, craig::OpNmr{d_part, np_vv(), d_scal, d_status, d_hist, par, itn, itnlim, prm.window,
-                                                prm.etol, d_v, 0, false}, nn);
+                                                prm.etol, vL(), 0, false}, nl);
             mk_launch_stream(this, craig::OpMmr{blk_next, d_u, d_d, d_dbar, d_x, 0, 0, 0, 0, 0}, m);
         }
-        if (d_dn) mk_launch_stream(this, OpScaleNv{d_scal, blk_next, 1, d_Nv, 0.0, false}, nn);          // lsqr.py:272
-        return MK_OK;
+        if (d_dn) mk_launch_stream(this, OpScaleNv{d_scal, blk_next, 1, d_Nv, 0.0, false}, nl);          // lsqr.py:272
+        if ((rc = sum_x()) != MK_OK) return rc;              // (sliced: ||dk||^2 / ||x||^2 partials of the slices)
+        return gather_v();                                   // ... and the next A v reads v whole
     }
 
     int finish(mk_result *res) override {
@@ -1204,10 +1241,14 @@ struct LlsSolver : mk_solver {
         res->converged = (is == 1 || is == 2 || is == 4 || is == 5 || is == 8) ? 1 : 0;     // `optimal`, lsqr.py:442
         // the gates leave itn one ahead when they admit a pass that the host never enqueued; report completed passes
         res->itn = res->nMatvec / 2;
+        if (sliced && kind != MK_CRAIGMR) {                  // the caller reads x whole (CRAIG-MR's x lives in m-space)
+            rc = mk_comm_allgather(d_x, d_xfull, cnt, stream);
+            if (rc != MK_OK) return rc;
+        }
         return MK_OK;
     }
 
-    const double *x() const override { return d_x; }
+    const double *x() const override { return (sliced && kind != MK_CRAIGMR) ? d_xfull : d_x; }
     const double *vector(int i) const override { return i == 0 ? d_r : (i == 1 ? d_u : (i == 2 ? d_v : nullptr)); }
     int set_metric(const double *dm, const double *dn) {
         if (!fn_m) d_dm = dm;                    // (a side that has a callback keeps its diagonal of ones)

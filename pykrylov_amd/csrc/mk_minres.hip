@@ -347,6 +347,14 @@ struct MinresSolver : mk_solver {
         return MK_OK;
     }
 
+    int enqueue_spmv_only() override {                     // (timing aid: the product kernel of a pass without its gate;
+        const int par = (int)(it & 1);                     //  writes v and t of the current pass, which the next pass
+        const double *blk = d_scal + S_BLK + par * BLK;    //  overwrites anyway)
+        double *r1 = d_r[it & 1], *r2 = d_r[(it + 1) & 1];
+        mk_launch_spmv(this, d_prec ? d_y : r2, EpiK1{blk, d_prec ? d_y : r2, r1, d_v, d_t, prm.shift, 0, 0.0, 0.0}, false);
+        return MK_OK;
+    }
+
     int enqueue_pass() override {
         const int par = (int)(it & 1);
         const double *blk = d_scal + S_BLK + par * BLK;

@@ -25,6 +25,8 @@ constexpr int64_t MK_BATCH_MAX = 256;
 // Collective hooks (implemented in mk_comm.hip; no-ops without a communicator).
 int mk_comm_active();
 int mk_comm_allreduce_sum(double *buf_dev, int64_t count, hipStream_t stream);
+int mk_comm_reduce_scatter_sum(const double *full_dev, double *mine_dev, int64_t count_per_rank, hipStream_t stream);
+int mk_comm_allgather(const double *mine_dev, double *full_dev, int64_t count_per_rank, hipStream_t stream);
 int mk_exchange_begin(const mk_csr *A, double *x_ext);     // may leave the messages in flight on a second stream
 int mk_exchange_wait(const mk_csr *A, hipStream_t stream); // ... until here
 

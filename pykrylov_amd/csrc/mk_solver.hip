@@ -240,7 +240,8 @@ extern "C" int mk_csr_set_row_block(mk_csr *A, int on) {
     MK_ARG(A != nullptr);
     if (on && A->ex.mode >= 0)
         return mk_fail(MK_ERR_STATE, "mk_csr_set_row_block: the matrix already carries a halo / all-gather exchange plan");
-    A->row_block = on != 0;
+    if (on < 0 || on > 2) return mk_fail(MK_ERR_ARG, "mk_csr_set_row_block: mode must be 0, 1 or 2");
+    A->row_block = on;
     return MK_OK;
 }
 

@@ -253,7 +253,7 @@ def partition_host_csr(world, indptr, indices, data, n, mode="halo"):
                            p["send_idx"]), p["ranges"]
 
 
-def partition_row_blocks(world, indptr, indices, data, shape):
+def partition_row_blocks(world, indptr, indices, data, shape, sliced=False):
     """Row blocks of a (replicated) host m x n CSR matrix for the least-squares solvers (lls/): this rank keeps rows
     ``ranges[rank]`` with their GLOBAL columns.  m-space vectors (rhs, u, r; x of CRAIG-MR) are sliced like the rows,
     n-space vectors (v, w, x) are whole and identical on every rank: ``A * v`` needs no exchange, ``A.T * u``
@@ -265,7 +265,10 @@ def partition_row_blocks(world, indptr, indices, data, shape):
     r0, r1 = ranges[world.rank]
     lp, li, ld = csr_row_slice(indptr, indices, data, r0, r1)
     op = CsrOperator(lp, li, ld, (r1 - r0, n))
-    _lib.check(_lib.init().mk_csr_set_row_block(op.handle, 1))
+    # mode 1: n-space vectors whole on every rank (A' u all-reduced; right for m >> n).  mode 2 (`sliced`): every rank
+    # owns a block of the n-space vectors as well -- A' u is reduce-scattered, the n-space updates and their inner
+    # products run on the blocks, only v is all-gathered for the next A v; x is returned whole either way
+    _lib.check(_lib.init().mk_csr_set_row_block(op.handle, 2 if sliced else 1))
     op.row_range, op.global_shape = (r0, r1), (m, n)
     return op, ranges
 

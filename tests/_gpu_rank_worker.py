@@ -166,9 +166,13 @@ def main():
     g = np.load(os.path.join(ROOT, "tests", "golden", "lls_random.npz"), allow_pickle=False)
     L = csr_ref.RefCsr(g["l_A_indptr"], g["l_A_indices"], g["l_A_data"], g["l_A_shape"])
     mL, nL = L.shape
-    for solver, btag, kw in (("lsqr", "ls", dict(damp=0.0)), ("lsqr", "cons", dict(damp=0.1)),
-                             ("lsmr", "ls", dict(damp=0.0)), ("craig", "cons", {}), ("craigmr", "cons", {})):
-        op, ranges = dist.partition_row_blocks(world, L.indptr, L.indices, L.data, L.shape)
+    cases = [(s_, b_, k_, False) for s_, b_, k_ in (("lsqr", "ls", dict(damp=0.0)), ("lsqr", "cons", dict(damp=0.1)),
+                                                     ("lsmr", "ls", dict(damp=0.0)), ("craig", "cons", {}),
+                                                     ("craigmr", "cons", {}))]
+    # ... and with the n-space vectors sliced over the ranks as well (reduce-scatter of A' u, all-gather of v)
+    cases += [(s_, b_, k_, True) for s_, b_, k_, _ in cases]
+    for solver, btag, kw, sliced in cases:
+        op, ranges = dist.partition_row_blocks(world, L.indptr, L.indices, L.data, L.shape, sliced=sliced)
         r0, r1 = ranges[rank]
         assert op.shape == (r1 - r0, nL) and op.global_shape == (mL, nL)
         b = g["l_b_" + btag]
@@ -195,20 +199,24 @@ def main():
             r = gather_x(world, s.r)                        # (the golden run kept no r: the oracle's)
             rref = lls_ref.craig(L.matvec, L.transpose().matvec, L.shape, b.copy(), etol=1e-6)["r"]
             ent["r_err"] = float(np.linalg.norm(r - rref) / np.linalg.norm(b))
-        out["lls_%s_%s" % (solver, btag)] = ent
+        out["lls_%s_%s%s" % (solver, btag, "_sliced" if sliced else "")] = ent
         op.free()
     # diagonal preconditioners: M sliced like the rows, N whole
     dm = 1.0 + 0.5 * np.cos(np.arange(mL))
     dn = 1.0 + 0.25 * np.sin(np.arange(nL))
-    op, ranges = dist.partition_row_blocks(world, L.indptr, L.indices, L.data, L.shape)
-    r0, r1 = ranges[rank]
-    s = lls.LSQRFramework(op)
-    s.solve(g["l_b_ls"][r0:r1], M=DiagonalOperator(dm[r0:r1]), N=DiagonalOperator(dn), etol=0.0)
     Lt = L.transpose()
     ref = lls_ref.lsqr(L.matvec, Lt.matvec, L.shape, g["l_b_ls"].copy(), etol=0.0, M=lambda v: dm * v, N=lambda v: dn * v)
-    out["lls_lsqr_precon"] = dict(itn=int(s.itn), ref=int(ref["itn"]), istop=int(s.istop),
-                                  x_err=float(np.linalg.norm(s.x - ref["x"]) / np.linalg.norm(ref["x"])))
-    op.free()
+    for sliced in (False, True):
+        op, ranges = dist.partition_row_blocks(world, L.indptr, L.indices, L.data, L.shape, sliced=sliced)
+        r0, r1 = ranges[rank]
+        s = lls.LSQRFramework(op)
+        s.solve(g["l_b_ls"][r0:r1], M=DiagonalOperator(dm[r0:r1]), N=DiagonalOperator(dn), etol=0.0)
+        xs = world.allgather_object(np.asarray(s.x))
+        assert all(np.array_equal(xs[0], xr) for xr in xs)
+        out["lls_lsqr_precon" + ("_sliced" if sliced else "")] = dict(
+            itn=int(s.itn), ref=int(ref["itn"]), istop=int(s.istop),
+            x_err=float(np.linalg.norm(s.x - ref["x"]) / np.linalg.norm(ref["x"])))
+        op.free()
 
     _lib.load().mk_comm_destroy()
     if rank == 0:

@@ -33,7 +33,7 @@ def test_partitioned_solvers_on_one_gpu(nranks):
     out = json.loads(line[len("RESULT "):])
     assert len(out) >= 10, sorted(out)
     lls_keys = [k for k in out if k.startswith("lls_")]
-    assert len(lls_keys) == 6, lls_keys
+    assert len(lls_keys) == 12 and sum(k.endswith("_sliced") for k in lls_keys) == 6, lls_keys
     for k in lls_keys:
         # (the tolerances of the single-GPU runs against the same golden traces, tests/test_gpu_lls.py)
         r = out.pop(k)
