@@ -344,6 +344,12 @@ int mk_solver_set_precon_diag(mk_solver *s, const double *diag);
  * and on partitioned operators.  Replaces a diagonal set earlier.  Call before mk_solver_setup. */
 typedef int (*mk_precon_fn)(void *user, const double *r_host, double *y_host);
 int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void *user);
+/* ... or a DEVICE operator: `precon * r` (generic/generic.py:76) evaluated as a product with a device matrix or
+ * composite -- a sparse approximate inverse such as the inverted diagonal blocks of block-Jacobi
+ * (pykrylov_amd.tools.block_jacobi) -- at the same sites as the callback, without leaving HBM.  M is borrowed, square,
+ * of the solver's (local) size, without an exchange plan (on several GPUs: a rank-local preconditioner).  NULL
+ * removes it.  Call before mk_solver_setup. */
+int mk_solver_set_precon_csr(mk_solver *s, const mk_csr *M);
 /* The least-squares kinds take two preconditioners, applied by the reference as `u = M(Mu)` in the m-space and
  * `v = N(Nv)` in the n-space of the Golub-Kahan process (lls/lsqr.py:189-190,201-202,253-254,265-266 and the same
  * lines of lsmr.py, craig.py, craigmr.py): device arrays with the diagonals of M (nrows(A) entries) and N

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "mk_csr_set_row_block": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "mk_solver_set_precon_diag": (ctypes.c_int, [c_vp, c_vp]),
     "mk_solver_set_precon_callback": (ctypes.c_int, [c_vp, PRECON_FN, c_vp]),
+    "mk_solver_set_precon_csr": (ctypes.c_int, [c_vp, c_vp]),
     "mk_solver_set_lls_precon_callback": (ctypes.c_int, [c_vp, PRECON_FN, c_vp, PRECON_FN, c_vp]),
     "mk_solver_set_lls_precon": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "mk_solver_setup": (ctypes.c_int, [c_vp, c_vp, c_vp]),

@@ -6,7 +6,7 @@ the GPU (``csrc/mk_cg.hip``: 3 fused kernels per iteration, no host round trip).
 import numpy as np
 
 from . import _lib
-from .generic import KrylovMethod, DeviceRun, HostPrecon
+from .generic import KrylovMethod, DeviceRun, DevicePrecon, HostPrecon
 from .tools import check_symmetric
 
 __docformat__ = 'restructuredtext'
@@ -56,7 +56,12 @@ class CG(KrylovMethod):
         def prec(r):                                                   # y = precon * r for `store_resids` (cg.py:96,133)
             if pdiag is None:
                 return r
-            return pdiag.precon * r if isinstance(pdiag, HostPrecon) else pdiag * r
+            if isinstance(pdiag, DevicePrecon):
+                return pdiag.apply(r)
+            if isinstance(pdiag, HostPrecon):                           # (same dispatch as the device loop's callback)
+                p = pdiag.precon
+                return p * r if hasattr(p, '__mul__') else p(r)
+            return pdiag * r
 
         with DeviceRun(op, _lib.MK_CG, rhs, guess, precon_diag=pdiag, abstol=float(self.abstol),
                        reltol=float(self.reltol),

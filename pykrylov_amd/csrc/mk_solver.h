@@ -40,6 +40,11 @@ struct mk_solver {
     mk_precon_fn precon_fn = nullptr;
     void *precon_user = nullptr;
     double *d_ones = nullptr, *h_pin = nullptr, *h_pout = nullptr;
+    // ... or through a DEVICE operator (mk_solver_set_precon_csr: a sparse approximate inverse, e.g. the inverted
+    // diagonal blocks of block-Jacobi, as a device matrix or composite): the same sites, the product stays in HBM
+    const mk_csr *precon_op = nullptr;
+    double *d_ptmp = nullptr;       // product target when a site preconditions a vector in place
+    int *d_nohalt = nullptr;        // two zero words: the halt input of a product that must run after the loop has ended
     int host_precon(const double *in_dev, double *out_dev, bool force = false);   // out = precon * in ; unless `force`, a no-op once the loop has halted
     mk_params prm{};
     int64_t n = 0;        // local rows = length of every solver vector

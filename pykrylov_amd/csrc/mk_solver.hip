@@ -32,8 +32,27 @@ int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
     return MK_OK;
 }
 
+// (stands in for the callback when the preconditioner is a device operator: every `if (precon_fn ...)` site stays as it is)
+static int mk_precon_on_device(void *, const double *, double *) { return 1; }
+
 int mk_solver::host_precon(const double *in_dev, double *out_dev, bool force) {
     if (!precon_fn) return MK_OK;
+    if (precon_op) {
+        // out = precon_op * in on the device.  Like every kernel of the loop the product obeys the halt words: once the
+        // loop condition has failed it is a no-op, exactly when the reference applies nothing more -- unless `force`.
+        double *dst = (in_dev == out_dev) ? d_ptmp : out_dev;
+        const int grid = mk_grid_spmv_for(precon_op);
+        if (force) {
+            mk_spmv_launch_blocks(precon_op, grid, stream, in_dev, MkPlainEpi{dst}, MkNoGate(),
+                                  [&] { return MkHalt{d_nohalt, 0, 0}; }, d_part);
+            if (dst != out_dev) MK_HIP(hipMemcpyAsync(out_dev, dst, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+        } else {
+            mk_spmv_launch_blocks(precon_op, grid, stream, in_dev, MkPlainEpi{dst}, MkNoGate(),
+                                  [&] { return next_halt(); }, d_part);
+            if (dst != out_dev) mk_launch_stream(this, MkOpCopy{dst, out_dev}, n);
+        }
+        return mk_ctx().pending_rc;
+    }
     int h = 0;
     MK_HIP(hipMemcpyAsync(&h, d_halt + (q & 1), sizeof(int), hipMemcpyDeviceToHost, stream));   // the next kernel's word
     if (n > 0) MK_HIP(hipMemcpyAsync(h_pin, in_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -50,6 +69,8 @@ int mk_solver::host_precon(const double *in_dev, double *out_dev, bool force) {
 
 mk_solver::~mk_solver() {
     hipFree(d_ones);
+    hipFree(d_ptmp);
+    hipFree(d_nohalt);
     if (h_pin) hipHostFree(h_pin);
     if (h_pout) hipHostFree(h_pout);
     if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
@@ -260,6 +281,7 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_fill_kernel(double *v, int64_t n,
 
 extern "C" int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void *user) {
     MK_ARG(s);
+    s->precon_op = nullptr;
     if (!fn) {
         s->precon_fn = nullptr;
         s->d_prec = nullptr;
@@ -271,13 +293,46 @@ extern "C" int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void
     const size_t len = (size_t)(s->n > 0 ? s->n : 1);
     if (!s->d_ones) {
         MK_HIP(hipMalloc((void **)&s->d_ones, sizeof(double) * len + 16));
-        MK_HIP(hipHostMalloc((void **)&s->h_pin, sizeof(double) * len, hipHostMallocDefault));
-        MK_HIP(hipHostMalloc((void **)&s->h_pout, sizeof(double) * len, hipHostMallocDefault));
         hipLaunchKernelGGL(mk_fill_kernel, dim3(512), dim3(MK_BLOCK), 0, s->stream, s->d_ones, (int64_t)len, 1.0);
         MK_HIP(hipGetLastError());
     }
+    if (!s->h_pin) {
+        MK_HIP(hipHostMalloc((void **)&s->h_pin, sizeof(double) * len, hipHostMallocDefault));
+        MK_HIP(hipHostMalloc((void **)&s->h_pout, sizeof(double) * len, hipHostMallocDefault));
+    }
     s->precon_fn = fn;
     s->precon_user = user;
+    s->d_prec = s->d_ones;
+    return MK_OK;
+}
+
+extern "C" int mk_solver_set_precon_csr(mk_solver *s, const mk_csr *M) {
+    MK_ARG(s);
+    if (!M) {
+        s->precon_op = nullptr;
+        s->precon_fn = nullptr;
+        s->d_prec = nullptr;
+        return MK_OK;
+    }
+    if (!s->takes_precon()) return mk_fail(MK_ERR_UNSUPPORTED, "this solver kind has no preconditioner hook");
+    if (M->nrows != s->n || M->ncols != s->n || M->ex.mode >= 0)
+        return mk_fail(MK_ERR_ARG, "mk_solver_set_precon_csr: the preconditioner must be a square device operator of the "
+                       "solver's (local) size %lld without an exchange plan, got %lld x %lld", (long long)s->n,
+                       (long long)M->nrows, (long long)M->ncols);
+    const size_t len = (size_t)(s->n > 0 ? s->n : 1);
+    if (!s->d_ones) {
+        MK_HIP(hipMalloc((void **)&s->d_ones, sizeof(double) * len + 16));
+        hipLaunchKernelGGL(mk_fill_kernel, dim3(512), dim3(MK_BLOCK), 0, s->stream, s->d_ones, (int64_t)len, 1.0);
+        MK_HIP(hipGetLastError());
+    }
+    if (!s->d_ptmp) {
+        MK_HIP(hipMalloc((void **)&s->d_ptmp, sizeof(double) * len + 16));
+        MK_HIP(hipMalloc((void **)&s->d_nohalt, 2 * sizeof(int)));
+        MK_HIP(hipMemsetAsync(s->d_nohalt, 0, 2 * sizeof(int), s->stream));
+    }
+    s->precon_op = M;
+    s->precon_fn = mk_precon_on_device;                      // (marks "general preconditioner" at the call sites)
+    s->precon_user = nullptr;
     s->d_prec = s->d_ones;
     return MK_OK;
 }

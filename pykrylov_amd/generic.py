@@ -97,6 +97,17 @@ class KrylovMethod(object):
         if diag is not None and not callable(diag):
             n = self.op.shape[0]
             return as_f64_vector(diag, getattr(self.op, 'local_size', None) or n, 'precon.diag')
+        # * a device matrix (CsrOperator -- e.g. the inverted diagonal blocks of `tools.block_jacobi`) or a block
+        #   operator of device matrices is applied ON the device, as a product at the same sites
+        from .linop import CsrOperator
+        dev = precon if isinstance(precon, CsrOperator) else None
+        if dev is None and hasattr(precon, '_device_view'):
+            dev = precon._device_view()
+        if dev is not None and getattr(dev, 'local_size', None) is None:
+            nloc = getattr(self.op, 'local_size', None) or self.op.shape[0]
+            if dev.shape != (nloc, nloc):
+                raise ValueError('%s: precon has shape %s, expected %s' % (self.__class__.__name__, dev.shape, (nloc, nloc)))
+            return DevicePrecon(precon, dev)
         if not hasattr(precon, '__mul__') and not callable(precon):
             raise TypeError('%s: precon must support `precon * vector`; got %r'
                             % (self.__class__.__name__, type(precon).__name__))
@@ -107,6 +118,17 @@ class KrylovMethod(object):
 
     def _logging(self):
         return self.logger is not null_log and self.logger.isEnabledFor(logging.INFO)
+
+
+class DevicePrecon(object):
+    """A preconditioner that is itself a device operator (a CsrOperator, or a block operator with a device view): the
+    loop evaluates ``precon * r`` as a product on the device (mk_solver_set_precon_csr) -- no host round trip."""
+
+    def __init__(self, precon, dev):
+        self.precon, self.dev = precon, dev
+
+    def apply(self, r):
+        return self.dev * r
 
 
 class HostPrecon(object):
@@ -153,6 +175,15 @@ class DeviceRun(object):
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.mk_solver_create(op.handle, ctypes.byref(p), ctypes.byref(self.handle)))
         self.host_precon = None
+        self.device_precon = None
+        if isinstance(precon_diag, DevicePrecon):
+            self.device_precon, precon_diag = precon_diag, None
+            try:
+                _lib.check(self.lib.mk_solver_set_precon_csr(self.handle, self.device_precon.dev.handle))
+            except Exception:
+                self.lib.mk_solver_destroy(self.handle)      # (no handle may outlive a failed constructor)
+                self.handle = ctypes.c_void_p()
+                raise
         if isinstance(precon_diag, HostPrecon):
             hp, self.host_precon, precon_diag = precon_diag, precon_diag, None
 
@@ -170,7 +201,12 @@ class DeviceRun(object):
                         hp.error = exc
                     return 1
             self._precon_cb = _lib.PRECON_FN(call)          # keep the thunk alive
-            _lib.check(self.lib.mk_solver_set_precon_callback(self.handle, self._precon_cb, None))
+            try:
+                _lib.check(self.lib.mk_solver_set_precon_callback(self.handle, self._precon_cb, None))
+            except Exception:
+                self.lib.mk_solver_destroy(self.handle)      # (no handle may outlive a failed constructor)
+                self.handle = ctypes.c_void_p()
+                raise
         if precon_diag is not None:
             self.d_prec = precon_diag if isinstance(precon_diag, _lib.DeviceArray) else \
                 _lib.DeviceArray.from_numpy(as_f64_vector(precon_diag, n, 'precon.diag'))
