@@ -126,6 +126,13 @@ int mk_csr_compose(const mk_csr *A, int32_t nops, const mk_rowop *ops, mk_csr **
 int mk_csr_create_sum(const mk_csr *A, const mk_csr *B, int sign, mk_csr **out);
 int mk_csr_create_product(const mk_csr *A, const mk_csr *B, mk_csr **out);
 
+/* Restriction of a device matrix to the rows `rows` and columns `cols` (host index arrays, copied), as one device
+ * operator: reference ReducedLinearOperator / SymmetricallyReducedLinearOperator (linop/linop.py:560-623), evaluated
+ * the same way -- `z = 0; z[cols] = x; y = (A z)[rows]` -- with scatter, product and gather on the device.  `cols` must
+ * not repeat an index.  A is borrowed (see mk_csr_create_sum). */
+int mk_csr_create_reduced(const mk_csr *A, int64_t nrows, const int32_t *rows, int64_t ncols, const int32_t *cols,
+                          mk_csr **out);
+
 /* A grid of device matrices as ONE operator (reference linop/blkop.py:8-152 BlockLinearOperator, :154-257
  * BlockDiagonalLinearOperator): `blocks` lists nbr x nbc handles row by row (NULL = zero block), block (i, j) being
  * heights[i] x widths[j].  A product evaluates every block product completely and adds the results to the block row's

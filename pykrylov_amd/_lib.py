@@ -75,6 +75,7 @@ PROTOTYPES = {
     "mk_csr_destroy": (ctypes.c_int, [c_vp]),
     "mk_csr_create_sum": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, P(c_vp)]),
     "mk_csr_create_product": (ctypes.c_int, [c_vp, c_vp, P(c_vp)]),
+    "mk_csr_create_reduced": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, P(c_vp)]),
     "mk_csr_create_block": (ctypes.c_int, [c_i32, c_i32, P(c_vp), P(c_i64), P(c_i64), P(c_vp)]),
     "mk_csr_create_callback": (ctypes.c_int, [c_i64, c_i64, MATVEC_FN, c_vp, ctypes.c_int, P(c_vp)]),
     "mk_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),

@@ -369,6 +369,54 @@ int mk_host_product(const mk_csr *A, hipStream_t st) {
     return MK_OK;
 }
 
+// Restriction of a device matrix to rows `rows` and columns `cols` (reference ReducedLinearOperator, linop.py:560-587:
+// `z = zeros(n); z[col_indices] = x; return (op * z)[row_indices]`).  `cols` must not repeat an index (the reference's
+// NumPy assignment would keep the last one; a parallel scatter has no "last").
+extern "C" int mk_csr_create_reduced(const mk_csr *A, int64_t nrows, const int32_t *rows, int64_t ncols,
+                                     const int32_t *cols, mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A && out && nrows >= 0 && ncols >= 0 && (nrows == 0 || rows) && (ncols == 0 || cols));
+    if (!A->is_plain())
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_create_reduced: the operand must be a device matrix, with or without a "
+                                           "row program (not a composite, matrix-free or partitioned operator)");
+    for (int64_t i = 0; i < nrows; ++i) MK_ARG(rows[i] >= 0 && rows[i] < A->nrows);
+    for (int64_t j = 0; j < ncols; ++j) MK_ARG(cols[j] >= 0 && cols[j] < A->ncols);
+    mk_csr *C = new mk_csr();
+    MkReduced *R = new MkReduced();
+    C->nrows = nrows;
+    C->ncols = ncols;
+    C->nnz = A->nnz;
+    C->ntiles = (nrows + MK_ROWS_PER_TILE - 1) / MK_ROWS_PER_TILE;
+    C->comp_kind = 5;
+    C->comp_a = A;
+    C->red = R;
+    C->plan.built = true;
+    hipStream_t st = mk_ctx().stream;
+    auto bytes = [](int64_t n, size_t w) { return w * (size_t)(n > 0 ? n : 1) + 16; };
+    bool ok = hipMalloc((void **)&R->d_rows, bytes(nrows, 4)) == hipSuccess &&
+              hipMalloc((void **)&R->d_cols, bytes(ncols, 4)) == hipSuccess &&
+              hipMalloc((void **)&R->d_z, bytes(A->ncols, 8)) == hipSuccess &&
+              hipMalloc((void **)&R->d_t, bytes(A->nrows, 8)) == hipSuccess &&
+              hipMalloc((void **)&C->d_comp_tmp, bytes(nrows, 8)) == hipSuccess;
+    if (ok && nrows) ok = hipMemcpyAsync(R->d_rows, rows, 4 * (size_t)nrows, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok && ncols) ok = hipMemcpyAsync(R->d_cols, cols, 4 * (size_t)ncols, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(R->d_t, 0, bytes(A->nrows, 8), st) == hipSuccess &&
+                 hipMemsetAsync(C->d_comp_tmp, 0, bytes(nrows, 8), st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (!ok) {
+        hipFree(R->d_rows);
+        hipFree(R->d_cols);
+        hipFree(R->d_z);
+        hipFree(R->d_t);
+        hipFree(C->d_comp_tmp);
+        delete R;
+        delete C;
+        return mk_fail(MK_ERR_HIP, "mk_csr_create_reduced: allocation failed");
+    }
+    A->dependents += 1;
+    *out = C;
+    return MK_OK;
+}
+
 // an operand loses one dependent; if its owner has destroyed it in the meantime, it goes now
 static void mk_release_operand(const mk_csr *B) {
     if (!B) return;
@@ -393,6 +441,13 @@ extern "C" int mk_csr_destroy(mk_csr *A) {
         hipFree(A->d_comp_tmp);
         const mk_csr *a = A->comp_a, *b = A->comp_b;
         MkBlockGrid *G = A->grid;
+        if (A->red) {
+            hipFree(A->red->d_rows);
+            hipFree(A->red->d_cols);
+            hipFree(A->red->d_z);
+            hipFree(A->red->d_t);
+            delete A->red;
+        }
         delete A;
         mk_release_operand(a);
         mk_release_operand(b);

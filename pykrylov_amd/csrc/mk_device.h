@@ -115,7 +115,7 @@ static inline int mk_stream_nt(const mk_csr *A) {
     return env ? atoi(env) : 0;
 }
 static inline int mk_tile_map(const mk_csr *A) {
-    if (A->comp_kind == 4) return 0;
+    if (A->comp_kind >= 4) return 0;
     if (A->comp_kind) return mk_tile_map(A->comp_kind == 3 ? A->comp_a : A->comp_b);
     if (A->host_fn) return 0;
     static const char *env = getenv("MK_SPMV_MAP");
@@ -144,7 +144,7 @@ int mk_host_product(const mk_csr *A, hipStream_t st);   // mk_core.hip: D2H, hos
 // kernel (fmt 4) ingests so little per tile that it is bound by the latency of its window copies: 7 per CU
 // (512^3: 1024 / 1536 / 1792 workgroups -> 1.26 / 1.01 / 0.91 ms).
 static inline int mk_grid_spmv_for(const mk_csr *A) {
-    if (A->comp_kind == 4) return mk_grid_spmv(A->ntiles);   // (the final launch walks the accumulated rows)
+    if (A->comp_kind >= 4) return mk_grid_spmv(A->ntiles);   // (the final launch walks the accumulated rows)
     if (A->comp_kind) return mk_grid_spmv_for(A->comp_kind == 3 ? A->comp_a : A->comp_b);   // the final launch's matrix
     int g = mk_grid_spmv(A->ntiles);
     if (getenv("MK_GRID_SPMV") || A->host_fn) return g;
@@ -624,6 +624,16 @@ struct MkPartialOf {
     __device__ void row(int64_t r, double s, double *) { ysum[r] = s; }
 };
 
+// Reduced operators (mk_csr_create_reduced): z = 0 ; z[col_indices] = x   and   y = t[row_indices]  (linop.py:566-575)
+static __global__ __launch_bounds__(MK_BLOCK) void mk_scatter_kernel(int64_t cnt, const int32_t *__restrict__ idx,
+                                                                    const double *__restrict__ x, double *__restrict__ z) {
+    for (int64_t k = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * MK_BLOCK) z[idx[k]] = x[k];
+}
+static __global__ __launch_bounds__(MK_BLOCK) void mk_gather_kernel(int64_t cnt, const int32_t *__restrict__ idx,
+                                                                   const double *__restrict__ t, double *__restrict__ y) {
+    for (int64_t k = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * MK_BLOCK) y[k] = t[idx[k]];
+}
+
 // Block operators (mk_csr_create_block): a block's finished row sums are added to the block row's accumulator,
 // `y_i += B_ij * x_j` (blkop.py:94); the first block of a row adds to the +0.0 the reference's np.zeros holds.
 template <class Epi>
@@ -668,6 +678,27 @@ struct MkNoXin : MkWrapBase<Epi> {   // the outer product of `A*(B*x)`: its inpu
 template <class Epi, class Gate, class HaltSrc>
 static inline void mk_spmv_launch_blocks(const mk_csr *A, int grid, hipStream_t st, const double *x, const Epi &epi,
                                          const Gate &gate, HaltSrc &&next, double *partials) {
+    if (A->comp_kind == 5) {
+        // Restriction of a device matrix: scatter x into a zero vector of the base's width, the base's complete product
+        // (gate with its side effects; the epilogue's on-the-fly scaling applies to the scattered entries), gather the
+        // chosen rows, and feed them to the real epilogue as a matrix-free operator's result is.
+        const mk_csr *B = A->comp_a;
+        const MkReduced &R = *A->red;
+        auto blocks_for = [](int64_t cnt) { int64_t g = (cnt + MK_BLOCK - 1) / MK_BLOCK; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); };
+        hipMemsetAsync(R.d_z, 0, sizeof(double) * (size_t)(B->ncols > 0 ? B->ncols : 1), st);
+        hipLaunchKernelGGL(mk_scatter_kernel, dim3(blocks_for(A->ncols)), dim3(MK_BLOCK), 0, st, A->ncols, R.d_cols, x, R.d_z);
+        MkCsrView v1 = mk_view(B);
+        v1.part = 1;
+        mk_spmv_launch_view(v1, mk_grid_spmv_for(B), st, R.d_z, MkPartialOf<Epi>{epi, R.d_t}, gate, next(), partials);
+        hipLaunchKernelGGL(mk_gather_kernel, dim3(blocks_for(A->nrows)), dim3(MK_BLOCK), 0, st, A->nrows, R.d_rows, R.d_t,
+                           A->d_comp_tmp);
+        MkCsrView v = mk_view(A);
+        v.cb_mode = 2;
+        v.y_ext = A->d_comp_tmp;
+        v.part = 2;
+        mk_spmv_launch_view(v, grid, st, x, epi, gate, next(), partials);
+        return;
+    }
     if (A->comp_kind == 4) {
         // Grid of device matrices: one launch per block into the rows' accumulators (the first launch evaluates the
         // gate with its side effects, the others repeat its decision), then the accumulated rows go through the real

@@ -133,6 +133,13 @@ struct MkBlockGrid {
     double *d_xtmp = nullptr;                  // aligned copy of an x slice that starts at an odd offset
 };
 
+// restriction of a device matrix to chosen rows and columns (mk_csr_create_reduced; reference linop/linop.py:560-587)
+struct MkReduced {
+    int32_t *d_rows = nullptr, *d_cols = nullptr;   // row_indices / col_indices on the device
+    double *d_z = nullptr;                           // x scattered into a zero vector of the base's width
+    double *d_t = nullptr;                           // the base's product
+};
+
 struct mk_csr {
     int64_t nrows = 0, ncols = 0, nnz = 0;
     int32_t *d_indptr = nullptr;
@@ -148,7 +155,8 @@ struct mk_csr {
     int want_map = -1, want_stripe = 0, want_plane = 0;   // mk_csr_set_tile_order: -1 = library default
     int want_nt = -1;              // mk_csr_set_tile_order: non-temporal loads of the streamed matrix data (-1 = default)
     // sum / difference / product of two device matrices (mk_csr_create_sum / _product): no arrays of its own
-    int comp_kind = 0;             // 0 none, 1 A + B, 2 A - B, 3 A * B, 4 block grid
+    int comp_kind = 0;             // 0 none, 1 A + B, 2 A - B, 3 A * B, 4 block grid, 5 reduced (comp_a restricted)
+    MkReduced *red = nullptr;      // comp_kind 5
     const mk_csr *comp_a = nullptr, *comp_b = nullptr;
     MkBlockGrid *grid = nullptr;   // comp_kind 4
     // operands of composites are borrowed: they count their dependents, and a matrix destroyed while composites still

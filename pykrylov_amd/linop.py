@@ -377,7 +377,11 @@ class ZeroOperator(LinearOperator):
 
 
 def ReducedLinearOperator(op, row_indices, col_indices):
-    "Restriction of `op` to the given rows and columns (linop.py:560-587)."
+    """Restriction of `op` to the given rows and columns (linop.py:560-587).  Of a device matrix: a device operator
+    (`_ReducedCsrOperator`, scatter / product / gather on the GPU), accepted by the device solvers as it is."""
+    dev = _ReducedCsrOperator.build(op, row_indices, col_indices, False) if isinstance(op, CsrOperator) else None
+    if dev is not None:
+        return dev
     nargin, nargout = len(col_indices), len(row_indices)
     m, n = op.shape
 
@@ -395,7 +399,10 @@ def ReducedLinearOperator(op, row_indices, col_indices):
 
 
 def SymmetricallyReducedLinearOperator(op, indices):
-    "Restriction of `op` to the same rows and columns (linop.py:590-623)."
+    "Restriction of `op` to the same rows and columns (linop.py:590-623); of a device matrix: a device operator."
+    dev = _ReducedCsrOperator.build(op, indices, indices, bool(op.symmetric)) if isinstance(op, CsrOperator) else None
+    if dev is not None:
+        return dev
     nargin = len(indices)
     m, n = op.shape
 
@@ -722,6 +729,65 @@ class _PairCsrOperator(CsrOperator):
 
     def to_csr_arrays(self):
         raise NotImplementedError('a device sum / product has no matrix of its own; use its operands')
+
+
+class _ReducedCsrOperator(CsrOperator):
+    """`ReducedLinearOperator` of a device matrix as ONE device operator (mk_csr_create_reduced): z = 0, z[cols] = x,
+    y = (A z)[rows] with every step on the device.  Products are counted on this operator and on the matrix it
+    restricts, as the reference's closure does (it evaluates `op * z`)."""
+
+    @classmethod
+    def build(cls, base, row_indices, col_indices, symmetric):
+        rows = np.ascontiguousarray(np.asarray(row_indices), dtype=np.int64).ravel()
+        cols = np.ascontiguousarray(np.asarray(col_indices), dtype=np.int64).ravel()
+        if not base._pair_ok() or len(np.unique(cols)) != len(cols):
+            return None                                       # (repeated column indices: NumPy keeps the last -- host)
+        m, n = base.shape
+        if (rows.size and (rows.min() < 0 or rows.max() >= m)) or (cols.size and (cols.min() < 0 or cols.max() >= n)):
+            return None                                       # (negative / out-of-range indices: NumPy semantics on the host)
+        r32, c32 = rows.astype(np.int32), cols.astype(np.int32)
+        h = ctypes.c_void_p()
+        if _lib.init().mk_csr_create_reduced(base.handle, r32.size, r32.ctypes.data, c32.size, c32.ctypes.data,
+                                             ctypes.byref(h)) != 0:
+            return None
+        self = cls.from_handle(h.value, symmetric=symmetric)
+        self._parts = (base, rows, cols)
+        return self
+
+    def _pair_ok(self):
+        return False
+
+    def _compose(self, steps, diag_bufs=()):
+        return None
+
+    def _get_count(self):
+        return self.__dict__.get('_count', 0)
+
+    def _set_count(self, v):
+        delta = v - self.__dict__.get('_count', 0)
+        self.__dict__['_count'] = v
+        parts = self.__dict__.get('_parts')
+        if parts is not None and delta:
+            parts[0]._nMatvec += delta
+
+    _nMatvec = property(_get_count, _set_count)
+
+    @property
+    def T(self):
+        if self.symmetric:
+            return self
+        if self._T_cache is None:
+            base, rows, cols = self._parts
+            t = ReducedLinearOperator(base.T, cols, rows)     # (linop.py:577-580: z[rows] = x ; (op.T * z)[cols])
+            if isinstance(t, _ReducedCsrOperator):
+                t._T_cache = self
+            self._T_cache = t
+        return self._T_cache
+
+    H = T
+
+    def to_csr_arrays(self):
+        raise NotImplementedError('a reduced device operator has no matrix of its own; slice the base matrix')
 
 
 class _BlockCsrOperator(CsrOperator):
