@@ -52,7 +52,7 @@ def test_partitioned_solvers_on_one_gpu(nranks):
     assert out["cg3d/halo"]["halo"] in (576, 1152)              # one or two neighbour planes of 24 x 24
 
 
-@pytest.mark.parametrize("launcher", ["self", "torchrun", "rccl-fallback"])
+@pytest.mark.parametrize("launcher", ["self", "torchrun", "rccl-fallback", "self-varcoef"])
 def test_bench_two_rank_path_smoke(launcher):
     """bench.py's N > 1 branch (per-rank matrix generation, gloo bootstrap, barrier / max-over-ranks timing, both
     exchange modes, comm timings, JSON line) with two ranks on GPU 0 over the host-staged transport: a smoke test of
@@ -63,6 +63,9 @@ def test_bench_two_rank_path_smoke(launcher):
         env.pop(k, None)
     args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--transport", "host",
             "--workload", "poisson3d-64", "--spmv-launches", "3"]
+    if launcher == "self-varcoef":                          # the default line's operator family, partitioned
+        args[args.index("poisson3d-64")] = "poisson3d-64-varcoef"
+        launcher = "self"
     if launcher == "rccl-fallback":
         # RCCL requested with both ranks on GPU 0: ncclCommInitRank refuses, every rank falls back to the host-staged
         # transport and the line says so (a broken RCCL setup on a multi-GPU box must not cost the whole line)
@@ -82,4 +85,6 @@ def test_bench_two_rank_path_smoke(launcher):
     assert set(ex) == {"halo", "allgather"} and ex["allgather"]["value"] > 0
     assert len(ex["halo"]["comm"]["per_rank"]) == 2 and ex["halo"]["comm"]["per_rank"][1]["exchange_alone_us"] > 0
     assert "host-staged gloo" in line["config"]["parallelism"]
+    # the line says what carried the collectives: a host-staged fallback can never pass for an RCCL measurement
+    assert line["transport"] == {"kind": "host-staged", "rccl_ranks_seen": 0, "halo_communicator_split": False}
     assert ("RCCL communicator unavailable" in line["config"]["parallelism"]) == (launcher == "rccl-fallback")
