@@ -814,40 +814,51 @@ __global__ __launch_bounds__(MK_BLOCK) void tr_sort_segments(int64_t ncols, cons
 
 constexpr int32_t MK_TR_DEVICE_MAX_COLUMN = 2048;     // longest column the device path sorts (one lane, insertion sort)
 
+// (a failure after B exists frees it -- and the cursor array -- before returning: ADVICE r2)
+#define MK_TR(expr)                                                                                \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            hipFree(cursor);                                                                       \
+            mk_csr_destroy(B);                                                                     \
+            return mk_fail(MK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                          \
+    } while (0)
 extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
     MK_REQUIRE_INIT();
     MK_ARG(A && out);
     if (A->comp_kind || A->host_fn)
         return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_transpose: the operand has no matrix of its own; transpose its parts");
     mk_csr *B = nullptr;
+    int32_t *cursor = nullptr;
     int rc = mk_csr_alloc(A->ncols, A->nrows, A->nnz, &B);
     if (rc != MK_OK) return rc;
     hipStream_t st = mk_ctx().stream;
     const size_t pbytes = sizeof(int32_t) * (size_t)(A->ncols + 1);
-    MK_HIP(hipMemsetAsync(B->d_indptr, 0, pbytes, st));
+    MK_TR(hipMemsetAsync(B->d_indptr, 0, pbytes, st));
     int g1 = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
     g1 = g1 < 1 ? 1 : (g1 > 65536 ? 65536 : g1);
     hipLaunchKernelGGL(tr_count, dim3(g1), dim3(MK_BLOCK), 0, st, A->nnz, A->d_indices, B->d_indptr);
     // exclusive scan of the column counts on the host (one-off, ncols ints)
     std::vector<int32_t> h((size_t)A->ncols + 1);
-    MK_HIP(hipMemcpyAsync(h.data(), B->d_indptr, pbytes, hipMemcpyDeviceToHost, st));
-    MK_HIP(hipStreamSynchronize(st));
+    MK_TR(hipMemcpyAsync(h.data(), B->d_indptr, pbytes, hipMemcpyDeviceToHost, st));
+    MK_TR(hipStreamSynchronize(st));
     int32_t longest = 0;
     for (int64_t c = 0; c < A->ncols; ++c) {
         longest = h[c + 1] > longest ? h[c + 1] : longest;
         h[c + 1] += h[c];
     }
-    MK_HIP(hipMemcpyAsync(B->d_indptr, h.data(), pbytes, hipMemcpyHostToDevice, st));
+    MK_TR(hipMemcpyAsync(B->d_indptr, h.data(), pbytes, hipMemcpyHostToDevice, st));
     if (longest > MK_TR_DEVICE_MAX_COLUMN) {
         // A column this long (dense columns of least-squares / LP matrices) would make the per-segment insertion
         // sort below quadratic on ONE lane.  Such matrices are transposed by a stable counting sort on the host:
         // rows are visited in ascending order, so every transposed row comes out sorted by original row.
         std::vector<int32_t> ip((size_t)A->nrows + 1), ix((size_t)A->nnz), tix((size_t)A->nnz);
         std::vector<double> dv((size_t)A->nnz), tdv((size_t)A->nnz);
-        MK_HIP(hipMemcpyAsync(ip.data(), A->d_indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost, st));
-        MK_HIP(hipMemcpyAsync(ix.data(), A->d_indices, sizeof(int32_t) * ix.size(), hipMemcpyDeviceToHost, st));
-        MK_HIP(hipMemcpyAsync(dv.data(), A->d_data, sizeof(double) * dv.size(), hipMemcpyDeviceToHost, st));
-        MK_HIP(hipStreamSynchronize(st));
+        MK_TR(hipMemcpyAsync(ip.data(), A->d_indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost, st));
+        MK_TR(hipMemcpyAsync(ix.data(), A->d_indices, sizeof(int32_t) * ix.size(), hipMemcpyDeviceToHost, st));
+        MK_TR(hipMemcpyAsync(dv.data(), A->d_data, sizeof(double) * dv.size(), hipMemcpyDeviceToHost, st));
+        MK_TR(hipStreamSynchronize(st));
         std::vector<int32_t> cur(h.begin(), h.end() - 1);
         for (int64_t r = 0; r < A->nrows; ++r)
             for (int32_t j = ip[r]; j < ip[r + 1]; ++j) {
@@ -855,17 +866,16 @@ extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
                 tix[dst] = (int32_t)r;
                 tdv[dst] = dv[j];
             }
-        MK_HIP(hipMemcpyAsync(B->d_indices, tix.data(), sizeof(int32_t) * tix.size(), hipMemcpyHostToDevice, st));
-        MK_HIP(hipMemcpyAsync(B->d_data, tdv.data(), sizeof(double) * tdv.size(), hipMemcpyHostToDevice, st));
-        MK_HIP(hipStreamSynchronize(st));
+        MK_TR(hipMemcpyAsync(B->d_indices, tix.data(), sizeof(int32_t) * tix.size(), hipMemcpyHostToDevice, st));
+        MK_TR(hipMemcpyAsync(B->d_data, tdv.data(), sizeof(double) * tdv.size(), hipMemcpyHostToDevice, st));
+        MK_TR(hipStreamSynchronize(st));
         B->nops = A->nops;
         for (int k = 0; k < A->nops; ++k) B->ops[k] = A->ops[k];
         *out = B;
         return MK_OK;
     }
-    int32_t *cursor = nullptr;
-    MK_HIP(hipMalloc((void **)&cursor, pbytes));
-    MK_HIP(hipMemcpyAsync(cursor, h.data(), pbytes, hipMemcpyHostToDevice, st));
+    MK_TR(hipMalloc((void **)&cursor, pbytes));
+    MK_TR(hipMemcpyAsync(cursor, h.data(), pbytes, hipMemcpyHostToDevice, st));
     int g2 = (int)((A->nrows + MK_BLOCK - 1) / MK_BLOCK);
     g2 = g2 < 1 ? 1 : (g2 > 65536 ? 65536 : g2);
     hipLaunchKernelGGL(tr_scatter, dim3(g2), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data,
@@ -874,9 +884,9 @@ extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
     g3 = g3 < 1 ? 1 : (g3 > 65536 ? 65536 : g3);
     hipLaunchKernelGGL(tr_sort_segments, dim3(g3), dim3(MK_BLOCK), 0, st, A->ncols, B->d_indptr, B->d_indices,
                        B->d_data);
-    MK_HIP(hipGetLastError());
-    MK_HIP(hipStreamSynchronize(st));
-    MK_HIP(hipFree(cursor));
+    MK_TR(hipGetLastError());
+    MK_TR(hipStreamSynchronize(st));
+    MK_TR(hipFree(cursor));
     // (alpha A + D)^T = alpha A^T + D: the row program of a composed operator carries over unchanged
     B->nops = A->nops;
     for (int k = 0; k < A->nops; ++k) B->ops[k] = A->ops[k];
