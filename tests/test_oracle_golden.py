@@ -378,3 +378,67 @@ def test_lls_diagonal_preconditioners(golden, solver, btag, ptag):
         assert out[name] == d[k + name].item(), name
     assert same(out["trace"], d[k + "trace"])
     assert same(out["x"], d[k + "x"])
+
+
+# ------------------------------------------------------------------ round 3: reference-run fixtures for the new operator kinds
+def test_round3_matrix_preconditioners_match_reference(golden):
+    """`precon * r` with a MATRIX (the inverted 4 x 4 diagonal blocks) in all six solvers: the oracle reproduces the
+    reference's counts, reduction traces and iterates bit for bit (tests/golden/make_golden_r3.py)."""
+    d = golden("round3_ops.npz")
+    V, MV = csr_from(d, "pc_A_"), csr_from(d, "pc_M_")
+    rhs = d["pc_rhs"]
+    out = kr.cg(V, rhs, precon=MV.matvec, matvec_max=60)
+    assert out["nMatvec"] == int(d["pc_cg_nMatvec"]) and same(out["residHistory"], d["pc_cg_hist"])
+    assert same(out["trace"], d["pc_cg_trace"]) and same(out["x"], d["pc_cg_x"])
+    out = kr.minres(V, rhs, precon=MV.matvec, check=False, etol=0.0, rtol=1e-10)
+    assert (out["istop"], out["itn"]) == (int(d["pc_minres_istop"]), int(d["pc_minres_itn"]))
+    assert same(out["residHistory"], d["pc_minres_hist"]) and same(out["trace"], d["pc_minres_trace"])
+    assert same(out["x"], d["pc_minres_x"])
+    out = kr.symmlq(V, rhs, precon=MV.matvec)
+    assert out["nMatvec"] == int(d["pc_symmlq_nMatvec"]) and same(out["trace"], d["pc_symmlq_trace"])
+    assert same(out["x"], d["pc_symmlq_x"]) and out["residNorm"] == float(d["pc_symmlq_residNorm"])
+    W, MW = csr_from(d, "pn_A_"), csr_from(d, "pn_M_")
+    for solver in ("bicgstab", "cgs", "tfqmr"):
+        out = getattr(kr, solver)(W, d["pn_rhs"], reltol=1e-10, matvec_max=400, precon=MW.matvec)
+        k = "pn_%s_" % solver
+        assert out["nMatvec"] == int(d[k + "nMatvec"]) and same(out["trace"], d[k + "trace"]), solver
+        assert same(out["x"], d[k + "x"]) and same(out["residNorm"], d[k + "residNorm"]), solver
+        assert bool(out["converged"]) == bool(d[k + "converged"])
+
+
+def test_round3_variable_coefficient_cg_matches_reference(golden):
+    d = golden("round3_ops.npz")
+    C = csr_from(d, "vc_A_")
+    mine = csr_ref.poisson3d_varcoef(24, 16, 8, seed=7)          # (the fixture's matrix IS this builder's output)
+    assert same(mine.indptr, C.indptr) and same(mine.indices, C.indices) and same(mine.data, C.data)
+    out = kr.cg(C, d["vc_rhs"])
+    assert out["nMatvec"] == int(d["vc_cg_nMatvec"]) and bool(d["vc_cg_converged"])
+    assert same(out["residHistory"], d["vc_cg_hist"]) and same(out["trace"], d["vc_cg_trace"]) and same(out["x"], d["vc_cg_x"])
+
+
+def test_round3_reduced_and_block_operators_host_composition(golden):
+    """The package's HOST compositions (what operators without a device form use) against the reference's results:
+    ReducedLinearOperator / SymmetricallyReducedLinearOperator (linop.py:560-623) and a saddle-point block operator
+    of sparse blocks (blkop.py:8-152), bit for bit."""
+    from pykrylov_amd import DiagonalOperator, LinearOperator, ReducedLinearOperator, SymmetricallyReducedLinearOperator
+    from pykrylov_amd.blkop import BlockLinearOperator
+    d = golden("round3_ops.npz")
+
+    def host_op(R, symmetric=False):
+        Rt = R.transpose()
+        return LinearOperator(R.shape[1], R.shape[0], matvec=R.matvec, matvec_transp=Rt.matvec, symmetric=symmetric)
+    R = csr_from(d, "red_A_")
+    red = ReducedLinearOperator(host_op(R), d["red_rows"], d["red_cols"])
+    assert red.shape == tuple(d["red_shape"])
+    assert same(red * d["red_x"], d["red_y"]) and same(red.T * d["red_u"], d["red_yt"])
+    P = csr_from(d, "sred_A_")
+    sred = SymmetricallyReducedLinearOperator(host_op(P, True), d["sred_idx"])
+    assert same(sred * d["sred_x"], d["sred_y"]) and bool(sred.symmetric) == bool(d["sred_sym"][0])
+    A, B = csr_from(d, "sp_A_"), csr_from(d, "sp_B_")
+    K = BlockLinearOperator([[host_op(A, True), host_op(B).T], [DiagonalOperator(d["sp_d"])]], symmetric=True)
+    assert same(K * d["sp_x"], d["sp_Kx"]) and same(K * np.ones(K.shape[1]), d["sp_rhs"])
+    call = lambda self, v: K * v                                     # noqa: E731  (the oracle calls `A(v)`)
+    out = kr.minres(type("Op", (), {"shape": K.shape, "matvec": call, "__call__": call})(), d["sp_rhs"], check=False,
+                    etol=0.0, rtol=1e-10)
+    assert (out["istop"], out["itn"]) == (int(d["sp_minres_istop"]), int(d["sp_minres_itn"]))
+    assert same(out["residHistory"], d["sp_minres_hist"]) and same(out["x"], d["sp_minres_x"])
