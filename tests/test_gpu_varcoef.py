@@ -215,3 +215,39 @@ def test_fuzz_over_grid_shapes():
         assert np.array_equal(op.T * x, A.rmatvec(x)), (mx, my, mz)
         op.free()
     assert 5 in seen
+
+
+def test_fuzz_random_banded_matrices_with_distinct_values():
+    """Random band structures (3 .. 8 offsets, some far, some near, some missing on random row ranges), random sizes with
+    ragged last tiles, rectangular shapes, all-distinct values: whichever format the builder settles on (5 where the
+    rows follow few patterns with little padding, 1 / 0 / 3 otherwise), products and transposed products keep the
+    scalar loop's bits."""
+    from pykrylov_amd import CsrOperator
+    rng = np.random.default_rng(2027)
+    seen = {}
+    for case in range(36):
+        n = int(rng.integers(300, 9000))
+        ncols = n if case % 5 else int(n + rng.integers(-200, 200))
+        k = int(rng.integers(3, 9))
+        near = rng.choice(np.arange(-12, 13), size=min(k, 5), replace=False)
+        far = rng.choice([-1024, -513, -300, -257, 257, 300, 511, 1024, 2000], size=max(0, k - len(near)), replace=False)
+        offs = np.unique(np.concatenate([near, far]))
+        rows, cols = [], []
+        for o in offs:
+            r = np.arange(max(0, -o), min(n, ncols - o))
+            if case % 3 == 0 and len(r) > 600:                       # a hole: the offset is missing on a range of rows
+                lo = int(rng.integers(0, len(r) - 300))
+                r = np.concatenate([r[:lo], r[lo + 300:]])
+            rows.append(r)
+            cols.append(r + o)
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        A = csr_ref.from_coo(rows, cols, rng.standard_normal(len(rows)), (n, ncols))
+        op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
+        f = fmt_info(op)["fmt"]
+        seen[f] = seen.get(f, 0) + 1
+        x = rng.standard_normal(ncols)
+        assert np.array_equal(op * x, A.matvec(x)), (case, n, ncols, offs, f)
+        u = rng.standard_normal(n)
+        assert np.array_equal(op.T * u, A.rmatvec(u)), (case, n, ncols, offs, f)
+        op.free()
+    assert seen.get(5, 0) >= 5, seen
