@@ -15,10 +15,15 @@ op = gallery.poisson3d_varcoef(m) if wl == "varcoef" else gallery.poisson3d(m)
 n = op.shape[0]
 ones = _lib.DeviceArray.from_numpy(np.ones(n))
 rhs = _lib.DeviceArray(n)
-op.spmv_device(ones.ptr, rhs.ptr)
+NO_ITER = bool(os.environ.get("AB_NO_ITER"))      # timing ablations that produce garbage: never let the loop see it
+if NO_ITER:
+    rhs = ones
+else:
+    op.spmv_device(ones.ptr, rhs.ptr)
 run = DeviceRun(op, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=1 << 60, check_curvature=1)
 run.setup()
-run.iterate(20)
+if not NO_ITER:
+    run.iterate(20)
 P = m * m // 256
 variants = [("order2", (2, 0, 0, 0)), ("order2+nt", (2, 0, 0, 1))]
 if True:
@@ -33,6 +38,9 @@ for r in range(rounds):
         avg = ctypes.c_double()
         _lib.check(lib.mk_solver_time_spmv(run.handle, 60, ctypes.byref(avg)))
         res[name].append(avg.value)
+        if NO_ITER:
+            step[name].append(float("nan"))
+            continue
         run.iterate(30)
         step[name].append(run.timing()["iterate_ms"] / 30)
 print("workload %s, %d rounds, medians (min .. max):" % (wl, rounds))
