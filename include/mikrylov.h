@@ -97,6 +97,11 @@ int mk_csr_poisson3d(int64_t nx, int64_t ny, int64_t nz, int64_t row_begin, int6
  * `matvec` brings to linop/linop.py:271-298). */
 int mk_csr_poisson3d_varcoef(int64_t nx, int64_t ny, int64_t nz, uint64_t seed, int64_t row_begin, int64_t row_end,
                              mk_csr **out);
+/* stencil27: the 27-point box stencil on the same grid (HPCG's sparsity; rows of 8 ... 27 entries, columns ascending).
+ * seed == 0: -1.0 off the diagonal, 26.0 on it; seed != 0: harmonic means of the hashed cell field as above, the
+ * diagonal their left-to-right sum over the 26 directions (k itself per missing neighbour).  SPD.  No reference
+ * counterpart beyond "a user's matvec" (linop/linop.py:271-298): the test matrix of the wide storage formats. */
+int mk_csr_stencil27(int64_t nx, int64_t ny, int64_t nz, uint64_t seed, int64_t row_begin, int64_t row_end, mk_csr **out);
 
 /* Operator algebra that stays on the device (linop.py:307-330 `alpha * op`, :375-398 `op + other`, :403-426
  * `op - other`, :400-401 `-op`, with `other` a DiagonalOperator (:473-516), an IdentityOperator (:455-470) or a scalar

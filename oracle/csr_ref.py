@@ -196,6 +196,37 @@ def poisson3d_varcoef(mx, my=None, mz=None, seed=7):
     return from_coo(*[np.concatenate(c) for c in zip(*parts)], shape=(n, n))
 
 
+def stencil27(mx, my=None, mz=None, seed=0):
+    """27-point box stencil, columns ascending.  seed == 0: -1 off the diagonal, 26 on it; otherwise entry (a, b) is
+    minus the harmonic mean of the two cells' coefficients and the diagonal the left-to-right sum, over the 26
+    directions in column order, of that mean -- or of k(a) where the neighbour is missing.  Twin of gen_stencil27
+    (pykrylov_amd/csrc/mk_core.hip; bit-identical arrays)."""
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    n = mx * my * mz
+    idx = np.arange(n, dtype=np.int64)
+    gx, gy, gz = idx % mx, (idx // mx) % my, idx // (mx * my)
+    kc = cell_field(idx, seed) if seed else np.ones(n)
+    diag = np.zeros(n)
+    parts = []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dz == 0 and dy == 0 and dx == 0:
+                    continue
+                ok = ((gz + dz >= 0) & (gz + dz < mz) & (gy + dy >= 0) & (gy + dy < my) & (gx + dx >= 0) & (gx + dx < mx))
+                off = dz * mx * my + dy * mx + dx
+                if seed:
+                    kb = cell_field(np.where(ok, idx + off, idx), seed)
+                    h = np.where(ok, ((2.0 * kc) * kb) / (kc + kb), kc)
+                else:
+                    h = kc
+                diag = diag + h
+                parts.append((idx[ok], idx[ok] + off, -h[ok]))
+    parts.append((idx, idx, diag))
+    return from_coo(*[np.concatenate(c) for c in zip(*parts)], shape=(n, n))
+
+
 def random_diagdom(n, seed=1, k=4):
     """k random off-diagonals per row (duplicates summed,
     accidental diagonal hits dropped), diagonal = sum|offdiag| + 1."""

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "mk_csr_poisson2d": (ctypes.c_int, [c_i64, c_i64, c_i64, P(c_vp)]),
     "mk_csr_poisson3d": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i64, c_i64, P(c_vp)]),
     "mk_csr_poisson3d_varcoef": (ctypes.c_int, [c_i64, c_i64, c_i64, ctypes.c_uint64, c_i64, c_i64, P(c_vp)]),
+    "mk_csr_stencil27": (ctypes.c_int, [c_i64, c_i64, c_i64, ctypes.c_uint64, c_i64, c_i64, P(c_vp)]),
     "mk_csr_set_format": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "mk_csr_format_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i64), P(c_i32), P(c_i32), P(c_i64)]),
     "mk_csr_launch_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),

@@ -773,6 +773,84 @@ extern "C" int mk_csr_poisson3d_varcoef(int64_t nx, int64_t ny, int64_t nz, uint
     return MK_OK;
 }
 
+// 27-point box stencil on an nx x ny x nz grid (every cell coupled to the <= 26 cells of its 3 x 3 x 3 neighbourhood,
+// columns ascending = (dz, dy, dx) lexicographic), the sparsity of HPCG's operator.  seed == 0: constant coefficients --
+// -1.0 off the diagonal, 26.0 on it (HPCG's values).  seed != 0: the variable-coefficient twin of
+// mk_csr_poisson3d_varcoef -- entry (a, b) = -h(a, b), h the harmonic mean of the two cells' hashed coefficients, the
+// diagonal the left-to-right sum over the 26 directions, in column order, of h where the neighbour exists and of k(a)
+// where it does not.  Symmetric bit for bit, weakly diagonally dominant with strict rows on the boundary: SPD.
+// Rows of 8 ... 27 entries: the matrix class of the wide storage formats (mk_format.hip).  NumPy twin: csr_ref.stencil27.
+__host__ __device__ static inline int64_t s27_line(int64_t g, int64_t n) {      // sum over x < g of the cells x - 1 .. x + 1 inside
+    return g + (g > 0 ? g - 1 : 0) + (g < n - 1 ? g : n - 1);
+}
+__host__ __device__ static inline int64_t s27_cnt(int64_t g, int64_t n) { return 1 + (g > 0 ? 1 : 0) + (g < n - 1 ? 1 : 0); }
+__host__ __device__ static inline int64_t s27_prefix(int64_t r, int64_t nx, int64_t ny, int64_t nz) {
+    const int64_t pl = nx * ny;
+    if (r >= pl * nz) return s27_line(nx, nx) * s27_line(ny, ny) * s27_line(nz, nz);
+    const int64_t gx = r % nx, gy = (r / nx) % ny, gz = r / pl;
+    const int64_t SX = s27_line(nx, nx), SY = s27_line(ny, ny);
+    return s27_line(gz, nz) * SY * SX + s27_cnt(gz, nz) * (s27_line(gy, ny) * SX + s27_cnt(gy, ny) * s27_line(gx, nx));
+}
+
+__global__ __launch_bounds__(MK_BLOCK) void gen_stencil27(int64_t nx, int64_t ny, int64_t nz, uint64_t seed, int64_t r_begin,
+                                                          int64_t r_end, int32_t *indptr, int32_t *indices, double *data) {
+    const int64_t pl = nx * ny;
+    const int64_t base = s27_prefix(r_begin, nx, ny, nz);
+    for (int64_t r = r_begin + (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r <= r_end;
+         r += (int64_t)gridDim.x * MK_BLOCK) {
+        int64_t p = s27_prefix(r, nx, ny, nz) - base;
+        indptr[r - r_begin] = (int32_t)p;
+        if (r == r_end) break;
+        const int64_t gx = r % nx, gy = (r / nx) % ny, gz = r / pl;
+        const double kc = seed ? mk_cell_field(r, seed) : 1.0;
+        double diag = 0.0;
+        int64_t pdiag = -1;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const bool self = (dz == 0 && dy == 0 && dx == 0);
+                    const bool have = gz + dz >= 0 && gz + dz < nz && gy + dy >= 0 && gy + dy < ny && gx + dx >= 0 && gx + dx < nx;
+                    const int64_t c = r + dz * pl + dy * nx + dx;
+                    if (self) {
+                        pdiag = p;
+                        indices[p++] = (int32_t)r;
+                        continue;
+                    }
+                    double h = kc;
+                    if (have && seed) {
+                        const double kb = mk_cell_field(c, seed);
+                        h = ((2.0 * kc) * kb) / (kc + kb);
+                    }
+                    diag += h;
+                    if (have) {
+                        indices[p] = (int32_t)c;
+                        data[p++] = -h;
+                    }
+                }
+        data[pdiag] = diag;
+    }
+}
+
+extern "C" int mk_csr_stencil27(int64_t nx, int64_t ny, int64_t nz, uint64_t seed, int64_t row_begin, int64_t row_end,
+                                mk_csr **out) {
+    MK_REQUIRE_INIT();
+    MK_ARG(out != nullptr && nx >= 1 && ny >= 1 && nz >= 1 && row_begin >= 0 && row_begin <= row_end && row_end <= nx * ny * nz);
+    const int64_t nnz = s27_prefix(row_end, nx, ny, nz) - s27_prefix(row_begin, nx, ny, nz);
+    if (nnz > (int64_t)0x7fffffff - MK_CSR_PAD) return mk_fail(MK_ERR_ARG, "mk_csr_stencil27: %lld nonzeros do not fit int32 row pointers", (long long)nnz);
+    mk_csr *A = nullptr;
+    int rc = mk_csr_alloc(row_end - row_begin, nx * ny * nz, nnz, &A);
+    if (rc != MK_OK) return rc;
+    const int64_t rows = row_end - row_begin + 1;
+    int grid = (int)((rows + MK_BLOCK - 1) / MK_BLOCK);
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(gen_stencil27, dim3(grid), dim3(MK_BLOCK), 0, mk_ctx().stream, nx, ny, nz, seed, row_begin, row_end,
+                       A->d_indptr, A->d_indices, A->d_data);
+    MK_HIP(hipGetLastError());
+    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    *out = A;
+    return MK_OK;
+}
+
 // ======================================================================================
 // transpose (K1T support): B = A^T with rows of B sorted by original row index
 // ======================================================================================

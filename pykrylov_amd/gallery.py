@@ -133,6 +133,17 @@ def poisson3d_varcoef(nx, ny=None, nz=None, seed=7):
     return CsrOperator.from_handle(h.value, symmetric=True)
 
 
+def stencil27(nx, ny=None, nz=None, seed=0):
+    """27-point box stencil (HPCG's sparsity), generated in HBM.  seed == 0: -1 / 26 (HPCG's values); otherwise
+    variable coefficients from the hashed cell field of `poisson3d_varcoef`."""
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    lib = _lib.init()
+    h = ctypes.c_void_p()
+    _lib.check(lib.mk_csr_stencil27(nx, ny, nz, seed, 0, nx * ny * nz, ctypes.byref(h)))
+    return CsrOperator.from_handle(h.value, symmetric=True)
+
+
 def random_diagdom(n, seed=1, k=4):
     indptr, indices, data, shape = random_diagdom_csr(n, seed, k)
     return CsrOperator(indptr, indices, data, shape)

@@ -1,0 +1,88 @@
+"""27-point box stencils (HPCG's sparsity; rows of 8 ... 27 entries): the generator against its NumPy twin, and the
+products / solves on whatever storage format the library picks for them -- BIT-identical to the scalar left-to-right
+CSR loop of the oracle, as for every format."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import csr_ref
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 8, 8), (17, 5, 3), (33, 9, 1), (1, 1, 40), (2, 3, 1), (1, 1, 1), (64, 16, 4), (256, 6, 5), (40, 40, 12)]
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_generator_matches_its_numpy_twin(shape, seed):
+    from pykrylov_amd import gallery
+    A = csr_ref.stencil27(*shape, seed=seed)
+    op = gallery.stencil27(*shape, seed=seed)
+    ip, ix, dv = op.to_csr_arrays()
+    assert np.array_equal(ip, A.indptr) and np.array_equal(ix, A.indices)
+    assert np.array_equal(dv.view(np.int64), A.data.view(np.int64))
+    op.free()
+
+
+def test_generator_row_ranges():
+    from pykrylov_amd import CsrOperator, _lib
+    A = csr_ref.stencil27(12, 7, 5, seed=3)
+    lib = _lib.init()
+    for a, b in ((0, 420), (100, 333), (419, 420), (5, 5)):
+        h = ctypes.c_void_p()
+        _lib.check(lib.mk_csr_stencil27(12, 7, 5, 3, a, b, ctypes.byref(h)))
+        op = CsrOperator.from_handle(h.value)
+        ip, ix, dv = op.to_csr_arrays()
+        lo, hi = A.indptr[a], A.indptr[b]
+        assert np.array_equal(ip, A.indptr[a:b + 1] - lo) and np.array_equal(ix, A.indices[lo:hi])
+        assert np.array_equal(dv, A.data[lo:hi])
+        op.free()
+
+
+def test_matrix_is_symmetric_positive_definite():
+    for seed in (0, 5):
+        D = csr_ref.stencil27(5, 4, 3, seed=seed).to_dense()
+        assert np.array_equal(D, D.T) and np.linalg.eigvalsh(D).min() > 0.1
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("fmt", [-1, 0, 1, 2, 4, 5])
+@pytest.mark.parametrize("shape", [(64, 16, 4), (256, 6, 5), (40, 40, 12), (300, 7, 3)])
+def test_products_are_the_scalar_loops_bits(shape, seed, fmt):
+    from pykrylov_amd import _lib, gallery
+    A = csr_ref.stencil27(*shape, seed=seed)
+    op = gallery.stencil27(*shape, seed=seed)
+    _lib.check(op._lib.mk_csr_set_format(op.handle, fmt))
+    rng = np.random.default_rng(shape[0] + seed)
+    for x in (np.ones(A.shape[1]), rng.standard_normal(A.shape[1]), 1e200 * rng.standard_normal(A.shape[1])):
+        with np.errstate(over="ignore", invalid="ignore"):
+            want = A.matvec(x)
+        got = op * x
+        assert np.array_equal(got.view(np.int64), want.view(np.int64))
+    op.free()
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("shape", [(48, 20, 9), (256, 8, 6)])
+def test_cg_on_a_27_point_operator(shape, seed):
+    """Bit for bit the oracle's CG run in the device's summation order, and within 1e-12 of the reference's own."""
+    import pykrylov_amd as pk
+    from oracle import gpu_order, krylov_ref as kr
+    from pykrylov_amd import gallery
+    A = csr_ref.stencil27(*shape, seed=seed)
+    n = A.shape[0]
+    op = gallery.stencil27(*shape, seed=seed)
+    rhs = A.matvec(np.ones(n))
+    s = pk.CG(op)
+    s.solve(rhs, reltol=1e-10)
+    ref = kr.cg(A, rhs, reltol=1e-10, red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], gpu_order.launch_geometry(op))))
+    assert s.converged and s.nMatvec == ref["nMatvec"]
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
+    ref0 = kr.cg(A, rhs, reltol=1e-10)
+    assert s.nMatvec == ref0["nMatvec"]
+    h, h0 = np.array(s.residHistory), ref0["residHistory"]
+    assert np.max(np.abs(h - h0) / np.maximum(h0, 1e-4 * h0[0])) <= 1e-12
+    assert np.linalg.norm(s.x - ref0["x"]) <= 1e-12 * np.linalg.norm(ref0["x"])
+    assert np.linalg.norm(s.x - 1.0) / np.sqrt(n) < 1e-5
+    op.free()
