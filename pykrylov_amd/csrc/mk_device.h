@@ -51,6 +51,8 @@ struct MkCsrView {
                              // 3 plain CSR with the tile resident in LDS and the gathers ordered by column block,
                              // 4 windows + dictionary + one pattern byte per row instead of a word per nonzero,
                              // 5 windows + pattern byte per row + the raw values streamed in tile-sliced ELL order
+                             // 6 / 7 / 8 wide tiles (rows <= 32 entries, <= 32 chunks): slots + values streamed /
+                             // pattern byte + values streamed / pattern byte + dictionary
     int wchunks;             // LDS chunks (128 doubles each) reserved for the x windows of a tile
     int ndict;
     const uint16_t *slots;   // per nonzero: position of its x entry in the tile's LDS window buffer
@@ -66,6 +68,10 @@ struct MkCsrView {
     // fmt 5: the values in tile-sliced ELL order and per tile {start of its block / 256, width} (mk_spmv_fmt5.h)
     const double *sval;
     const int32_t *sdesc;
+    // fmt 6, 7, 8 (mk_spmv_fmtw.h): wmode = fmt - 6; window chunks per wave (4: 16-chunk cover, 8: 32-chunk cover); the
+    // LDS slots in tile-sliced ELL order (fmt 6); sdesc holds FOUR ints per tile {value block, width, slot block, -}
+    int wmode, wper;
+    const uint16_t *sslot;
     int allwin;              // every tile of the matrix has windows (no tile ever takes the gather path)
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
@@ -129,7 +135,7 @@ static inline int mk_tile_map(const mk_csr *A) {
     // runs into the fabric on re-fetched x windows: XCD-contiguous blocks within every step of the grid keep neighbouring
     // tiles' windows in one L2 (512^3: fabric reads 4.4 -> 3.6 GB, 838 -> 790 us)
     const MkPlan *P = mk_csr_plan(A);
-    return (P && (P->fmt == 4 || P->fmt == 5)) ? 2 : 0;
+    return (P && P->fmt >= 4) ? 2 : 0;
 }
 
 constexpr int MK_PROD_LD = MK_BLOCK + 1;             // (product staging buffer of the SpMV kernels, see below)
@@ -162,6 +168,15 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         const int64_t lds = 8 * (top + MK_BLOCK) + (P->fmt == 4 ? 16 : 4) * (int64_t)(P->npat * P->pmax + 4) + 2560;   // + static arrays
         int64_t per_cu = (160 * 1024) / lds;
         per_cu = per_cu > 7 ? 7 : (per_cu < 1 ? 1 : per_cu);
+        cap = 256 * per_cu;
+    }
+    else if (P && P->fmt >= 6) {                             // wide tiles: 3 per CU (168 registers; fmt 8: 7), as many as LDS holds
+        int64_t top = 128 * (int64_t)P->wchunks + 2;
+        if (P->covered != A->ntiles && top < MK_PROD_LDS) top = MK_PROD_LDS;
+        const int64_t lds = 8 * (top + MK_BLOCK) + 4 * (int64_t)((P->fmt >= 7 ? P->npat * P->pmax : 0) + 4) + 4608;   // + static arrays
+        int64_t per_cu = (160 * 1024) / lds;
+        const int64_t top_cu = (P->fmt == 8) ? 7 : 3;
+        per_cu = per_cu > top_cu ? top_cu : (per_cu < 1 ? 1 : per_cu);
         cap = 256 * per_cu;
     }
     else if (P && P->fmt == 2) cap = mk_xcd_chunks(A) ? 1280 : 1024;
@@ -230,6 +245,9 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.sval = P->d_sval;
         v.sdesc = P->d_sdesc;
         v.allwin = (P->covered == A->ntiles) ? 1 : 0;
+        v.wper = P->wide ? 8 : 4;
+        v.wmode = v.fmt >= 6 ? v.fmt - 6 : 0;
+        v.sslot = P->d_sslot;
     }
     return v;
 }
@@ -250,6 +268,8 @@ static inline MkCsrView mk_view_part(const mk_csr *A, int part, int poff2) {
 typedef double mk_d2 __attribute__((ext_vector_type(2)));
 typedef int mk_i2 __attribute__((ext_vector_type(2)));
 typedef int mk_i4 __attribute__((ext_vector_type(4)));
+typedef unsigned mk_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned mk_u4 __attribute__((ext_vector_type(4)));
 
 // Composed operators (mk_csr_compose): the reference evaluates `alpha * op`, `op + D`, `op - D` as one NumPy
 // expression per node on the product vector (linop.py:307-330, :375-426); the same expressions, in the same order,
@@ -489,6 +509,10 @@ __device__ __forceinline__ void mk_load_meta(const MkCsrView &A, int64_t p, int6
 #include "mk_spmv_fmt24.h"
 #include "mk_spmv_fmt3.h"
 #include "mk_spmv_fmt5.h"
+#include "mk_spmv_fmtw.h"
+
+constexpr int MK_FMT_WIDE = 7;                       // template values of the wide kernels (6 = format 5, non-temporal):
+constexpr int MK_FMT_WIDE_DICT = 8;                  // 7 streams values (fmt 6, 7), 8 takes them from the dictionary (fmt 8)
 
 template <int FMT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
@@ -496,6 +520,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     if constexpr (FMT == 0) mk_spmv_tiles_fmt0<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 1) mk_spmv_tiles_fmt1<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 3) mk_spmv_tiles_fmt3<PROG>(A, x, epi, prod, xw, acc);
+    else if constexpr (FMT == MK_FMT_WIDE || FMT == MK_FMT_WIDE_DICT) mk_spmv_tiles_wide<FMT == MK_FMT_WIDE_DICT, PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT >= 5) mk_spmv_tiles_fmt5<PROG, FMT == 6>(A, x, epi, prod, xw, acc);
     else mk_spmv_tiles_fmt24<FMT, PROG>(A, x, epi, prod, xw, acc);
 }
@@ -508,7 +533,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : ((FMT >= 4) ? 7 : 4)) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : (FMT == 7 ? 3 : (FMT >= 4 ? 7 : 4))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
@@ -587,6 +612,16 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         else
             hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 5>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                                halt, partials);
+    } else if (v.fmt >= 6) {                                 // wide tiles: windows + zeros + pattern words
+        size_t wtop = (size_t)(128 * v.wchunks + 2);
+        if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
+        lds = sizeof(double) * (wtop + MK_BLOCK) + 4 * (size_t)((v.fmt >= 7 ? v.npat * v.pmax : 0) + 4);
+        if (v.fmt == 8)
+            hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_WIDE_DICT>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
+                               epi, gate, halt, partials);
+        else
+            hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_WIDE>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi,
+                               gate, halt, partials);
     } else if (v.fmt == 3) {                                 // the tile's values and columns
         lds = (size_t)v.rt_cap * 12;
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 3>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,

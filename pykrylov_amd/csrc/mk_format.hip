@@ -21,7 +21,6 @@
 
 namespace {
 
-constexpr int COVER_CAP = MK_SPMV_TILE;                      // nonzeros of an eligible tile
 constexpr unsigned long long DICT_EMPTY = 0x7ff8dead00c0ffeeULL;
 constexpr int DICT_SLOTS = 512;
 
@@ -44,11 +43,15 @@ __device__ inline void bitonic_sort_i32(int *a, int n2) {
 }
 
 // stats: [0] max chunks of a tile, [1] eligible tiles
+// <16, 2048>: the cover of fmt 1, 2, 4, 5 (tiles the per-nonzero kernels can stage); <32, 8192>: the wide cover of
+// fmt 6, 7, 8 (row-walk kernels only: no staging buffer bounds the tile).  Chunk c of a tile belongs to wave c % 4:
+// wg[(tile * 4 + wave) * (CMAX / 4) + c / 4], half lengths one byte each in wn[(tile * 4 + wave) * (CMAX / 16) + c / 16].
+template <int CMAX, int COVER_CAP>
 __global__ __launch_bounds__(MK_BLOCK) void cover_kernel(const int32_t *__restrict__ ip, const int32_t *__restrict__ ix,
                                                          int64_t nrows, int64_t ntiles, int64_t xlen,
                                                          int32_t *__restrict__ wg, uint32_t *__restrict__ wn,
                                                          uint16_t *__restrict__ sl, int *__restrict__ stats) {
-    constexpr int CMAX = MK_WCHUNKS_MAX;
+    constexpr int CPW = CMAX / 4;
     __shared__ int key[COVER_CAP];
     __shared__ int heads[CMAX + 1];
     __shared__ int wst[CMAX], wof[CMAX];
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(MK_BLOCK) void cover_kernel(const int32_t *__restri
         const int p_lo = ip[r0], p_hi = ip[rend], cnt = p_hi - p_lo;
         __syncthreads();                                     // previous tile's shared state is no longer read
         if (tid < CMAX) wg[tile * CMAX + tid] = 0;
-        if (tid < 4) wn[tile * 4 + tid] = 0;
-        if (cnt <= 0 || p_hi - (p_lo & ~7) > MK_SPMV_TILE) continue;
+        if (tid < CMAX / 4) wn[tile * (CMAX / 4) + tid] = 0;
+        if (cnt <= 0 || p_hi - (p_lo & ~7) > COVER_CAP) continue;
         int n2 = 2;
         while (n2 < cnt) n2 <<= 1;
         for (int i = tid; i < n2; i += MK_BLOCK) key[i] = (i < cnt) ? (ix[p_lo + i] >> 1) : 0x7fffffff;
@@ -101,19 +104,21 @@ __global__ __launch_bounds__(MK_BLOCK) void cover_kernel(const int32_t *__restri
                     }
                     ok = ok && C <= CMAX;                    // (a wider gap may still merge many tiny windows)
                     if (ok) {
-                        unsigned lens[4] = {0, 0, 0, 0};
+                        unsigned lens[4][CPW / 4];
+                        for (int w = 0; w < 4; ++w)
+                            for (int q = 0; q < CPW / 4; ++q) lens[w][q] = 0;
                         for (int k = 0; k < nw; ++k) {
                             const int en = (key[heads[k + 1] - 1] + 1) * 2;
                             for (int c = wof[k] / MK_WCHUNK, g = wst[k]; g < en; ++c, g += MK_WCHUNK) {
                                 const int wv = c & 3, i = c >> 2;
                                 const int half = ((en - g < MK_WCHUNK) ? en - g : MK_WCHUNK) / 2;
-                                wg[tile * CMAX + wv * 4 + i] = g;
-                                lens[wv] |= (unsigned)half << (8 * i);
+                                wg[tile * CMAX + wv * CPW + i] = g;
+                                lens[wv][i >> 2] |= (unsigned)half << (8 * (i & 3));
                             }
                         }
                         for (int w = 0; w < 4; ++w) {
-                            wn[tile * 4 + w] = lens[w];
-                            wg[tile * CMAX + w * 4] |= 1;    // bit 0 of every wave's first start: tile is eligible
+                            for (int q = 0; q < CPW / 4; ++q) wn[(tile * 4 + w) * (CPW / 4) + q] = lens[w][q];
+                            wg[tile * CMAX + w * CPW] |= 1;  // bit 0 of every wave's first start: tile is eligible
                         }
                         atomicMax(&stats[0], C);
                         atomicAdd(&stats[1], 1);
@@ -223,6 +228,7 @@ __global__ __launch_bounds__(MK_BLOCK) void dict_encode(int64_t nnz, const doubl
 // order, written into a table of `pmax` words per pattern and then VERIFIED row by row against the table, so that a
 // hash collision can only make the builder give up, never change a product.
 constexpr int PAT_WORDS = 1024;                              // table capacity in entries (npat * pmax): <= 16 KB of LDS
+constexpr int PAT_WORDS_WIDE = 4096;                         // ... of the wide formats (one 4-byte word per entry: 16 KB)
 
 // (pk == null: a matrix without a value dictionary -- the words are the bare LDS slots, fmt 5)
 __device__ inline int pat_row_words(const int32_t *__restrict__ ip, const uint32_t *__restrict__ pk,
@@ -237,8 +243,10 @@ __device__ inline int pat_row_words(const int32_t *__restrict__ ip, const uint32
     return len;
 }
 
-__device__ inline unsigned long long pat_hash(int len, const uint32_t *w) {
-    unsigned long long h = 0xcbf29ce484222325ULL ^ (unsigned long long)len;
+// (kd: position of the diagonal entry in the row, 255 = none -- part of a pattern's identity: rows of mirror-image
+// boundary tiles can share their relative slots and differ in where the diagonal sits)
+__device__ inline unsigned long long pat_hash(int len, int kd, const uint32_t *w) {
+    unsigned long long h = 0xcbf29ce484222325ULL ^ (unsigned long long)len ^ ((unsigned long long)kd << 8);
     for (int k = 0; k < len; ++k) {
         h ^= (unsigned long long)w[k];
         h *= 0x100000001b3ULL;
@@ -266,10 +274,10 @@ __device__ inline void set_insert(unsigned long long *table, int *state, unsigne
 }
 
 __global__ __launch_bounds__(MK_BLOCK) void pat_maxlen(int64_t nrows, const int32_t *__restrict__ ip,
-                                                       const int32_t *__restrict__ wg, int *__restrict__ out) {
+                                                       const int32_t *__restrict__ wg, int cmax, int *__restrict__ out) {
     int mx = 0;
     for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
-        if (!(wg[(r / MK_ROWS_PER_TILE) * 16] & 1)) continue;          // rows of windowed tiles only
+        if (!(wg[(r / MK_ROWS_PER_TILE) * cmax] & 1)) continue;        // rows of windowed tiles only
         const int len = ip[r + 1] - ip[r];
         mx = len > mx ? len : mx;
     }
@@ -277,12 +285,13 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_maxlen(int64_t nrows, const int3
 }
 
 __global__ __launch_bounds__(MK_BLOCK) void pat_collect(int64_t nrows, const int32_t *__restrict__ ip,
-                                                        const int32_t *__restrict__ wg, const uint32_t *__restrict__ pk,
-                                                        const uint16_t *__restrict__ sl,
+                                                        const int32_t *__restrict__ ix,
+                                                        const int32_t *__restrict__ wg, int cmax,
+                                                        const uint32_t *__restrict__ pk, const uint16_t *__restrict__ sl,
                                                         int pmax, int limit, unsigned long long *table, int *state) {
     unsigned long long seen = DICT_EMPTY;
     for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
-        if (!(wg[(r / MK_ROWS_PER_TILE) * 16] & 1)) continue;
+        if (!(wg[(r / MK_ROWS_PER_TILE) * cmax] & 1)) continue;
         if (__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         uint32_t w[32];
         const int len = pat_row_words(ip, pk, sl, r, (int)(r % MK_ROWS_PER_TILE), pmax, w);
@@ -290,7 +299,10 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_collect(int64_t nrows, const int
             state[1] = 1;
             return;
         }
-        const unsigned long long key = pat_hash(len, w);
+        int kd = 255;
+        for (int q = 0; q < len; ++q)
+            if ((int64_t)ix[ip[r] + q] == r) kd = q;
+        const unsigned long long key = pat_hash(len, kd, w);
         if (key == seen) continue;
         set_insert(table, state, key, limit);
         seen = key;
@@ -302,8 +314,8 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_collect(int64_t nrows, const int
 // x[r] to epilogues that ask for it from the LDS window instead of loading it again
 __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int32_t *__restrict__ ip,
                                                        const int32_t *__restrict__ ix,
-                                                       const int32_t *__restrict__ wg, const uint32_t *__restrict__ pk,
-                                                       const uint16_t *__restrict__ sl,
+                                                       const int32_t *__restrict__ wg, int cmax,
+                                                       const uint32_t *__restrict__ pk, const uint16_t *__restrict__ sl,
                                                        int pmax, int count, const double *__restrict__ sorted_keys,
                                                        uint8_t *__restrict__ pid, uint32_t *__restrict__ pat,
                                                        uint8_t *__restrict__ plen, int mode, int *state) {
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
     k[threadIdx.x] = (threadIdx.x < count) ? (unsigned long long)__double_as_longlong(sorted_keys[threadIdx.x]) : ~0ULL;
     __syncthreads();
     for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
-        if (!(wg[(r / MK_ROWS_PER_TILE) * 16] & 1)) {
+        if (!(wg[(r / MK_ROWS_PER_TILE) * cmax] & 1)) {
             if (mode == 0) pid[r] = 0;
             continue;
         }
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
         for (int q = 0; q < len; ++q)
             if ((int64_t)ix[ip[r] + q] == r) kd = q;
         if (mode == 0) {
-            const unsigned long long key = pat_hash(len, w);
+            const unsigned long long key = pat_hash(len, kd, w);
             int lo = 0;
 #pragma unroll
             for (int step = 128; step >= 1; step >>= 1)
@@ -343,28 +355,29 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
 // fmt 5: the values of every windowed tile in the order the pattern kernel's lanes consume them (mk_spmv_fmt5.h).
 // width[T] = longest row of tile T (0 for a tile without windows: it keeps the CSR gather path)
 __global__ __launch_bounds__(MK_BLOCK) void sell_width(int64_t nrows, int64_t ntiles, const int32_t *__restrict__ ip,
-                                                       const int32_t *__restrict__ wg, int32_t *__restrict__ width) {
+                                                       const int32_t *__restrict__ wg, int cmax, int32_t *__restrict__ width) {
     __shared__ int mx;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
         if (threadIdx.x == 0) mx = 0;
         __syncthreads();
         const int64_t r = tile * MK_ROWS_PER_TILE + threadIdx.x;
-        if ((wg[tile * 16] & 1) && r < nrows) atomicMax(&mx, ip[r + 1] - ip[r]);
+        if ((wg[tile * cmax] & 1) && r < nrows) atomicMax(&mx, ip[r + 1] - ip[r]);
         __syncthreads();
         if (threadIdx.x == 0) width[tile] = mx;
     }
 }
 
 // sdesc[2 T] = start of tile T's block in units of 256 doubles, sdesc[2 T + 1] = its width
+// (ds: ints per tile in sdesc -- 2 for fmt 5, 4 for the wide formats, whose third int is the start of the tile's slot block)
 __global__ __launch_bounds__(MK_BLOCK) void sell_fill(int64_t nrows, int64_t ntiles, const int32_t *__restrict__ ip,
                                                       const double *__restrict__ dv, const int32_t *__restrict__ sdesc,
-                                                      double *__restrict__ sval) {
+                                                      int ds, double *__restrict__ sval) {
     const int t = threadIdx.x;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int w = sdesc[2 * tile + 1];
+        const int w = sdesc[ds * tile + 1];
         if (w == 0) continue;
-        double *vb = sval + (int64_t)sdesc[2 * tile] * MK_ROWS_PER_TILE;
+        double *vb = sval + (int64_t)sdesc[ds * tile] * MK_ROWS_PER_TILE;
         const int64_t r = tile * MK_ROWS_PER_TILE + t;
         const int lo = (r < nrows) ? ip[r] : 0, len = (r < nrows) ? ip[r + 1] - lo : 0;
         for (int k = 0; k < w; ++k) {
@@ -372,6 +385,22 @@ __global__ __launch_bounds__(MK_BLOCK) void sell_fill(int64_t nrows, int64_t nti
             const int64_t at = (k < (w & ~1)) ? (int64_t)(k >> 1) * 512 + 2 * t + (k & 1) : (int64_t)k * 256 + t;
             vb[at] = v;
         }
+    }
+}
+
+// fmt 6: the LDS slots of a tile's nonzeros, entry k of row t at [(k >> 2) * 1024 + 4 t + (k & 3)], 0xffff = padding
+__global__ __launch_bounds__(MK_BLOCK) void sell_fill_slots(int64_t nrows, int64_t ntiles, const int32_t *__restrict__ ip,
+                                                            const uint16_t *__restrict__ sl, const int32_t *__restrict__ sdesc,
+                                                            uint16_t *__restrict__ sslot) {
+    const int t = threadIdx.x;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int w = sdesc[4 * tile + 1];
+        if (w == 0) continue;
+        uint16_t *sb = sslot + (int64_t)sdesc[4 * tile + 2] * 1024;
+        const int64_t r = tile * MK_ROWS_PER_TILE + t;
+        const int lo = (r < nrows) ? ip[r] : 0, len = (r < nrows) ? ip[r + 1] - lo : 0;
+        const int w4 = (w + 3) & ~3;
+        for (int k = 0; k < w4; ++k) sb[(int64_t)(k >> 2) * 1024 + 4 * t + (k & 3)] = (k < len) ? sl[lo + k] : (uint16_t)0xffffu;
     }
 }
 
@@ -434,14 +463,15 @@ void plan_free(MkPlan &P) {
     hipFree(P.d_plen);
     hipFree(P.d_sval);
     hipFree(P.d_sdesc);
+    hipFree(P.d_sslot);
     P = MkPlan();
 }
 
 int default_format() {
     static int f = [] {
         const char *e = getenv("MK_SPMV_FORMAT");
-        int v = e ? atoi(e) : 5;
-        return v < 0 ? 0 : (v > 5 ? 5 : v);
+        int v = e ? atoi(e) : 8;
+        return v < 0 ? 0 : (v > 8 ? 8 : v);
     }();
     return f;
 }
@@ -558,101 +588,136 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     return MK_OK;
 }
 
+// The values (and, `with_slots`, the LDS slots) of every windowed tile in tile-sliced ELL order: widths -> host scan ->
+// block starts -> fill.  ds = ints per tile in the descriptor (2: fmt 5; 4: the wide formats).  Refuses more than
+// 12.5 % of padding.  On success the plan owns d_sval / d_sdesc (/ d_sslot).
+bool sell_build(const mk_csr *A, MkPlan &P, int ds, bool with_slots) {
+    hipStream_t st = mk_ctx().stream;
+    const int cmax = P.wide ? MK_WCHUNKS_WIDE : MK_WCHUNKS_MAX;
+    int32_t *d_sdesc = nullptr, *d_width = nullptr;
+    double *d_sval = nullptr;
+    uint16_t *d_sslot = nullptr;
+    std::vector<int32_t> wd((size_t)A->ntiles), sd((size_t)ds * (size_t)A->ntiles, 0);
+    int tg = (int)(A->ntiles < 16384 ? A->ntiles : 16384);
+    bool ok = hipMalloc((void **)&d_sdesc, sizeof(int32_t) * sd.size()) == hipSuccess &&
+              hipMalloc((void **)&d_width, sizeof(int32_t) * wd.size()) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(sell_width, dim3(tg), dim3(MK_BLOCK), 0, st, A->nrows, A->ntiles, A->d_indptr, P.d_wg, cmax, d_width);
+        ok = hipMemcpyAsync(wd.data(), d_width, sizeof(int32_t) * wd.size(), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    hipFree(d_width);
+    int64_t blocks = 0, sblocks = 0;
+    if (ok) {
+        for (int64_t t = 0; t < A->ntiles; ++t) {
+            sd[ds * t] = (int32_t)blocks;
+            sd[ds * t + 1] = wd[t];
+            blocks += wd[t];
+            if (ds == 4) {
+                sd[ds * t + 2] = (int32_t)sblocks;
+                if (with_slots) sblocks += (wd[t] + 3) / 4;
+            }
+            if (wd[t] > 32) ok = false;                       // (the row-walk kernels keep a row in <= 32 registers)
+        }
+        // (A->nnz: upper bound of the nonzeros the blocks hold)
+        ok = ok && blocks > 0 && blocks < (int64_t)0x7fffffff && 8 * blocks * MK_ROWS_PER_TILE <= 9 * A->nnz + 8 * 2048;
+        if (with_slots) ok = ok && 8 * sblocks * 1024 <= 10 * A->nnz + 8 * 8192;
+    }
+    ok = ok && hipMalloc((void **)&d_sval, sizeof(double) * (size_t)(blocks * MK_ROWS_PER_TILE + 2)) == hipSuccess;
+    if (ok && with_slots) ok = hipMalloc((void **)&d_sslot, sizeof(uint16_t) * (size_t)(sblocks * 1024 + 8)) == hipSuccess;
+    if (ok) {
+        ok = hipMemcpyAsync(d_sdesc, sd.data(), sizeof(int32_t) * sd.size(), hipMemcpyHostToDevice, st) == hipSuccess;
+        hipLaunchKernelGGL(sell_fill, dim3(tg), dim3(MK_BLOCK), 0, st, A->nrows, A->ntiles, A->d_indptr, A->d_data, d_sdesc, ds, d_sval);
+        if (with_slots)
+            hipLaunchKernelGGL(sell_fill_slots, dim3(tg), dim3(MK_BLOCK), 0, st, A->nrows, A->ntiles, A->d_indptr, P.d_slots,
+                               d_sdesc, d_sslot);
+        ok = ok && hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+    }
+    if (!ok) {
+        hipFree(d_sdesc);
+        hipFree(d_sval);
+        hipFree(d_sslot);
+        return false;
+    }
+    P.d_sdesc = d_sdesc;
+    P.d_sval = d_sval;
+    P.d_sslot = d_sslot;
+    P.sell_entries = blocks * MK_ROWS_PER_TILE;
+    P.slot_entries = sblocks * 1024;
+    return true;
+}
+
 // fmt 2 -> fmt 4 when every row of every windowed tile follows one of a few patterns (see above).  Any failure leaves
 // the matrix in fmt 2.  `raw`: fmt 1 -> fmt 5, the same for a matrix without a value dictionary -- patterns of the bare
 // slots, and the values copied into tile-sliced ELL order (any failure, or more than 12.5 % of padding: stays fmt 1).
-void pattern_plan(const mk_csr *A, MkPlan &P, bool raw) {
-    if (getenv("MK_NO_PATTERNS")) return;
+bool pattern_plan(const mk_csr *A, MkPlan &P, bool raw) {
+    if (getenv("MK_NO_PATTERNS")) return false;
     const uint32_t *words = raw ? nullptr : P.d_pk;
+    const int cmax = P.wide ? MK_WCHUNKS_WIDE : MK_WCHUNKS_MAX;
+    const int cap_words = P.wide ? PAT_WORDS_WIDE : PAT_WORDS;
     hipStream_t st = mk_ctx().stream;
     int *d_state = nullptr;
     unsigned long long *d_table = nullptr;
     double *d_keys = nullptr;
     uint8_t *d_pid = nullptr, *d_plen = nullptr;
     uint32_t *d_pat = nullptr;
+    const char *why = "";
     auto cleanup = [&]() {
+        if (*why && getenv("MK_DEBUG_PLAN")) fprintf(stderr, "mikrylov: no row patterns (%s)\n", why);
         hipFree(d_state);
         hipFree(d_table);
         hipFree(d_keys);
         hipFree(d_pid);
         hipFree(d_plen);
         hipFree(d_pat);
+        return false;
     };
     int h_state[2] = {0, 0};
     int grid = (int)((A->nrows + MK_BLOCK - 1) / MK_BLOCK);
     grid = grid > 4096 ? 4096 : (grid < 1 ? 1 : grid);
     if (hipMalloc((void **)&d_state, 2 * sizeof(int)) != hipSuccess) return cleanup();
     hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
-    hipLaunchKernelGGL(pat_maxlen, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, d_state);
+    hipLaunchKernelGGL(pat_maxlen, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, cmax, d_state);
     if (hipMemcpyAsync(h_state, d_state, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return cleanup();
     const int maxlen = h_state[0];
     const int pmax = maxlen <= 8 ? 8 : (maxlen <= 16 ? 16 : (maxlen <= 32 ? 32 : 0));
+    why = "rows of more than 32 entries";
     if (pmax == 0 || maxlen < 1) return cleanup();
-    if (raw && pmax != 8) return cleanup();                  // (the fmt 5 kernel keeps a row's values in 8 registers)
-    const int limit = PAT_WORDS / pmax > 256 ? 256 : PAT_WORDS / pmax;
+    why = "rows of more than 8 entries in the 16-chunk cover";
+    if (raw && !P.wide && pmax != 8) return cleanup();       // (the fmt 5 kernel keeps a row's values in 8 registers)
+    why = "allocation";
+    const int limit = cap_words / pmax > 256 ? 256 : cap_words / pmax;
     std::vector<unsigned long long> empty(DICT_SLOTS, DICT_EMPTY);
     if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS) != hipSuccess ||
         hipMalloc((void **)&d_keys, sizeof(double) * 256) != hipSuccess ||
         hipMalloc((void **)&d_pid, (size_t)A->nrows + 16) != hipSuccess ||
         hipMalloc((void **)&d_plen, 512) != hipSuccess ||
-        hipMalloc((void **)&d_pat, sizeof(uint32_t) * PAT_WORDS) != hipSuccess)
+        hipMalloc((void **)&d_pat, sizeof(uint32_t) * cap_words) != hipSuccess)
         return cleanup();
     hipMemcpyAsync(d_table, empty.data(), sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyHostToDevice, st);
     hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
-    hipMemsetAsync(d_pat, 0, sizeof(uint32_t) * PAT_WORDS, st);
+    hipMemsetAsync(d_pat, 0, sizeof(uint32_t) * cap_words, st);
     hipMemsetAsync(d_plen, 0, 512, st);
-    hipLaunchKernelGGL(pat_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, P.d_wg, words, P.d_slots,
+    hipLaunchKernelGGL(pat_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, P.d_wg, cmax, words, P.d_slots,
                        pmax, limit, d_table, d_state);
+    why = "too many distinct patterns";
     if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess || h_state[1] || h_state[0] < 1 || h_state[0] > limit)
         return cleanup();
     const int count = h_state[0];
     hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_keys);
     for (int mode = 0; mode < 2; ++mode)
-        hipLaunchKernelGGL(pat_assign, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, P.d_wg, words,
-                           P.d_slots, pmax, count, d_keys, d_pid, d_pat, d_plen, mode, d_state);
+        hipLaunchKernelGGL(pat_assign, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, P.d_wg, cmax,
+                           words, P.d_slots, pmax, count, d_keys, d_pid, d_pat, d_plen, mode, d_state);
+    why = "verification against the table";
     if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess || h_state[1])
         return cleanup();
-    if (raw) {
-        // the values in the order the lanes consume them: widths -> host scan -> block starts -> fill
-        int32_t *d_sdesc = nullptr;
-        double *d_sval = nullptr;
-        std::vector<int32_t> wd((size_t)A->ntiles), sd(2 * (size_t)A->ntiles);
-        int tg = (int)(A->ntiles < 16384 ? A->ntiles : 16384);
-        bool ok = hipMalloc((void **)&d_sdesc, sizeof(int32_t) * 2 * (size_t)A->ntiles) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL(sell_width, dim3(tg), dim3(MK_BLOCK), 0, st, A->nrows, A->ntiles, A->d_indptr, P.d_wg, d_sdesc);
-            ok = hipMemcpyAsync(wd.data(), d_sdesc, sizeof(int32_t) * wd.size(), hipMemcpyDeviceToHost, st) == hipSuccess &&
-                 hipStreamSynchronize(st) == hipSuccess;
-        }
-        int64_t blocks = 0, nnz_win = 0;
-        if (ok) {
-            for (int64_t t = 0; t < A->ntiles; ++t) {
-                sd[2 * t] = (int32_t)blocks;
-                sd[2 * t + 1] = wd[t];
-                blocks += wd[t];
-            }
-            nnz_win = A->nnz;                                 // (upper bound of the nonzeros the blocks hold)
-            ok = blocks > 0 && blocks < (int64_t)0x7fffffff && 8 * blocks * MK_ROWS_PER_TILE <= 9 * nnz_win + 8 * 2048;
-        }
-        ok = ok && hipMalloc((void **)&d_sval, sizeof(double) * (size_t)(blocks * MK_ROWS_PER_TILE + 2)) == hipSuccess;
-        if (ok) {
-            ok = hipMemcpyAsync(d_sdesc, sd.data(), sizeof(int32_t) * sd.size(), hipMemcpyHostToDevice, st) == hipSuccess;
-            hipLaunchKernelGGL(sell_fill, dim3(tg), dim3(MK_BLOCK), 0, st, A->nrows, A->ntiles, A->d_indptr, A->d_data, d_sdesc, d_sval);
-            ok = ok && hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
-        }
-        if (!ok) {
-            hipFree(d_sdesc);
-            hipFree(d_sval);
-            return cleanup();
-        }
-        P.d_sdesc = d_sdesc;
-        P.d_sval = d_sval;
-        P.sell_entries = blocks * MK_ROWS_PER_TILE;
-    }
+    why = "padding of the value blocks";
+    if (raw && !sell_build(A, P, P.wide ? 4 : 2, false)) return cleanup();
+    why = "";
     P.d_pid = d_pid;
     P.d_pat = d_pat;
     P.d_plen = d_plen;
@@ -661,16 +726,98 @@ void pattern_plan(const mk_csr *A, MkPlan &P, bool raw) {
     d_plen = nullptr;
     P.npat = count;
     P.pmax = pmax;
-    P.fmt = raw ? 5 : 4;
-    if (getenv("MK_DEBUG_PLAN")) fprintf(stderr, "mikrylov: %lld rows, %d row patterns of <= %d entries\n", (long long)A->nrows, count, pmax);
+    P.fmt = P.wide ? (raw ? 7 : 8) : (raw ? 5 : 4);
+    if (getenv("MK_DEBUG_PLAN")) fprintf(stderr, "mikrylov: %lld rows, %d row patterns of <= %d entries (fmt %d)\n", (long long)A->nrows, count, pmax, P.fmt);
     // the per-nonzero streams are not read any more (tiles without windows gather from the CSR arrays)
     hipFree(P.d_pk);
     hipFree(P.d_slots);
     P.d_pk = nullptr;
     P.d_slots = nullptr;
     cleanup();
+    return true;
 }
 
+// the value dictionary of a covered matrix: <= 256 distinct bit patterns -> P.d_dict / P.ndict and one packed word
+// {slot | code << 16} per nonzero in P.d_pk.  Returns 1 = built, 0 = too many values (nothing kept), -1 = HIP failure.
+int dictionary_build(const mk_csr *A, MkPlan &P) {
+    hipStream_t st = mk_ctx().stream;
+    unsigned long long *d_table = nullptr;
+    int h_state[2] = {0, 0};
+    auto drop = [&](int rc) {
+        hipFree(d_table);
+        hipFree(P.d_dict);
+        hipFree(P.d_pk);
+        P.d_dict = nullptr;
+        P.d_pk = nullptr;
+        return rc;
+    };
+    if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS + 2 * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&P.d_dict, sizeof(double) * 256) != hipSuccess)
+        return drop(-1);
+    int *d_state = reinterpret_cast<int *>(d_table + DICT_SLOTS);
+    std::vector<unsigned long long> empty(DICT_SLOTS, DICT_EMPTY);
+    if (hipMemcpyAsync(d_table, empty.data(), sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(d_state, 0, 2 * sizeof(int), st) != hipSuccess)
+        return drop(-1);
+    int grid = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
+    grid = grid > 4096 ? 4096 : grid;
+    hipLaunchKernelGGL(dict_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, d_table, d_state);
+    if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return drop(-1);
+    if (h_state[1] || h_state[0] > 256 || h_state[0] < 1) return drop(0);
+    // (the fmt 2 kernel copies whole 1 KiB pieces of the word stream: room for one piece behind the last nonzero)
+    const size_t pkpad = (size_t)A->nnz + 256 + MK_CSR_PAD;
+    if (hipMalloc((void **)&P.d_pk, sizeof(uint32_t) * pkpad) != hipSuccess) return drop(-1);
+    hipMemsetAsync(P.d_pk, 0, sizeof(uint32_t) * pkpad, st);
+    hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, P.d_dict);
+    hipLaunchKernelGGL(dict_encode, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, P.d_dict, h_state[0], P.d_slots,
+                       P.d_pk);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return drop(-1);
+    hipFree(d_table);
+    P.ndict = h_state[0];
+    return 1;
+}
+
+// windows of every tile: the cover with 16 chunks / 2048 nonzeros per tile, or the wide one (32 / 8192)
+bool cover_build(const mk_csr *A, MkPlan &P, bool wide) {
+    hipStream_t st = mk_ctx().stream;
+    const size_t pad = (size_t)A->nnz + MK_CSR_PAD;
+    const int cmax = wide ? MK_WCHUNKS_WIDE : MK_WCHUNKS_MAX;
+    int *d_stats = nullptr;
+    int h_stats[4] = {0, 0, 0, 0};
+    bool ok = hipMalloc((void **)&P.d_slots, sizeof(uint16_t) * pad) == hipSuccess &&
+              hipMalloc((void **)&P.d_wg, sizeof(int32_t) * (size_t)cmax * (size_t)A->ntiles) == hipSuccess &&
+              hipMalloc((void **)&P.d_wn, sizeof(uint32_t) * (size_t)(cmax / 4) * (size_t)A->ntiles) == hipSuccess &&
+              hipMalloc((void **)&d_stats, 4 * sizeof(int)) == hipSuccess;
+    ok = ok && hipMemsetAsync(P.d_slots, 0, sizeof(uint16_t) * pad, st) == hipSuccess &&
+         hipMemsetAsync(d_stats, 0, 4 * sizeof(int), st) == hipSuccess;
+    if (ok) {
+        const int grid = (int)(A->ntiles < 4096 ? A->ntiles : 4096);
+        if (wide)
+            hipLaunchKernelGGL((cover_kernel<MK_WCHUNKS_WIDE, MK_WIDE_TILE>), dim3(grid), dim3(MK_BLOCK), 0, st, A->d_indptr,
+                               A->d_indices, A->nrows, A->ntiles, A->x_len(), P.d_wg, P.d_wn, P.d_slots, d_stats);
+        else
+            hipLaunchKernelGGL((cover_kernel<MK_WCHUNKS_MAX, MK_SPMV_TILE>), dim3(grid), dim3(MK_BLOCK), 0, st, A->d_indptr,
+                               A->d_indices, A->nrows, A->ntiles, A->x_len(), P.d_wg, P.d_wn, P.d_slots, d_stats);
+        ok = hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+    }
+    hipFree(d_stats);
+    P.wide = wide;
+    P.wchunks = h_stats[0];
+    P.covered = h_stats[1];
+    return ok;
+}
+
+// Which format: `want` (mk_csr_set_format, MK_SPMV_FORMAT; default 8) is the highest one the builder may choose.
+//   0 / 3     plain CSR (3: resident tiles when x is longer than an L2)
+//   1 .. 5    the 16-chunk cover (tiles of <= 2048 nonzeros): 1 slots + values, 2 + dictionary, 4 + row patterns,
+//             5 row patterns + values in tile-sliced ELL order (no dictionary)
+//   6 .. 8    when that cover reaches less than half of the tiles (rows of more than 8 entries): the wide cover
+//             (32 chunks, 8192 nonzeros) with 8 dictionary + row patterns, 7 row patterns + streamed values,
+//             6 streamed slots + values.  want == 6 or 7 given explicitly also applies them to a matrix the narrow
+//             cover would have served (format comparisons, tests).
 int plan_build(const mk_csr *A) {
     MkPlan &P = A->plan;
     P.built = true;
@@ -688,80 +835,61 @@ int plan_build(const mk_csr *A) {
         return MK_OK;
     };
     if (want == 0 || want == 3) return plain();
-    hipStream_t st = mk_ctx().stream;
-    const size_t pad = (size_t)A->nnz + MK_CSR_PAD;
-    int *d_stats = nullptr;
-    unsigned long long *d_table = nullptr;
     auto fail = [&](const char *what) {
-        hipFree(d_stats);
-        hipFree(d_table);
         plan_free(P);
         P.built = true;
         return mk_fail(MK_ERR_HIP, "windowed format: %s failed (the matrix stays on the CSR path)", what);
     };
-    if (hipMalloc((void **)&P.d_slots, sizeof(uint16_t) * pad) != hipSuccess ||
-        hipMalloc((void **)&P.d_wg, sizeof(int32_t) * MK_WCHUNKS_MAX * (size_t)A->ntiles) != hipSuccess ||
-        hipMalloc((void **)&P.d_wn, sizeof(uint32_t) * 4 * (size_t)A->ntiles) != hipSuccess ||
-        hipMalloc((void **)&d_stats, 4 * sizeof(int)) != hipSuccess)
-        return fail("hipMalloc");
-    if (hipMemsetAsync(P.d_slots, 0, sizeof(uint16_t) * pad, st) != hipSuccess ||
-        hipMemsetAsync(d_stats, 0, 4 * sizeof(int), st) != hipSuccess)
-        return fail("hipMemset");
-    int grid = (int)(A->ntiles < 4096 ? A->ntiles : 4096);
-    hipLaunchKernelGGL(cover_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, A->d_indptr, A->d_indices, A->nrows, A->ntiles,
-                       A->x_len(), P.d_wg, P.d_wn, P.d_slots, d_stats);
-    int h_stats[4] = {0, 0, 0, 0};
-    if (hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-        return fail("cover kernel");
-    hipFree(d_stats);
-    d_stats = nullptr;
-    P.wchunks = h_stats[0];
-    P.covered = h_stats[1];
-    if (2 * P.covered < A->ntiles) {                         // mostly scattered columns: not worth the second code path
+    const bool force_wide = (A->want_fmt == 6 || A->want_fmt == 7);
+    if (!cover_build(A, P, false)) return fail("cover kernel");
+    const bool narrow_ok = 2 * P.covered >= A->ntiles;
+    if (narrow_ok && !force_wide) {
+        P.fmt = 1;
+        if (want < 2) return MK_OK;
+        const int rc = dictionary_build(A, P);
+        if (rc < 0) return fail("value dictionary");
+        if (rc == 0) {                                       // too many distinct values: windows with raw values
+            if (want >= 5) pattern_plan(A, P, true);         // ... in pattern order when the rows follow patterns (fmt 5)
+            return MK_OK;
+        }
+        P.fmt = 2;
+        if (want >= 4) pattern_plan(A, P, false);
+        return MK_OK;
+    }
+    if (want < 6) {                                          // mostly scattered columns or long rows: the CSR path
         plan_free(P);
         P.built = true;
         return plain();
     }
-    P.fmt = 1;
-    if (want < 2) return MK_OK;
-    // ---- value dictionary
-    int h_state[2] = {0, 0};
-    if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS + 2 * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&P.d_dict, sizeof(double) * 256) != hipSuccess)
-        return fail("hipMalloc");
-    int *d_state = reinterpret_cast<int *>(d_table + DICT_SLOTS);
-    std::vector<unsigned long long> empty(DICT_SLOTS, DICT_EMPTY);
-    if (hipMemcpyAsync(d_table, empty.data(), sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemsetAsync(d_state, 0, 2 * sizeof(int), st) != hipSuccess)
-        return fail("dictionary setup");
-    grid = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
-    grid = grid > 4096 ? 4096 : grid;
-    hipLaunchKernelGGL(dict_collect, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, d_table, d_state);
-    if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-        return fail("dictionary kernel");
-    if (h_state[1] || h_state[0] > 256 || h_state[0] < 1) {  // too many distinct values: windows with raw values
-        hipFree(d_table);
-        hipFree(P.d_dict);
-        P.d_dict = nullptr;
-        if (want >= 5) pattern_plan(A, P, true);             // ... in pattern order when the rows follow patterns (fmt 5)
+    // ---- wide tiles
+    plan_free(P);
+    P.built = true;
+    if (!cover_build(A, P, true)) return fail("wide cover kernel");
+    if (2 * P.covered < A->ntiles) {
+        plan_free(P);
+        P.built = true;
+        return plain();
+    }
+    if (want >= 8) {
+        const int rc = dictionary_build(A, P);
+        if (rc < 0) return fail("value dictionary");
+        if (rc > 0) {
+            if (pattern_plan(A, P, false)) return MK_OK;     // fmt 8
+            hipFree(P.d_pk);                                 // (no wide kernel reads a per-nonzero word stream)
+            hipFree(P.d_dict);
+            P.d_pk = nullptr;
+            P.d_dict = nullptr;
+            P.ndict = 0;
+        }
+    }
+    if (want >= 7 && pattern_plan(A, P, true)) return MK_OK; // fmt 7
+    if (sell_build(A, P, 4, true)) {                         // fmt 6
+        P.fmt = 6;
         return MK_OK;
     }
-    // (the kernel copies whole 1 KiB pieces of the word stream: room for one piece behind the last nonzero)
-    const size_t pkpad = (size_t)A->nnz + 256 + MK_CSR_PAD;
-    if (hipMalloc((void **)&P.d_pk, sizeof(uint32_t) * pkpad) != hipSuccess) return fail("hipMalloc");
-    hipMemsetAsync(P.d_pk, 0, sizeof(uint32_t) * pkpad, st);
-    hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, P.d_dict);
-    hipLaunchKernelGGL(dict_encode, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, P.d_dict, h_state[0], P.d_slots,
-                       P.d_pk);
-    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return fail("dictionary encode");
-    hipFree(d_table);
-    d_table = nullptr;
-    P.ndict = h_state[0];
-    P.fmt = 2;
-    if (want >= 4) pattern_plan(A, P, false);
-    return MK_OK;
+    plan_free(P);                                            // (too much padding: rows of very different lengths)
+    P.built = true;
+    return plain();
 }
 
 }  // namespace
@@ -778,7 +906,7 @@ void mk_csr_plan_reset(const mk_csr *A) {
 
 extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {
     MK_REQUIRE_INIT();
-    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 5);
+    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 8);
     if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_format: set the format on the matrix a composed operator was built from");
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
@@ -792,7 +920,7 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
     if (fmt) *fmt = P->fmt;
-    const bool windowed = (P->fmt == 1 || P->fmt == 2 || P->fmt == 4 || P->fmt == 5);
+    const bool windowed = (P->fmt == 1 || P->fmt == 2 || P->fmt >= 4);
     if (tiles_windowed) *tiles_windowed = windowed ? P->covered : 0;
     if (lds_chunks) *lds_chunks = windowed ? P->wchunks : (P->fmt == 3 ? P->rt_k : 0);
     if (dict_size) *dict_size = P->ndict;
@@ -806,11 +934,13 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
             const double share = A->ntiles ? (double)P->covered / (double)A->ntiles : 0.0;
             // (fmt 4: one byte per ROW and no row pointers for the windowed tiles)
             // (fmt 5: the same byte per row, the padded values of the windowed tiles and 8 bytes per tile for their blocks)
-            const double per = (P->fmt == 4 || P->fmt == 5) ? 0.0 : ((P->fmt == 2) ? 4.0 : 10.0);
-            b += (int64_t)(A->nnz * (share * per + (1.0 - share) * 12.0)) + 80 * A->ntiles;
-            if (P->fmt == 4 || P->fmt == 5)
-                b += (int64_t)(share * (double)A->nrows) - (int64_t)(share * 4.0 * (double)(A->nrows + 1));
+            // (fmt 6, 7, 8: the wide twins -- fmt 6 streams padded values and padded uint16 slots and reads no pattern byte)
+            const double per = (P->fmt >= 4) ? 0.0 : ((P->fmt == 2) ? 4.0 : 10.0);
+            b += (int64_t)(A->nnz * (share * per + (1.0 - share) * 12.0)) + (P->wide ? 160 : 80) * A->ntiles;
+            if (P->fmt >= 4)
+                b += (int64_t)(P->fmt == 6 ? 0.0 : share * (double)A->nrows) - (int64_t)(share * 4.0 * (double)(A->nrows + 1));
             if (P->fmt == 5) b += 8 * P->sell_entries + 8 * A->ntiles;
+            if (P->fmt == 6 || P->fmt == 7) b += 8 * P->sell_entries + 2 * P->slot_entries + 16 * A->ntiles;
         }
         *matrix_bytes_per_product = b;
     }

@@ -92,12 +92,16 @@ struct MkExchange {
 // Windowed tile format of a matrix (mk_format.hip), built on first use of the matrix in a product.
 constexpr int MK_WCHUNK = 128;     // doubles per window chunk (one wave-level 16-byte load)
 constexpr int MK_WCHUNKS_MAX = 16; // chunks per tile (4 per wave): 16 KiB of LDS windows at most
+constexpr int MK_WCHUNKS_WIDE = 32; // ... of the wide cover (8 per wave, 32 KiB), tiles of up to MK_WIDE_TILE nonzeros
+constexpr int MK_WIDE_TILE = 8192;
 struct MkPlan {
     bool built = false;
     int fmt = 0;                   // 0 plain CSR, 1 windows + uint16 slots, 2 windows + slots + value dictionary,
                                    // 3 plain CSR, tile resident in LDS, gathers ordered by column block,
                                    // 4 windows + dictionary + row patterns (one byte per row)
                                    // 5 windows + row patterns + raw values in tile-sliced ELL order
+                                   // 6 wide tiles: slots + values in tile-sliced ELL order; 7 wide: row patterns +
+                                   // values; 8 wide: row patterns + dictionary
     int wchunks = 0;               // max chunks of a tile
     int ndict = 0;
     int64_t covered = 0;           // tiles on the windowed path
@@ -115,6 +119,11 @@ struct MkPlan {
     double *d_sval = nullptr;
     int32_t *d_sdesc = nullptr;
     int64_t sell_entries = 0;      // doubles in d_sval (256 * sum of the tile widths)
+    // fmt 6, 7, 8 (wide tiles): the cover has 32 chunks per tile (8 per wave) and tiles of up to 8192 nonzeros; fmt 6
+    // streams the LDS slots in tile-sliced ELL order beside the values; d_sdesc then holds four ints per tile
+    bool wide = false;
+    uint16_t *d_sslot = nullptr;
+    int64_t slot_entries = 0;      // uint16 in d_sslot
     // fmt 3 (resident tiles, column phases): plain CSR arrays, only launch parameters
     int rt_cap = 0;                // LDS capacity per tile in nonzeros (max tile stream length rounded up to 256)
     int rt_k = 1;                  // column phases

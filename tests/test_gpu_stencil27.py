@@ -74,8 +74,8 @@ def test_cg_on_a_27_point_operator(shape, seed):
     n = A.shape[0]
     op = gallery.stencil27(*shape, seed=seed)
     rhs = A.matvec(np.ones(n))
-    s = pk.CG(op)
-    s.solve(rhs, reltol=1e-10)
+    s = pk.CG(op, reltol=1e-10)
+    s.solve(rhs)
     ref = kr.cg(A, rhs, reltol=1e-10, red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], gpu_order.launch_geometry(op))))
     assert s.converged and s.nMatvec == ref["nMatvec"]
     assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
