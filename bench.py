@@ -62,7 +62,12 @@ FMT_NAMES = {0: "csr (int32 columns + fp64 values, x gathered)",
              4: "windowed tiles + value dictionary + row patterns (one byte per ROW: the number of its pattern of "
                 "{LDS slot - lane, value code} words)",
              5: "windowed tiles + row patterns for the x positions (one byte per row) + the fp64 values streamed in "
-                "tile-sliced ELL order (8 B per nonzero; no column indices, no row pointers)"}
+                "tile-sliced ELL order (8 B per nonzero; no column indices, no row pointers)",
+             6: "wide windowed tiles (rows <= 32 entries, 32 window chunks): uint16 LDS slots + fp64 values, both streamed in "
+                "tile-sliced ELL order (10 B per nonzero)",
+             7: "wide windowed tiles + row patterns (one byte per row) + fp64 values streamed in tile-sliced ELL order",
+             8: "wide windowed tiles + value dictionary + row patterns (one byte per ROW, entries {offset, value} through "
+                "the scalar cache)"}
 
 
 def spmv_bytes(nrows, ncols, nnz):
@@ -133,7 +138,11 @@ def cpu_baseline(name, seconds_budget=20.0):
         scale, sample = 1.0, "first %%d CG iterations of %s (n=%d), rhs=A*1" % (name, m * m)
     else:
         ms = min(m, 128)                 # 512^3 does not fit a host-side sample: time 128^3 and scale by rows
-        A = csr_ref.poisson3d_varcoef(ms, seed=VARCOEF_SEED) if name.endswith("-varcoef") else csr_ref.poisson3d(ms)
+        if name.startswith("stencil27-"):
+            ms = min(m, 80)
+            A = csr_ref.stencil27(ms, seed=VARCOEF_SEED if name.endswith("-varcoef") else 0)
+        else:
+            A = csr_ref.poisson3d_varcoef(ms, seed=VARCOEF_SEED) if name.endswith("-varcoef") else csr_ref.poisson3d(ms)
         scale = float(ms ** 3) / float(m ** 3)
         sample = ("first %%d CG iterations on %d^3 (%d rows, same operator family), measured iterations/s "
                   "EXTRAPOLATED by the rows ratio %.4g to %s" % (ms, ms ** 3, scale, name))
@@ -205,6 +214,13 @@ def build_workload(name, world, exchange):
             return (gallery.poisson3d_varcoef(m, seed=seed) if seed is not None else gallery.poisson3d(m)), n, meta
         op, _ = dist.partition_poisson3d(world, m, m, m, mode=exchange, varcoef_seed=seed)
         return op, n, meta
+    if name.startswith("stencil27-"):                        # (27-point box stencil, HPCG's sparsity; single GPU only)
+        m = int(name.split("-")[1])
+        seed = VARCOEF_SEED if name.endswith("-varcoef") else 0
+        if world.nranks != 1:
+            raise SystemExit("workload %r runs on one GPU" % name)
+        return gallery.stencil27(m, seed=seed), m ** 3, {"grid": [m, m, m], "stencil": 27, "coefficients":
+                                                          "variable (seed %d)" % seed if seed else "constant (-1 / 26)"}
     raise SystemExit("unknown workload %r" % name)
 
 

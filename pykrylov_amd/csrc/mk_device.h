@@ -72,6 +72,8 @@ struct MkCsrView {
     // LDS slots in tile-sliced ELL order (fmt 6); sdesc holds FOUR ints per tile {value block, width, slot block, -}
     int wmode, wper;
     const uint16_t *sslot;
+    const void *ptab;        // fmt 8: pattern entries {byte offset, value} (mk_spmv_fmtw.h) and per pattern {length | diagonal << 8}
+    const int32_t *pinfo;
     int allwin;              // every tile of the matrix has windows (no tile ever takes the gather path)
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
@@ -170,12 +172,12 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         per_cu = per_cu > 7 ? 7 : (per_cu < 1 ? 1 : per_cu);
         cap = 256 * per_cu;
     }
-    else if (P && P->fmt >= 6) {                             // wide tiles: 3 per CU (168 registers; fmt 8: 7), as many as LDS holds
+    else if (P && P->fmt >= 6) {                             // wide tiles: 4 per CU (128 registers; fmt 8: 7), as many as LDS holds
         int64_t top = 128 * (int64_t)P->wchunks + 2;
         if (P->covered != A->ntiles && top < MK_PROD_LDS) top = MK_PROD_LDS;
-        const int64_t lds = 8 * (top + MK_BLOCK) + 4 * (int64_t)((P->fmt >= 7 ? P->npat * P->pmax : 0) + 4) + 4608;   // + static arrays
+        const int64_t lds = 8 * (top + MK_BLOCK) + 4 * (int64_t)((P->fmt == 7 ? P->npat * P->pmax : 0) + 4) + 2560;   // + static arrays
         int64_t per_cu = (160 * 1024) / lds;
-        const int64_t top_cu = (P->fmt == 8) ? 7 : 3;
+        const int64_t top_cu = (P->fmt == 8) ? 7 : 4;
         per_cu = per_cu > top_cu ? top_cu : (per_cu < 1 ? 1 : per_cu);
         cap = 256 * per_cu;
     }
@@ -248,6 +250,8 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.wper = P->wide ? 8 : 4;
         v.wmode = v.fmt >= 6 ? v.fmt - 6 : 0;
         v.sslot = P->d_sslot;
+        v.ptab = P->d_ptab;
+        v.pinfo = P->d_pinfo;
     }
     return v;
 }
@@ -533,7 +537,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : (FMT == 7 ? 3 : (FMT >= 4 ? 7 : 4))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : (FMT == 7 ? 4 : (FMT >= 4 ? 7 : 4))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
@@ -612,10 +616,10 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         else
             hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 5>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                                halt, partials);
-    } else if (v.fmt >= 6) {                                 // wide tiles: windows + zeros + pattern words
+    } else if (v.fmt >= 6) {                                 // wide tiles: zeros + windows (or the gather path's products) + pattern words
         size_t wtop = (size_t)(128 * v.wchunks + 2);
         if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
-        lds = sizeof(double) * (wtop + MK_BLOCK) + 4 * (size_t)((v.fmt >= 7 ? v.npat * v.pmax : 0) + 4);
+        lds = sizeof(double) * (wtop + MK_BLOCK) + 4 * (size_t)((v.fmt == 7 ? v.npat * v.pmax : 0) + 4);
         if (v.fmt == 8)
             hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_WIDE_DICT>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
                                epi, gate, halt, partials);

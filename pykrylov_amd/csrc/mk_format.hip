@@ -309,7 +309,9 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_collect(int64_t nrows, const int
     }
 }
 
-// mode 0: number the rows and fill the table (identical writes race benignly); mode 1: compare every row with it
+// mode 0: number the rows and fill the table (identical writes race benignly); mode 1: compare every row with it.
+// padword: what the table holds behind a pattern's end -- the wide kernels read it (relative slot -256 = the lane's
+// zero cell, mk_spmv_fmtw.h), the kernels of fmt 4 / 5 stop at plen
 // plen[p] = entries of pattern p, plen[256 + p] = position of the DIAGONAL entry in it (255: none) -- the kernel hands
 // x[r] to epilogues that ask for it from the LDS window instead of loading it again
 __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int32_t *__restrict__ ip,
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
                                                        const uint32_t *__restrict__ pk, const uint16_t *__restrict__ sl,
                                                        int pmax, int count, const double *__restrict__ sorted_keys,
                                                        uint8_t *__restrict__ pid, uint32_t *__restrict__ pat,
-                                                       uint8_t *__restrict__ plen, int mode, int *state) {
+                                                       uint8_t *__restrict__ plen, int mode, uint32_t padword, int *state) {
     __shared__ unsigned long long k[256];
     k[threadIdx.x] = (threadIdx.x < count) ? (unsigned long long)__double_as_longlong(sorted_keys[threadIdx.x]) : ~0ULL;
     __syncthreads();
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
             pid[r] = (uint8_t)lo;
             plen[lo] = (uint8_t)len;
             plen[256 + lo] = (uint8_t)kd;
-            for (int q = 0; q < pmax; ++q) pat[lo * pmax + q] = (q < len) ? w[q] : 0u;
+            for (int q = 0; q < pmax; ++q) pat[lo * pmax + q] = (q < len) ? w[q] : padword;
         } else {
             const int id = pid[r];
             bool same = (plen[id] == len) && (plen[256 + id] == kd);
@@ -349,6 +351,45 @@ __global__ __launch_bounds__(MK_BLOCK) void pat_assign(int64_t nrows, const int3
             if (!same) state[1] = 1;
         }
     }
+}
+
+// fmt 8: the pattern table in the form the kernel takes through the scalar cache -- per entry {byte offset of the x
+// value from the lane's own cell, value}; behind a pattern's end {-2048 = the lane's zero cell, +0.0}.  pinfo[p] =
+// entries of pattern p | position of its diagonal entry << 8 (255: none)
+struct PatEntryHost {
+    int off, pad;
+    double val;
+};
+__global__ __launch_bounds__(MK_BLOCK) void ptab_build(int npat, int pmax, const uint32_t *__restrict__ pat,
+                                                       const uint8_t *__restrict__ plen, const double *__restrict__ dict,
+                                                       PatEntryHost *__restrict__ ptab, int32_t *__restrict__ pinfo) {
+    for (int e = blockIdx.x * MK_BLOCK + threadIdx.x; e < npat * pmax; e += gridDim.x * MK_BLOCK) {
+        const int p = e / pmax, k = e - p * pmax;
+        const uint32_t w = pat[e];
+        PatEntryHost en;
+        en.pad = 0;
+        if (k < (int)plen[p]) {
+            en.off = 8 * (int)(short)(w & 0xffffu);
+            en.val = dict[(w >> 16) & 0xffu];
+        } else {
+            en.off = -8 * MK_BLOCK;
+            en.val = 0.0;
+        }
+        ptab[e] = en;
+    }
+    for (int p = blockIdx.x * MK_BLOCK + threadIdx.x; p < 256; p += gridDim.x * MK_BLOCK)
+        pinfo[p] = (p < npat) ? ((int)plen[p] | ((int)plen[256 + p] << 8)) : (255 << 8);
+}
+// fmt 7: the same for a matrix without dictionary -- per entry the byte offset alone
+__global__ __launch_bounds__(MK_BLOCK) void poff_build(int npat, int pmax, const uint32_t *__restrict__ pat,
+                                                       const uint8_t *__restrict__ plen, int32_t *__restrict__ poff,
+                                                       int32_t *__restrict__ pinfo) {
+    for (int e = blockIdx.x * MK_BLOCK + threadIdx.x; e < npat * pmax; e += gridDim.x * MK_BLOCK) {
+        const int p = e / pmax, k = e - p * pmax;
+        poff[p * (pmax < 16 ? 16 : pmax) + k] = (k < (int)plen[p]) ? 8 * (int)(short)(pat[e] & 0xffffu) : -8 * MK_BLOCK;
+    }
+    for (int p = blockIdx.x * MK_BLOCK + threadIdx.x; p < 256; p += gridDim.x * MK_BLOCK)
+        pinfo[p] = (p < npat) ? ((int)plen[p] | ((int)plen[256 + p] << 8)) : (255 << 8);
 }
 
 // ------------------------------------------------------------------------------------------------ sliced ELL values
@@ -388,7 +429,7 @@ __global__ __launch_bounds__(MK_BLOCK) void sell_fill(int64_t nrows, int64_t nti
     }
 }
 
-// fmt 6: the LDS slots of a tile's nonzeros, entry k of row t at [(k >> 2) * 1024 + 4 t + (k & 3)], 0xffff = padding
+// fmt 6: the LDS slots of a tile's nonzeros, entry k of row t at [(k >> 2) * 1024 + 4 t + (k & 3)]
 __global__ __launch_bounds__(MK_BLOCK) void sell_fill_slots(int64_t nrows, int64_t ntiles, const int32_t *__restrict__ ip,
                                                             const uint16_t *__restrict__ sl, const int32_t *__restrict__ sdesc,
                                                             uint16_t *__restrict__ sslot) {
@@ -400,7 +441,8 @@ __global__ __launch_bounds__(MK_BLOCK) void sell_fill_slots(int64_t nrows, int64
         const int64_t r = tile * MK_ROWS_PER_TILE + t;
         const int lo = (r < nrows) ? ip[r] : 0, len = (r < nrows) ? ip[r + 1] - lo : 0;
         const int w4 = (w + 3) & ~3;
-        for (int k = 0; k < w4; ++k) sb[(int64_t)(k >> 2) * 1024 + 4 * t + (k & 3)] = (k < len) ? sl[lo + k] : (uint16_t)0xffffu;
+        // (indices into the kernel's LDS counted from its 256 zeros: real slots + 256, padding = the lane's zero cell)
+        for (int k = 0; k < w4; ++k) sb[(int64_t)(k >> 2) * 1024 + 4 * t + (k & 3)] = (k < len) ? (uint16_t)(sl[lo + k] + 256) : (uint16_t)t;
     }
 }
 
@@ -464,6 +506,8 @@ void plan_free(MkPlan &P) {
     hipFree(P.d_sval);
     hipFree(P.d_sdesc);
     hipFree(P.d_sslot);
+    hipFree(P.d_ptab);
+    hipFree(P.d_pinfo);
     P = MkPlan();
 }
 
@@ -710,13 +754,38 @@ bool pattern_plan(const mk_csr *A, MkPlan &P, bool raw) {
     hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_keys);
     for (int mode = 0; mode < 2; ++mode)
         hipLaunchKernelGGL(pat_assign, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, P.d_wg, cmax,
-                           words, P.d_slots, pmax, count, d_keys, d_pid, d_pat, d_plen, mode, d_state);
+                           words, P.d_slots, pmax, count, d_keys, d_pid, d_pat, d_plen, mode, P.wide ? 0xff00u : 0u, d_state);
     why = "verification against the table";
     if (hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess || h_state[1])
         return cleanup();
     why = "padding of the value blocks";
     if (raw && !sell_build(A, P, P.wide ? 4 : 2, false)) return cleanup();
+    if (P.wide) {                                            // fmt 8: the table as {offset, value} entries; fmt 7: offsets
+        why = "pattern table";
+        void *d_ptab = nullptr;
+        int32_t *d_pinfo = nullptr;
+        const size_t tbytes = sizeof(PatEntryHost) * (size_t)(count * (pmax < 16 ? 16 : pmax) + 64);
+        bool ok = hipMalloc(&d_ptab, tbytes) == hipSuccess &&
+                  hipMalloc((void **)&d_pinfo, sizeof(int32_t) * 256) == hipSuccess;
+        if (ok) {
+            hipMemsetAsync(d_ptab, 0, tbytes, st);
+            if (raw)
+                hipLaunchKernelGGL(poff_build, dim3(4), dim3(MK_BLOCK), 0, st, count, pmax, d_pat, d_plen,
+                                   static_cast<int32_t *>(d_ptab), d_pinfo);
+            else
+                hipLaunchKernelGGL(ptab_build, dim3(4), dim3(MK_BLOCK), 0, st, count, pmax, d_pat, d_plen, P.d_dict,
+                                   static_cast<PatEntryHost *>(d_ptab), d_pinfo);
+            ok = hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+        }
+        if (!ok) {
+            hipFree(d_ptab);
+            hipFree(d_pinfo);
+            return cleanup();
+        }
+        P.d_ptab = d_ptab;
+        P.d_pinfo = d_pinfo;
+    }
     why = "";
     P.d_pid = d_pid;
     P.d_pat = d_pat;

@@ -124,6 +124,8 @@ struct MkPlan {
     bool wide = false;
     uint16_t *d_sslot = nullptr;
     int64_t slot_entries = 0;      // uint16 in d_sslot
+    void *d_ptab = nullptr;        // fmt 8: the pattern table as {offset, value} entries, read through the scalar cache
+    int32_t *d_pinfo = nullptr;    // ... and per pattern {entries | position of the diagonal << 8}
     // fmt 3 (resident tiles, column phases): plain CSR arrays, only launch parameters
     int rt_cap = 0;                // LDS capacity per tile in nonzeros (max tile stream length rounded up to 256)
     int rt_k = 1;                  // column phases

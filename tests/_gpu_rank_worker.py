@@ -102,6 +102,26 @@ def main():
                                               x_err=float(np.linalg.norm(x - r["x"]) / np.linalg.norm(r["x"])))
         op.free()
 
+    # ---- CG on a partitioned 27-point operator: every rank's slab takes a wide storage format (rows of 27 entries),
+    # interior / boundary launches and the halo windows included
+    S = csr_ref.stencil27(64, 12, 9, seed=5)
+    ns = S.shape[0]
+    rhs_s = S.matvec(np.ones(ns))
+    refc = kr.cg(S, rhs_s, reltol=1e-9)
+    for mode in ("halo", "allgather"):
+        op, ranges = dist.partition_host_csr(world, S.indptr, S.indices, S.data, ns, mode=mode)
+        c0, c1 = ranges[rank]
+        fmt = ctypes.c_int32()
+        _lib.check(_lib.load().mk_csr_format_info(op.handle, ctypes.byref(fmt), None, None, None, None))
+        s = CG(op, reltol=1e-9)
+        s.solve(rhs_s[c0:c1])
+        x = gather_x(world, s.x)
+        out["cg27/" + mode] = dict(nMatvec=int(s.nMatvec), ref=int(refc["nMatvec"]),
+                                   hist_err=rel_hist_err(s.residHistory, refc["residHistory"]),
+                                   x_err=float(np.linalg.norm(x - refc["x"]) / np.linalg.norm(refc["x"])),
+                                   fmt=int(fmt.value))
+        op.free()
+
     # ---- MINRES / SYMMLQ on a partitioned 2-D Laplacian
     mm = 43
     C = csr_ref.poisson2d(mm)
