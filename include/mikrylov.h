@@ -168,11 +168,19 @@ int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn, void *
  *   4  format 2 + row patterns: when the rows of the windowed tiles follow <= 256 distinct sequences of
  *      {LDS slot - lane, dictionary index} words (stencils), ONE BYTE per row names its sequence and nothing is read
  *      per nonzero;
+ *   5  format 1's windows + row patterns for matrices WITHOUT a dictionary (variable-coefficient stencils): one byte
+ *      per row names its sequence of LDS slots, the values are streamed in tile-sliced ELL order (8 bytes per nonzero);
+ *   6, 7, 8  the wide twins for rows of up to 32 entries (tiles of up to 8192 nonzeros in 32 window chunks), chosen when
+ *      the cover of formats 1 .. 5 (16 chunks, 2048 nonzeros) reaches less than half of the tiles: 8 = dictionary + row
+ *      patterns (one byte per row), 7 = row patterns + streamed values, 6 = uint16 slots + values both streamed in
+ *      tile-sliced ELL order (10 bytes per nonzero; needs neither patterns nor a dictionary).  6 or 7 asked for
+ *      explicitly are also applied to matrices formats 1 .. 5 would have served;
  *   3  plain CSR for matrices without a window cover whose x is longer than an L2: the tile's stream is held in LDS
  *      and the gathers of all workgroups walk x slice by slice (same arrays as format 0).
- * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 4; format 3 is chosen automatically for scattered
- * matrices with more than 5 MiB of x).  A request the matrix does not qualify for degrades silently
- * (4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the gather path of format 0.
+ * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 8 = the most compact format the matrix qualifies for;
+ * format 3 is chosen automatically for scattered matrices with more than 5 MiB of x).  A request is an upper bound and
+ * degrades silently (8 -> 7 -> 6 -> 0, 5 -> 1, 4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the
+ * gather path of format 0.
  * mk_csr_format_info reports what is in use: the format, the number of windowed tiles, the LDS chunks (128
  * doubles each) a workgroup reserves (format 3: the number of column phases), the dictionary size and the bytes of
  * matrix data (everything except x and y) one product streams. */

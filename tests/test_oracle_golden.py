@@ -442,3 +442,36 @@ def test_round3_reduced_and_block_operators_host_composition(golden):
                     etol=0.0, rtol=1e-10)
     assert (out["istop"], out["itn"]) == (int(d["sp_minres_istop"]), int(d["sp_minres_itn"]))
     assert same(out["residHistory"], d["sp_minres_hist"]) and same(out["x"], d["sp_minres_x"])
+
+
+def test_stencil27_twin_against_a_brute_force_construction():
+    """The 27-point test operator of the wide storage formats (no reference counterpart beyond "a user's matvec"):
+    the vectorised NumPy twin against three nested loops, constant and variable coefficients."""
+    from oracle import csr_ref
+    for (mx, my, mz), seed in (((4, 3, 5), 0), ((3, 4, 2), 9), ((1, 1, 6), 2), ((5, 1, 1), 0)):
+        A = csr_ref.stencil27(mx, my, mz, seed=seed)
+        n = mx * my * mz
+        k = csr_ref.cell_field(np.arange(n), seed) if seed else np.ones(n)
+        D = np.zeros((n, n))
+        for z in range(mz):
+            for y in range(my):
+                for x in range(mx):
+                    r = (z * my + y) * mx + x
+                    diag = 0.0
+                    for dz in (-1, 0, 1):
+                        for dy in (-1, 0, 1):
+                            for dx in (-1, 0, 1):
+                                if (dz, dy, dx) == (0, 0, 0):
+                                    continue
+                                inside = 0 <= z + dz < mz and 0 <= y + dy < my and 0 <= x + dx < mx
+                                c = r + (dz * my + dy) * mx + dx
+                                h = k[r]
+                                if inside and seed:
+                                    h = ((2.0 * k[r]) * k[c]) / (k[r] + k[c])
+                                diag = diag + h
+                                if inside:
+                                    D[r, c] = -h
+                    D[r, r] = diag
+        assert np.array_equal(A.to_dense(), D)
+        assert np.array_equal(D, D.T) and np.linalg.eigvalsh(D).min() > 0
+        assert np.all(np.diff(A.indices[A.indptr[0]:A.indptr[1]]) > 0)

@@ -28,7 +28,12 @@ ref = None
 print("workload %s: %d rows, %d nonzeros" % (wl, n, op.nnz))
 for f in fmts:
     _lib.check(lib.mk_csr_set_format(op.handle, f))
-    op.spmv_device(x.ptr, y.ptr)
+    import time
+    _lib.check(lib.mk_sync())
+    t0 = time.perf_counter()
+    op.spmv_device(x.ptr, y.ptr)                # (first product: builds the format)
+    _lib.check(lib.mk_sync())
+    t_build = time.perf_counter() - t0
     yh = y.to_numpy()
     if ref is None:
         ref = yh
@@ -41,7 +46,7 @@ for f in fmts:
     _lib.check(lib.mk_solver_time_spmv(run.handle, 40, ctypes.byref(avg)))
     total = by.value + 16 * n
     print("  want %2d -> fmt %d  windowed tiles %d  chunks %d  dict %d  matrix bytes %.3f GB  spmv %9.1f us  physical %.2f TB/s  "
-          "CSR-equivalent %.2f TB/s  bits %s" % (f, fmt.value, tw.value, ch.value, nd.value, by.value / 1e9, avg.value,
+          "CSR-equivalent %.2f TB/s  build %.0f ms  bits %s" % (f, fmt.value, tw.value, ch.value, nd.value, by.value / 1e9, avg.value,
                                                   total / avg.value / 1e6, (12 * op.nnz + 4 * n + 16 * n) / avg.value / 1e6,
-                                                  "same" if same else "DIFFER"), flush=True)
+                                                  t_build * 1e3, "same" if same else "DIFFER"), flush=True)
     del run
