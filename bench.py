@@ -79,7 +79,7 @@ def kernel_source_sha():
     """Fingerprint of the SpMV kernel sources: PMC traffic figures under profiles/ are only quoted while it matches."""
     h = hashlib.sha256()
     for f in ("mk_device.h", "mk_format.hip", "mk_internal.h", "mk_spmv_fmt0.h", "mk_spmv_fmt1.h", "mk_spmv_fmt24.h",
-              "mk_spmv_fmt3.h", "mk_spmv_fmt5.h"):
+              "mk_spmv_fmt3.h", "mk_spmv_fmt5.h", "mk_spmv_fmtw.h"):
         with open(os.path.join(ROOT, "pykrylov_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -513,6 +513,8 @@ def main():
         inloop_us = 1e3 * tm["spmv_ms"] / tm["spmv_launches"] if tm["spmv_launches"] else None
         stencil = info["meta"]["stencil"]
         nnz_global = stencil * n_g - 2 * sum(n_g // g for g in info["meta"]["grid"])
+        if stencil == 27:
+            nnz_global = int(np.prod([3 * g - 2 for g in info["meta"]["grid"]]))
         its = steps / info["elapsed"]
         fmt = info["fmt"]
         # bytes this kernel has to stream: the matrix in its storage format + x once + y once (nothing for the fused
@@ -612,6 +614,8 @@ def main():
         others = [("poisson2d-1000", 2000, 200)]
         if name.endswith("-varcoef"):
             others.insert(0, ("poisson3d-512", max(100, args.steps // 2), max(10, args.warmup // 2)))
+            # rows of 27 entries (HPCG's sparsity): the wide storage formats, constant and variable coefficients
+            others += [("stencil27-256", 400, 40), ("stencil27-256-varcoef", 200, 20)]
         for wname, st, wu in others:
             exi = run_cg(wname, st, wu, 0)
             e_its, e_nnz, e_roof, e_it = roofline_of(exi, wname)
@@ -622,6 +626,10 @@ def main():
             extra["poisson3d-512@1"]["note"] = ("constant-coefficient special case of the headline workload: rows AND "
                                                 "values compress to one byte per row (format 4), so the product moves "
                                                 "a fraction of the CSR bytes; its roofline is priced at those bytes")
+        for k27 in ("stencil27-256@1", "stencil27-256-varcoef@1"):
+            if k27 in extra:
+                extra[k27]["note"] = ("not a BASELINE config: the 27-point box stencil (4.5e8 nonzeros), the matrix class "
+                                      "of storage formats 6 / 7 / 8; CSR gathers take 1.25-1.36 ms per product here")
         extra.update(other_configs(lib))
         line["extra"] = extra
     if rank == 0:

@@ -14,6 +14,8 @@ from pmc_summary2 import counters, report, trace  # noqa: E402
 WORKLOADS = [("varcoef", "poisson3d-512-varcoef@1", "CG, 512^3 variable coefficients (the default line's workload)"),
              ("const", "poisson3d-512@1", "CG, 512^3 constant coefficients"),
              ("p2d", "poisson2d-1000@1", "CG, 2-D n = 1e6"),
+             ("s27c", "stencil27-256@1", "CG, 27-point stencil 256^3, constant coefficients (format 8)"),
+             ("s27v", "stencil27-256-varcoef@1", "CG, 27-point stencil 256^3, variable coefficients (format 7)"),
              ("others", None, "BiCGSTAB random n = 1e6 and MINRES shifted 2-D n = 4e6")]
 
 
@@ -35,6 +37,8 @@ def main():
                 ent = {"bytes": int(c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024),
                        "read_bytes": int(c["FETCH_SIZE"] * 2048), "written_bytes": int(c["WRITE_SIZE"] * 1024),
                        "format": 5 if fmt == 6 else fmt, "kernel": k, "avg_us_in_trace": dur.get(k)}
+                if key and key.startswith("stencil27"):      # (template values 7 / 8 -> formats 7 / 8)
+                    ent["format"] = fmt
                 if key and "CgSpmvEpi" in k:
                     traffic[key] = ent
                 elif not key:

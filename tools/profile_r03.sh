@@ -15,13 +15,15 @@ CMD[varcoef]="--workload poisson3d-512-varcoef --no-extra --no-cpu"
 CMD[const]="--workload poisson3d-512 --no-extra --no-cpu"
 CMD[p2d]="--workload poisson2d-1000 --no-extra --no-cpu"
 CMD[others]="--only-other-configs"
-for w in varcoef const p2d others; do
+CMD[s27c]="--workload stencil27-256 --no-extra --no-cpu"
+CMD[s27v]="--workload stencil27-256-varcoef --no-extra --no-cpu"
+for w in varcoef const p2d s27c s27v others; do
   steps="--steps 300 --warmup 20"; [ $w = p2d ] && steps="--steps 2000 --warmup 100"
   rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_$w -o b -- python $R/bench.py ${CMD[$w]} $steps > $OUT/bench_trace_$w.json 2> $OUT/trace_$w.err
 done
 # the driver's command itself (one process, every workload): the judged kernel-stats file
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_default -o b -- python $R/bench.py --no-cpu > $OUT/bench_trace_default.json 2> $OUT/trace_default.err
-for w in varcoef const p2d others; do
+for w in varcoef const p2d s27c s27v others; do
   steps="--steps 40 --warmup 5 --spmv-launches 10"; [ $w = p2d ] && steps="--steps 300 --warmup 20 --spmv-launches 20"
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" \
