@@ -254,3 +254,24 @@ def test_lsqr_on_a_wide_rectangular_operator():
     assert itn == ref["itn"] and istop == ref["istop"]
     assert np.linalg.norm(x - ref["x"]) <= 1e-11 * np.linalg.norm(ref["x"])
     op.free()
+
+
+def test_fuzz_over_grid_shapes():
+    """27-point operators on grids of every aspect ratio (lines shorter and longer than a tile, single planes, single
+    lines), constant and variable coefficients: whatever format the builder settles on, the scalar loop's bits."""
+    from pykrylov_amd import gallery
+    rng = np.random.default_rng(21)
+    shapes = [(int(a), int(b), int(c)) for a, b, c in zip(rng.integers(2, 90, 10), rng.integers(1, 30, 10), rng.integers(1, 12, 10))]
+    shapes += [(256, 3, 2), (255, 2, 2), (257, 2, 1), (512, 2, 2), (1, 1, 300), (2, 129, 3), (1024, 1, 1), (100, 100, 1)]
+    seen = set()
+    for k, (mx, my, mz) in enumerate(shapes):
+        seed = 0 if k % 2 else mx + my
+        A = csr_ref.stencil27(mx, my, mz, seed=seed)
+        op = gallery.stencil27(mx, my, mz, seed=seed)
+        seen.add(fmt_info(op)["fmt"])
+        x = rng.standard_normal(A.shape[1])
+        assert np.array_equal((op * x).view(np.int64), A.matvec(x).view(np.int64)), (mx, my, mz, seed, fmt_info(op))
+        T = op.T
+        assert np.array_equal((T * x).view(np.int64), A.rmatvec(x).view(np.int64)), (mx, my, mz, seed)
+        op.free()
+    assert seen & {7, 8}, seen
