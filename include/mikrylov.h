@@ -71,6 +71,10 @@ int mk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const int32_t *indp
                   const int32_t *indices_host, const double *data_host, mk_csr **out);
 int mk_csr_destroy(mk_csr *A);
 int mk_csr_shape(const mk_csr *A, int64_t *nrows, int64_t *ncols, int64_t *nnz);
+/* Smallest and largest stored column index (2147483647 / -1 without entries), found on the device: the range check
+ * a binding applies to a matrix built from caller arrays (the reference has none: its operator wraps a callable,
+ * linop/linop.py:114; an out-of-range column would read outside x). */
+int mk_csr_col_range(const mk_csr *A, int32_t *min_col, int32_t *max_col);
 /* Canonical CSR from coordinate triples (host arrays, borrowed), built on the device: the on-disk side of the
  * path -- MatrixMarket coordinate files (examples/1138bus.mtx, jpwh_991.mtx; examples/demo_common.py:12-16 used
  * Pysparse for this) and the reference's CoordLinearOperator (linop.py:638-685).  Columns sorted per row,

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "mk_csr_create_block": (ctypes.c_int, [c_i32, c_i32, P(c_vp), P(c_i64), P(c_i64), P(c_vp)]),
     "mk_csr_create_callback": (ctypes.c_int, [c_i64, c_i64, MATVEC_FN, c_vp, ctypes.c_int, P(c_vp)]),
     "mk_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),
+    "mk_csr_col_range": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
     "mk_csr_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "mk_csr_from_coo": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),
     "mk_csr_transpose": (ctypes.c_int, [c_vp, P(c_vp)]),

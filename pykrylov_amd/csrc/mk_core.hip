@@ -1,6 +1,9 @@
 // mk_core.hip -- context, memory, CSR container, standalone SpMV / BLAS-1 entry points and
 // the on-device matrix generators of libmikrylov (C ABI in include/mikrylov.h).
 #include <stdarg.h>
+#include <string.h>
+#include <atomic>
+#include <thread>
 
 #include "mk_solver.h"
 
@@ -68,10 +71,13 @@ extern "C" int mk_init(int device) {
     return MK_OK;
 }
 
+static void mk_stager_release();                            // (staged host copies, below)
+
 extern "C" int mk_shutdown(void) {
     MkContext &c = mk_ctx();
     if (!c.ready) return MK_OK;
     hipStreamSynchronize(c.stream);
+    mk_stager_release();
     hipFree(g_halt0);
     g_halt0 = nullptr;
     hipFree(c.d_scratch);
@@ -115,22 +121,120 @@ extern "C" int mk_free(void *dptr) {
     return MK_OK;
 }
 
+// Large transfers between PAGEABLE host arrays (NumPy's) and the device.  hipMemcpy stages such a copy through
+// pinned memory on one thread: 10-12 GB/s measured here (tools/setup_time.py), a second for the CSR arrays of a 512^3
+// matrix.  Above 64 MiB the copy is cut into 16 MiB pieces that MK_COPY_THREADS (default 4) workers take in turn,
+// each with its own pinned buffer and stream: host memcpy of one piece overlaps the DMA of the others.  Synchronous:
+// the solver stream is drained first (the device side of the copy may be in use) and every worker waits for its own
+// pieces, so on return the data is where it should be.
+namespace {
+constexpr size_t MK_COPY_PIECE = (size_t)16 << 20;
+constexpr int MK_COPY_MAXT = 8;
+struct MkStager {
+    void *pin[MK_COPY_MAXT] = {};
+    hipStream_t st[MK_COPY_MAXT] = {};
+    int n = -1;                                              // -1: not tried yet, 0: unavailable
+};
+MkStager g_stager;
+
+int stager_threads() {
+    if (g_stager.n >= 0) return g_stager.n;
+    const char *e = getenv("MK_COPY_THREADS");
+    int want = e ? atoi(e) : 4;
+    want = want < 0 ? 0 : (want > MK_COPY_MAXT ? MK_COPY_MAXT : want);
+    int got = 0;
+    for (; got < want; ++got) {
+        if (hipHostMalloc(&g_stager.pin[got], MK_COPY_PIECE, hipHostMallocDefault) != hipSuccess) break;
+        if (hipStreamCreateWithFlags(&g_stager.st[got], hipStreamNonBlocking) != hipSuccess) {
+            hipHostFree(g_stager.pin[got]);
+            g_stager.pin[got] = nullptr;
+            break;
+        }
+    }
+    (void)hipGetLastError();
+    g_stager.n = got < 2 ? 0 : got;                          // (one worker would only add a copy)
+    return g_stager.n;
+}
+
+// returns MK_OK, or -1 when the caller should use the plain copy
+int staged_copy(void *dst, const void *src, size_t bytes, bool h2d) {
+    if (bytes < 4 * MK_COPY_PIECE) return -1;
+    const int nt = stager_threads();
+    if (nt == 0) return -1;
+    if (hipStreamSynchronize(mk_ctx().stream) != hipSuccess) return -1;
+    const int dev = mk_ctx().device;
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&](int k) {
+        if (hipSetDevice(dev) != hipSuccess) {
+            failed = 1;
+            return;
+        }
+        for (;;) {
+            const size_t off = next.fetch_add(MK_COPY_PIECE);
+            if (off >= bytes || failed.load()) return;
+            const size_t len = bytes - off < MK_COPY_PIECE ? bytes - off : MK_COPY_PIECE;
+            bool ok;
+            if (h2d) {
+                memcpy(g_stager.pin[k], (const char *)src + off, len);
+                ok = hipMemcpyAsync((char *)dst + off, g_stager.pin[k], len, hipMemcpyHostToDevice, g_stager.st[k]) == hipSuccess &&
+                     hipStreamSynchronize(g_stager.st[k]) == hipSuccess;
+            } else {
+                ok = hipMemcpyAsync(g_stager.pin[k], (const char *)src + off, len, hipMemcpyDeviceToHost, g_stager.st[k]) == hipSuccess &&
+                     hipStreamSynchronize(g_stager.st[k]) == hipSuccess;
+                if (ok) memcpy((char *)dst + off, g_stager.pin[k], len);
+            }
+            if (!ok) failed = 1;
+        }
+    };
+    std::thread th[MK_COPY_MAXT];
+    for (int k = 1; k < nt; ++k) th[k] = std::thread(work, k);
+    work(0);
+    for (int k = 1; k < nt; ++k) th[k].join();
+    if (failed.load()) return mk_fail(MK_ERR_HIP, "staged host copy of %zu bytes failed", bytes);
+    return MK_OK;
+}
+}  // namespace
+
+static void mk_stager_release() {
+    for (int k = 0; k < MK_COPY_MAXT; ++k) {
+        if (g_stager.st[k]) hipStreamDestroy(g_stager.st[k]);
+        if (g_stager.pin[k]) hipHostFree(g_stager.pin[k]);
+    }
+    g_stager = MkStager();
+}
+
+// host -> device on the solver stream; large pageable sources take the staged path.  `sync`: wait for the copy.
+int mk_upload(void *dst, const void *src, size_t bytes, bool sync) {
+    if (!bytes) return MK_OK;
+    const int rc = staged_copy(dst, src, bytes, true);
+    if (rc >= 0) return rc;
+    MK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, mk_ctx().stream));
+    if (sync) MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    return MK_OK;
+}
+
+int mk_download(void *dst, const void *src, size_t bytes, bool sync) {
+    if (!bytes) return MK_OK;
+    const int rc = staged_copy(dst, src, bytes, false);
+    if (rc >= 0) return rc;
+    MK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, mk_ctx().stream));
+    if (sync) MK_HIP(hipStreamSynchronize(mk_ctx().stream));
+    return MK_OK;
+}
+
 extern "C" int mk_memcpy_h2d(void *dst, const void *src, size_t bytes) {
     MK_REQUIRE_INIT();
     if (!bytes) return MK_OK;
     MK_ARG(dst && src);
-    MK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, mk_ctx().stream));
-    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
-    return MK_OK;
+    return mk_upload(dst, src, bytes, true);
 }
 
 extern "C" int mk_memcpy_d2h(void *dst, const void *src, size_t bytes) {
     MK_REQUIRE_INIT();
     if (!bytes) return MK_OK;
     MK_ARG(dst && src);
-    MK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, mk_ctx().stream));
-    MK_HIP(hipStreamSynchronize(mk_ctx().stream));
-    return MK_OK;
+    return mk_download(dst, src, bytes, true);
 }
 
 extern "C" int mk_memcpy_d2d(void *dst, const void *src, size_t bytes) {
@@ -190,8 +294,12 @@ extern "C" int mk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const in
     hipStream_t st = mk_ctx().stream;
     MK_HIP(hipMemcpyAsync(A->d_indptr, indptr, sizeof(int32_t) * (size_t)(nrows + 1), hipMemcpyHostToDevice, st));
     if (nnz) {
-        MK_HIP(hipMemcpyAsync(A->d_indices, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, st));
-        MK_HIP(hipMemcpyAsync(A->d_data, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, st));
+        rc = mk_upload(A->d_indices, indices, sizeof(int32_t) * (size_t)nnz, false);
+        if (rc == MK_OK) rc = mk_upload(A->d_data, data, sizeof(double) * (size_t)nnz, false);
+        if (rc != MK_OK) {
+            mk_csr_destroy(A);
+            return rc;
+        }
     }
     MK_HIP(hipStreamSynchronize(st));
     *out = A;
@@ -492,6 +600,43 @@ extern "C" int mk_csr_shape(const mk_csr *A, int64_t *nrows, int64_t *ncols, int
     return MK_OK;
 }
 
+// smallest and largest stored column index (2147483647 / -1 for a matrix without entries): the range check of a
+// matrix that came from host arrays, done where the arrays already are instead of in two NumPy passes over them
+static __global__ __launch_bounds__(MK_BLOCK) void col_range_kernel(int64_t nnz, const int32_t *__restrict__ idx,
+                                                                    int *__restrict__ minmax) {
+    int lo = 2147483647, hi = -1;
+    for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * MK_BLOCK) {
+        const int c = idx[j];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+    atomicMin(&minmax[0], lo);
+    atomicMax(&minmax[1], hi);
+}
+
+extern "C" int mk_csr_col_range(const mk_csr *A, int32_t *min_col, int32_t *max_col) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr);
+    if (A->comp_kind || A->host_fn) return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_col_range: the operand has no matrix of its own");
+    int h_mm[2] = {2147483647, -1};
+    if (A->nnz > 0) {
+        hipStream_t st = mk_ctx().stream;
+        int *d_mm = nullptr;
+        MK_HIP(hipMalloc((void **)&d_mm, sizeof(h_mm)));
+        bool ok = hipMemcpyAsync(d_mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, st) == hipSuccess;
+        int grid = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
+        grid = grid > 4096 ? 4096 : grid;
+        if (ok) hipLaunchKernelGGL(col_range_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, A->nnz, A->d_indices, d_mm);
+        ok = ok && hipMemcpyAsync(h_mm, d_mm, sizeof(h_mm), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+        hipFree(d_mm);
+        if (!ok) return mk_fail(MK_ERR_HIP, "mk_csr_col_range: device pass failed");
+    }
+    if (min_col) *min_col = h_mm[0];
+    if (max_col) *max_col = h_mm[1];
+    return MK_OK;
+}
+
 extern "C" int mk_csr_download(const mk_csr *A, int32_t *indptr, int32_t *indices, double *data) {
     MK_REQUIRE_INIT();
     MK_ARG(A != nullptr);
@@ -499,10 +644,10 @@ extern "C" int mk_csr_download(const mk_csr *A, int32_t *indptr, int32_t *indice
     hipStream_t st = mk_ctx().stream;
     if (indptr)
         MK_HIP(hipMemcpyAsync(indptr, A->d_indptr, sizeof(int32_t) * (size_t)(A->nrows + 1), hipMemcpyDeviceToHost, st));
-    if (indices && A->nnz)
-        MK_HIP(hipMemcpyAsync(indices, A->d_indices, sizeof(int32_t) * (size_t)A->nnz, hipMemcpyDeviceToHost, st));
-    if (data && A->nnz)
-        MK_HIP(hipMemcpyAsync(data, A->d_data, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost, st));
+    int rc = MK_OK;
+    if (indices && A->nnz) rc = mk_download(indices, A->d_indices, sizeof(int32_t) * (size_t)A->nnz, false);
+    if (rc == MK_OK && data && A->nnz) rc = mk_download(data, A->d_data, sizeof(double) * (size_t)A->nnz, false);
+    if (rc != MK_OK) return rc;
     MK_HIP(hipStreamSynchronize(st));
     return MK_OK;
 }

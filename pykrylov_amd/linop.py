@@ -452,11 +452,12 @@ def _canonical_csr(indptr, indices, data, shape):
     nnz = int(indptr[-1])
     if indices.shape[0] != nnz or np.asarray(data).shape[0] != nnz:
         raise ShapeError('indices/data must have indptr[-1] = %d entries' % nnz)
-    if nnz and (indices.min() < 0 or indices.max() >= shape[1]):
-        raise ValueError('column index out of range')
     if nnz > np.iinfo(np.int32).max or shape[1] > np.iinfo(np.int32).max:
         raise ValueError('matrix too large for int32 indices')
-    return (indptr.astype(np.int32), indices.astype(np.int32),
+    if indices.dtype != np.int32:                            # (wider indices: the range check before they are narrowed;
+        if nnz and (indices.min() < 0 or indices.max() >= shape[1]):   # int32 arrays are checked on the device)
+            raise ValueError('column index out of range')
+    return (indptr.astype(np.int32, copy=False), indices.astype(np.int32, copy=False),
             np.ascontiguousarray(data, dtype=np.float64), nnz)
 
 
@@ -482,6 +483,11 @@ class CsrOperator(LinearOperator):
         h = ctypes.c_void_p()
         _lib.check(lib.mk_csr_create(shape[0], shape[1], nnz, indptr.ctypes.data, indices.ctypes.data,
                                      data.ctypes.data, ctypes.byref(h)))
+        lo, hi = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(lib.mk_csr_col_range(h, ctypes.byref(lo), ctypes.byref(hi)))
+        if nnz and (lo.value < 0 or hi.value >= shape[1]):
+            lib.mk_csr_destroy(h)
+            raise ValueError('column index out of range')
         self._finish_init(h.value, shape, nnz, symmetric, kwargs)
 
     @classmethod
@@ -640,6 +646,12 @@ class CsrOperator(LinearOperator):
         self._xbuf.upload(x)
         _lib.check(self._lib.mk_spmv(self._handle, self._xbuf.ptr, self._ybuf.ptr))
         return self._ybuf.to_numpy()          # a fresh ndarray every call (solvers update it in place)
+
+    def _times_vector(self, x):
+        # (the base class copies what the user's callable returned, linop.py:356-360; the device product already is a
+        # fresh array: one gigabyte less to move per product at 512^3)
+        self._nMatvec += 1
+        return self._matvec(x).astype(np.result_type(self.dtype, x.dtype), copy=False)
 
     def spmv_device(self, x_ptr, y_ptr):
         "y = A x on device pointers (no host traffic); counts as a product."

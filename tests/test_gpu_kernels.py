@@ -334,3 +334,32 @@ def test_transpose_of_a_composed_operator_keeps_its_row_program():
     e = 3.0 * d                                                    # five: host closure, same result
     assert not isinstance(e, CsrOperator)
     assert np.array_equal(e * x, 3.0 * (0.5 * ((2.0 * (A.rmatvec(x) - 1.5 * x)) + 0.25 * x)))
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_out_of_range_columns_are_refused(dtype):
+    """The range check of a matrix built from caller arrays (on the device for int32 indices, before narrowing for
+    wider ones): a column outside x must never reach a kernel."""
+    from pykrylov_amd import CsrOperator
+    indptr = np.array([0, 2, 3], dtype=dtype)
+    data = np.ones(3)
+    for bad in ([0, 3, 1], [-1, 1, 2]):
+        with pytest.raises(ValueError):
+            CsrOperator(indptr, np.array(bad, dtype=dtype), data, (2, 3))
+    op = CsrOperator(indptr, np.array([0, 2, 1], dtype=dtype), data, (2, 3))
+    assert np.array_equal(op * np.array([1.0, 2.0, 4.0]), [5.0, 2.0])
+    op.free()
+
+
+def test_large_host_transfers_take_the_staged_path_and_keep_every_byte():
+    """Transfers above 64 MiB are cut into pieces that several host threads stage through pinned buffers
+    (mk_core.hip): contents and order must survive, for sizes that are not multiples of a piece."""
+    from pykrylov_amd import _lib
+    lib = _lib.init()
+    rng = np.random.default_rng(8)
+    for n in (9_000_001, 8_388_608 + 3):
+        x = rng.standard_normal(n)
+        d = _lib.DeviceArray.from_numpy(x)
+        y = d.to_numpy()
+        assert np.array_equal(x.view(np.int64), y.view(np.int64))
+        del d

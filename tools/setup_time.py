@@ -40,6 +40,14 @@ def main():
     timed("second product from a host vector (2 copies of %d MB)" % (8 * n >> 20), lambda: A * x)
     ip, ix, da = timed("device -> host copy of the CSR arrays", A.to_csr_arrays)
     A.free()
+    from pykrylov_amd import linop as _linop, _lib as _l
+    import ctypes
+    timed("   of which: host-side checks (_canonical_csr)", lambda: _linop._canonical_csr(ip, ix, da, (n, n)))
+    def raw_upload():
+        h = ctypes.c_void_p()
+        _l.check(_l.load().mk_csr_create(n, n, len(ix), ip.ctypes.data, ix.ctypes.data, da.ctypes.data, ctypes.byref(h)))
+        _l.load().mk_csr_destroy(h)
+    timed("   of which: mk_csr_create (allocation + upload of %.1f GB)" % ((ip.nbytes + ix.nbytes + da.nbytes) / 1e9), raw_upload)
     B = timed("CsrOperator(indptr, indices, data): canonical check + upload",
               lambda: CsrOperator(ip, ix, da, (n, n), symmetric=True))
     timed("first product of the uploaded copy", lambda: B * x)
