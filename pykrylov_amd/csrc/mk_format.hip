@@ -9,7 +9,9 @@
 //    neighbours are more than G pairs apart (G = 4, 16, ... until the cover fits); a window is stored as chunks
 //    of 128 doubles, chunk c of a tile belonging to wave c % 4.  A tile is eligible when it has 1..2048 nonzeros
 //    (counted from the 8-aligned start of its stream) and its cover needs <= 16 chunks.  Per nonzero the builder
-//    stores the uint16 position of its x entry in the tile's LDS window buffer.
+//    stores the uint16 position of its x entry in the tile's LDS window buffer.  Matrices this cover does not
+//    reach (rows of more than 8 entries) get the WIDE cover -- 32 chunks, 8192 nonzeros per tile -- and one of the
+//    row-walk formats 6 / 7 / 8 (slots + values, row patterns + values, row patterns + dictionary; plan_build).
 //  * value dictionary: when the whole matrix holds <= 256 distinct values (bit patterns), `data` is replaced
 //    by an 8-bit index into the sorted dictionary, packed with the slot into ONE 32-bit word per nonzero --
 //    constant-coefficient stencils, graph Laplacians,
@@ -954,6 +956,8 @@ int plan_build(const mk_csr *A) {
     if (want >= 7 && pattern_plan(A, P, true)) return MK_OK; // fmt 7
     if (sell_build(A, P, 4, true)) {                         // fmt 6
         P.fmt = 6;
+        hipFree(P.d_slots);                                  // (the kernel reads the slots from their ELL copy)
+        P.d_slots = nullptr;
         return MK_OK;
     }
     plan_free(P);                                            // (too much padding: rows of very different lengths)

@@ -104,7 +104,6 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt5(const MkCsrView &A, const dou
                 }
             }
             const unsigned id = (r < rend) ? (unsigned)A.pid[r] : 0u;       // one byte per row
-            const int w = dcur.sd.y;
             double v[8];
             load_vals(dcur.sd, v);
             load_desc(pos + stride, dnxt);                   // next tile's descriptors go in flight
