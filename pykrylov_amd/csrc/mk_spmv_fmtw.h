@@ -10,10 +10,10 @@
 //
 //   0 (fmt 6)  per nonzero a uint16 LDS slot and the value, both streamed in tile-sliced ELL order: 10 B per nonzero.
 //              Any matrix whose tiles have column sets that fit 32 chunks; no pattern, no dictionary needed.
-//   1 (fmt 7)  per ROW one pattern byte (the row's x positions relative to its lane, table in LDS), values streamed:
-//              8 B per nonzero + 1 B per row.  Variable-coefficient stencils of any width <= 32.
-//   2 (fmt 8)  per ROW one pattern byte, the pattern's words carry {relative slot, value code}: 1 B per row.
-//              Constant-coefficient stencils (HPCG's operator: 27 entries per row from 2 distinct values).
+//   1 (fmt 7)  per ROW one pattern byte (the row's x positions relative to its lane), values streamed: 8 B per nonzero
+//              + 1 B per row.  Variable-coefficient stencils of any width <= 32.
+//   2 (fmt 8)  per ROW one pattern byte, a pattern's entries carry {offset, value}: 1 B per row.  Constant-coefficient
+//              stencils (HPCG's operator: 27 entries per row from 2 distinct values).
 //
 // Layouts (mk_format.hip): values of tile T at sval + 256 * start_T, entry k of row t at [(k >> 1) * 512 + 2 t + (k & 1)]
 // (pairs: one 16-byte load per lane) and, for an odd width, the last column at [(w - 1) * 256 + t]; slots at
@@ -23,11 +23,13 @@
 // lane's number (real slots are stored + 256), padded values are +0.0.  A padded product is +-0.0 * 0.0 and leaves a
 // running sum that started at +0.0 unchanged, bit for bit.
 //
-// Mode 2 reads no per-nonzero data at all, and a tile's rows almost all follow ONE pattern: a wave walks the distinct
-// pattern numbers among its lanes (one, or two in a wave that holds a boundary row) and takes the pattern's entries
-// {byte offset from the lane's cell, value} through the SCALAR cache -- per entry one address add, one LDS read, one
-// multiply, one add.  (The first version read {slot, code} words from an LDS table per lane and picked the value from
-// a second LDS table: 15 vector instructions per entry, 323 us for the 256^3 HPCG operator; see DESIGN.md.)
+// Pattern tables.  A tile's rows almost all follow ONE pattern, so a wave walks the distinct pattern numbers among its
+// lanes (one, or two in a wave that holds a boundary row) and takes a pattern's entries through the SCALAR cache --
+// mode 2: {byte offset from the lane's cell, value}, per entry one address add, one LDS read, one multiply with a
+// scalar operand, one add; mode 1: the offsets alone (two rounds, then lanes that are left read a word table in LDS:
+// waves whose rows follow many patterns must not pay a round each).  (The first version of mode 2 read {slot, code}
+// words from an LDS table per lane and picked the value from a second table: 15 vector instructions per entry, 323 us
+// for the 256^3 HPCG operator against 200 now)
 // fmt 8: a pattern entry as mk_format.hip builds it -- {byte offset of the x value from the lane's own cell, 0, value} --
 // is read as four ints, four entries as sixteen (one s_load_dwordx16)
 typedef int mk_i16 __attribute__((ext_vector_type(16)));
@@ -110,7 +112,8 @@ __device__ __forceinline__ void mk_spmv_tiles_wide(const MkCsrView &A, const dou
             }
             const int w = dcur.sd.y;
             int id = 0;
-            if (mode >= 1) id = (r < rend) ? (int)A.pid[r] : 0;                 // one byte per row
+            if (mode >= 1) id = (r < rend) ? (int)A.pid[r] : 0;                 // one byte per row (loading it one tile
+                                                                                // ahead was tried: no change, 203 us)
             [[maybe_unused]] double v[DICT ? 1 : 32];
             [[maybe_unused]] mk_u2 sl[DICT ? 1 : 8];
             if constexpr (!DICT) {                           // the tile's values: (w >> 1) 16-byte loads + one 8-byte load

@@ -275,3 +275,27 @@ def test_fuzz_over_grid_shapes():
         assert np.array_equal((T * x).view(np.int64), A.rmatvec(x).view(np.int64)), (mx, my, mz, seed)
         op.free()
     assert seen & {7, 8}, seen
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("order", [(0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 4, 0), (4, 2, 16)])
+def test_wide_formats_in_every_tile_order(order, seed):
+    """64 x 64 x 12 grid of the 27-point operator: 192 tiles, 16 per plane.  Products and a whole CG solve, bit for bit
+    the oracle's in the device's summation order, whichever way the tiles are dealt to the workgroups."""
+    from pykrylov_amd import CG, _lib, gallery
+    from oracle import gpu_order, krylov_ref as kr
+    A = csr_ref.stencil27(64, 64, 12, seed=seed)
+    n = A.shape[0]
+    op = gallery.stencil27(64, 64, 12, seed=seed)
+    _lib.check(_lib.init().mk_csr_set_tile_order(op.handle, order[0], order[1], order[2], -1))
+    assert fmt_info(op)["fmt"] == (7 if seed else 8)
+    x = np.random.default_rng(2).standard_normal(n)
+    assert np.array_equal(op * x, A.matvec(x))
+    rhs = A.matvec(np.ones(n))
+    s = CG(op)
+    s.solve(rhs, matvec_max=40)
+    geo = gpu_order.launch_geometry(op)
+    ref = kr.cg(A, rhs, matvec_max=40, red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geo)))
+    assert s.nMatvec == ref["nMatvec"]
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
+    op.free()
