@@ -98,3 +98,34 @@ def test_minres_config4_n4e6_bit_exact_first_500(monkeypatch):
     for name in ("rnorm", "Arnorm", "Anorm", "Acond", "ynorm"):
         assert getattr(s, name) == ref[name], name
     op.free()
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_cg_27_point_160cubed_wide_formats_bit_exact(seed):
+    """The wide storage formats at size: 27-point operator on 160^3 (4.1e6 rows, 1.08e8 nonzeros; formats 8 and 7,
+    16 000 tiles on a multi-step launch).  Product against the oracle's scalar loop, the first 12 CG passes against
+    the oracle run in the device's summation order -- bit for bit -- and against the order-independent anchor."""
+    from pykrylov_amd import CG, gallery, _lib
+    import ctypes
+    m = 160
+    op = gallery.stencil27(m, seed=seed)
+    n = op.shape[0]
+    fmt = ctypes.c_int32()
+    _lib.check(_lib.init().mk_csr_format_info(op.handle, ctypes.byref(fmt), None, None, None, None))
+    assert fmt.value == (7 if seed else 8)
+    A = csr_ref.RefCsr(*op.to_csr_arrays(), (n, n))          # (the generator against its twin: tests/test_gpu_stencil27.py)
+    x = np.random.default_rng(3).standard_normal(n)
+    assert np.array_equal((op * x).view(np.int64), A.matvec(x).view(np.int64))
+    rhs = A.matvec(np.ones(n))
+    geo = gpu_order.launch_geometry(op)
+    assert geo[0] >= 768
+    s = CG(op)
+    s.solve(rhs, matvec_max=12)
+    ref = kr.cg(A, rhs, matvec_max=12, red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geo)))
+    assert s.nMatvec == ref["nMatvec"] == 12
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"]) and np.array_equal(s.x, ref["x"])
+    exact = kr.cg(A, rhs, matvec_max=12, red=kr.Reductions(gpu_order.ExactDots()))
+    h, he = np.array(s.residHistory), exact["residHistory"]
+    assert np.max(np.abs(h - he) / he) <= 1e-12
+    assert np.linalg.norm(s.x - exact["x"]) <= 1e-12 * np.linalg.norm(exact["x"])
+    op.free()
