@@ -15,7 +15,8 @@ namespace {
 
 enum { S_RY0 = 0, S_RY1 = 1, S_THRESH = 2, S_RESID = 3, S_RESID0 = 4, S_PAP = 5, S_ALPHA = 6 };
 
-struct CgSpmvEpi {
+template <bool NTY>
+struct CgSpmvEpiT {
     static constexpr int NACC = 1, SLOT0 = 0;
     const double *p;
     double *Ap;
@@ -24,16 +25,20 @@ struct CgSpmvEpi {
     __device__ double xin(double v) const { return v; }
     __device__ void pre(int64_t r) { pr = p[r]; }          // issued at the top of the tile
     __device__ void row(int64_t r, double s, double *acc) {
-        Ap[r] = s;
+        if constexpr (NTY) __builtin_nontemporal_store(s, Ap + r);
+        else Ap[r] = s;
         acc[0] += pr * s;
     }
+    // (NTY: the product vector goes past the caches -- mk_store_nt, mk_device.h)
     // p is the product's input vector: where the kernel has p[r] at hand (pattern format: the tile's LDS window) it
     // passes it instead of `pre` loading it again -- one stream of n doubles less per product
     __device__ void row_x(int64_t r, double s, double xr, double *acc) {
-        Ap[r] = s;
+        if constexpr (NTY) __builtin_nontemporal_store(s, Ap + r);
+        else Ap[r] = s;
         acc[0] += xr * s;
     }
 };
+using CgSpmvEpi = CgSpmvEpiT<false>;
 
 struct CgUpdateR {
     static constexpr int NACC = 1, SLOT0 = 1;
@@ -218,7 +223,8 @@ struct CgSolver : mk_solver {
     }
 
     int enqueue_spmv_only() override {
-        mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0}, false);
+        if (A && mk_store_nt(A)) mk_launch_spmv(this, d_p, CgSpmvEpiT<true>{d_p, d_Ap, 0.0}, false);
+        else mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0}, false);
         return MK_OK;
     }
 
@@ -226,7 +232,8 @@ struct CgSolver : mk_solver {
         const int par = (int)(it & 1);
         int rc = exchange(d_p);
         if (rc != MK_OK) return rc;
-        mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0});
+        if (A && mk_store_nt(A)) mk_launch_spmv(this, d_p, CgSpmvEpiT<true>{d_p, d_Ap, 0.0});
+        else mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0});
         if ((rc = allreduce(0, 1)) != MK_OK) return rc;
         mk_launch_stream(this, CgUpdateR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_Ap, d_r,
                                          d_prec, 0.0, false}, n);

@@ -117,11 +117,20 @@ static inline bool mk_tile_map4_ok(const mk_csr *A) {
     const int P = mk_tile_plane(A), S = mk_tile_stripe(A);
     return P > 0 && S > 0 && A->ntiles % P == 0 && P % (8 * S) == 0;
 }
+// Non-temporal accesses of a product: the value stream of fmt 5 / 6 / 7 (read once) and the product vector (written once)
+// go past the caches so that the x windows stay in the L2.  Default: on when a vector is larger than the Infinity Cache
+// (256 MiB).  Measured in one process each (tools/ab_spmv.py, AB_NT_Y): 512^3, variable coefficients 1 768 -> 1 711 us
+// with the loads, 1 730 with the stores, 1 639 with both, CG pass 3.40 -> 3.27 ms; constant coefficients (fmt 4, stores
+// only) 808 -> 768 us.  At 256^3 (134 MB per vector: the update kernel that reads the product finds it in the cache,
+// and the caches hold a good part of the pass's working set) the 27-point product gains 5 % and the CG pass LOSES
+// 3-7 %, with the stores, the loads or both: off there.
 static inline int mk_stream_nt(const mk_csr *A) {
     static const char *env = getenv("MK_SPMV_NT");
     if (mk_owner(A)->want_nt >= 0) return mk_owner(A)->want_nt;
-    return env ? atoi(env) : 0;
+    if (env) return atoi(env);
+    return (!A->comp_kind && !A->host_fn && 8 * A->nrows > (int64_t)256 * 1024 * 1024) ? 1 : 0;
 }
+static inline int mk_store_nt(const mk_csr *A) { return mk_stream_nt(A); }
 static inline int mk_tile_map(const mk_csr *A) {
     if (A->comp_kind >= 4) return 0;
     if (A->comp_kind) return mk_tile_map(A->comp_kind == 3 ? A->comp_a : A->comp_b);
@@ -516,7 +525,8 @@ __device__ __forceinline__ void mk_load_meta(const MkCsrView &A, int64_t p, int6
 #include "mk_spmv_fmtw.h"
 
 constexpr int MK_FMT_WIDE = 7;                       // template values of the wide kernels (6 = format 5, non-temporal):
-constexpr int MK_FMT_WIDE_DICT = 8;                  // 7 streams values (fmt 6, 7), 8 takes them from the dictionary (fmt 8)
+constexpr int MK_FMT_WIDE_DICT = 8;                  // 7 streams values (fmt 6, 7), 8 takes them from the dictionary (fmt 8),
+constexpr int MK_FMT_WIDE_NT = 9;                    // 9 = 7 with non-temporal loads of the streams
 
 template <int FMT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
@@ -524,7 +534,8 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     if constexpr (FMT == 0) mk_spmv_tiles_fmt0<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 1) mk_spmv_tiles_fmt1<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 3) mk_spmv_tiles_fmt3<PROG>(A, x, epi, prod, xw, acc);
-    else if constexpr (FMT == MK_FMT_WIDE || FMT == MK_FMT_WIDE_DICT) mk_spmv_tiles_wide<FMT == MK_FMT_WIDE_DICT, PROG>(A, x, epi, prod, xw, acc);
+    else if constexpr (FMT == MK_FMT_WIDE || FMT == MK_FMT_WIDE_DICT || FMT == MK_FMT_WIDE_NT)
+        mk_spmv_tiles_wide<FMT == MK_FMT_WIDE_DICT, FMT == MK_FMT_WIDE_NT, PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT >= 5) mk_spmv_tiles_fmt5<PROG, FMT == 6>(A, x, epi, prod, xw, acc);
     else mk_spmv_tiles_fmt24<FMT, PROG>(A, x, epi, prod, xw, acc);
 }
@@ -537,7 +548,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : (FMT == 7 ? 4 : (FMT >= 4 ? 7 : 4))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
@@ -622,6 +633,9 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         lds = sizeof(double) * (wtop + MK_BLOCK) + 4 * (size_t)((v.fmt == 7 ? v.npat * v.pmax : 0) + 4);
         if (v.fmt == 8)
             hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_WIDE_DICT>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
+                               epi, gate, halt, partials);
+        else if (v.nt)
+            hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_WIDE_NT>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
                                epi, gate, halt, partials);
         else
             hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_WIDE>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi,

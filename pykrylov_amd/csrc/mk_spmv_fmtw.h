@@ -35,7 +35,8 @@
 typedef int mk_i16 __attribute__((ext_vector_type(16)));
 
 // DICT: the instantiation for mode 2, which holds no values in registers (twice the occupancy of the streaming one).
-template <bool DICT, bool PROG, class Epi, int NACC>
+// NT: values and slots, read once per product, are loaded non-temporally (mk_stream_nt: matrices beyond the caches).
+template <bool DICT, bool NT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles_wide(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
         double *prod, double *smem, double (&acc)[NACC]) {
     const int tid = threadIdx.x;
@@ -123,11 +124,12 @@ __device__ __forceinline__ void mk_spmv_tiles_wide(const MkCsrView &A, const dou
                     v[2 * q] = 0.0;
                     v[2 * q + 1] = 0.0;
                     if (2 * q + 1 < w) {
-                        const mk_d2 pr = *reinterpret_cast<const mk_d2 *>(vb + q * 512 + 2 * tid);
+                        const mk_d2 pr = NT ? __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(vb + q * 512 + 2 * tid))
+                                            : *reinterpret_cast<const mk_d2 *>(vb + q * 512 + 2 * tid);
                         v[2 * q] = pr.x;
                         v[2 * q + 1] = pr.y;
                     } else if (2 * q < w) {
-                        v[2 * q] = vb[2 * q * 256 + tid];
+                        v[2 * q] = NT ? __builtin_nontemporal_load(vb + 2 * q * 256 + tid) : vb[2 * q * 256 + tid];
                     }
                 }
                 if (mode == 0) {                             // ... and their LDS slots, four to a load
@@ -135,7 +137,9 @@ __device__ __forceinline__ void mk_spmv_tiles_wide(const MkCsrView &A, const dou
 #pragma unroll
                     for (int h = 0; h < 8; ++h) {
                         sl[h] = mk_u2{0u, 0u};
-                        if (4 * h < w) sl[h] = *reinterpret_cast<const mk_u2 *>(sb + h * 1024 + 4 * tid);
+                        if (4 * h < w)
+                            sl[h] = NT ? __builtin_nontemporal_load(reinterpret_cast<const mk_u2 *>(sb + h * 1024 + 4 * tid))
+                                       : *reinterpret_cast<const mk_u2 *>(sb + h * 1024 + 4 * tid);
                     }
                 }
             }

@@ -10,8 +10,9 @@ from pykrylov_amd.generic import DeviceRun
 lib = _lib.init(0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "varcoef"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-m = 512
-op = gallery.poisson3d_varcoef(m) if wl == "varcoef" else gallery.poisson3d(m)
+m = 256 if wl.startswith("s27") else 512
+op = {"varcoef": lambda: gallery.poisson3d_varcoef(m), "const": lambda: gallery.poisson3d(m),
+      "s27v": lambda: gallery.stencil27(m, seed=7), "s27c": lambda: gallery.stencil27(m, seed=0)}[wl]()
 n = op.shape[0]
 ones = _lib.DeviceArray.from_numpy(np.ones(n))
 rhs = _lib.DeviceArray(n)
@@ -30,10 +31,13 @@ if True:
     for S in (8, 16, 32, 64):
         variants += [("order4 S=%d" % S, (4, S, P, 0)), ("order4 S=%d +nt" % S, (4, S, P, 1))]
     variants += [("order3 S=128 +nt", (3, 128, 0, 1)), ("order0 +nt", (0, 0, 0, 1))]
+if os.environ.get("AB_NT_Y"):                      # non-temporal loads of the value stream + stores of the product vector
+    variants = [("order2", (2, 0, 0, 0)), ("order2+nt", (2, 0, 0, 1)), ("order4 S=32", (4, 32, P, 0)), ("order4 S=32 +nt", (4, 32, P, 1))]
+variants = [(nm, par + (0,)) for nm, par in variants]
 res = {k: [] for k, _ in variants}
 step = {k: [] for k, _ in variants}
 for r in range(rounds):
-    for name, (o, s, p, nt) in variants:
+    for name, (o, s, p, nt, nty) in variants:
         _lib.check(lib.mk_csr_set_tile_order(op.handle, o, s, p, nt))
         avg = ctypes.c_double()
         _lib.check(lib.mk_solver_time_spmv(run.handle, 60, ctypes.byref(avg)))
