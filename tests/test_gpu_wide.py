@@ -170,15 +170,17 @@ def test_ragged_rows_are_refused():
 
 
 @pytest.mark.parametrize("seed", [0, 7])
-def test_minres_row_x_hook_in_the_wide_formats(seed, monkeypatch):
+@pytest.mark.parametrize("shape", [(128, 10, 5), (20, 20, 16), (7, 40, 23)])
+def test_minres_row_x_hook_in_the_wide_formats(shape, seed, monkeypatch):
+    """(short lines: a wave's rows follow three and more patterns -- the rounds of the scalar path and its LDS fallback,
+    each with the diagonal cell handed to the epilogue)"""
     from pykrylov_amd import Minres, gallery
     from oracle import gpu_order, krylov_ref as kr
     monkeypatch.setattr(kr, "_sq", lambda a: a * a)
-    shape = (128, 10, 5)
     A = csr_ref.stencil27(*shape, seed=seed)
     n = A.shape[0]
     op = gallery.stencil27(*shape, seed=seed)
-    assert fmt_info(op)["fmt"] == (7 if seed else 8)
+    assert fmt_info(op)["fmt"] in ((7 if seed else 8), 6)    # (7 x 40 x 23: too many patterns for the table -> slots)
     rhs = A.matvec(np.linspace(1.0, 2.0, n))
     s = Minres(op)
     s.solve(rhs, show=False, check=False, etol=0.0, rtol=1e-12, itnlim=40)
