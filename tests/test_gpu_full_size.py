@@ -197,3 +197,28 @@ def test_full_runs_against_the_order_independent_anchor():
             assert abs(s.nMatvec - exact["nMatvec"]) <= max(5, abs(ref["nMatvec"] - exact["nMatvec"]) * 3)
             assert xerr <= max(1e-12, 20 * xblas), (name, xerr, xblas)
         op.free()
+
+
+def test_non_temporal_accesses_are_the_default_beyond_the_infinity_cache(op512):
+    """Value loads of the streaming formats and the CG product's stores go past the caches when a vector is larger than
+    256 MiB (mk_stream_nt, csrc/mk_device.h); smaller problems keep their vectors in the caches.  The products above and
+    the CG runs below therefore exercise the non-temporal instantiations at 512^3."""
+    import ctypes
+    from pykrylov_amd import _lib, gallery
+    lib = _lib.init()
+
+    def nt_of(op):
+        o, s, p, nt = (ctypes.c_int32() for _ in range(4))
+        _lib.check(lib.mk_csr_tile_order(op.handle, ctypes.byref(o), ctypes.byref(s), ctypes.byref(p), ctypes.byref(nt)))
+        return nt.value
+
+    assert nt_of(op512) == 1
+    small = gallery.poisson3d(128)
+    assert nt_of(small) == 0
+    _lib.check(lib.mk_csr_set_tile_order(small.handle, -1, 0, 0, 1))
+    assert nt_of(small) == 1                                  # (an explicit request wins)
+    x = np.random.default_rng(4).standard_normal(small.shape[0])
+    y1 = small * x
+    _lib.check(lib.mk_csr_set_tile_order(small.handle, -1, 0, 0, 0))
+    assert np.array_equal(small * x, y1)
+    small.free()
