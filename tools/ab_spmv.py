@@ -10,7 +10,7 @@ from pykrylov_amd.generic import DeviceRun
 lib = _lib.init(0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "varcoef"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-m = 256 if wl.startswith("s27") else 512
+m = int(os.environ.get("AB_M", "256" if wl.startswith("s27") else "512"))
 op = {"varcoef": lambda: gallery.poisson3d_varcoef(m), "const": lambda: gallery.poisson3d(m),
       "s27v": lambda: gallery.stencil27(m, seed=7), "s27c": lambda: gallery.stencil27(m, seed=0)}[wl]()
 n = op.shape[0]
