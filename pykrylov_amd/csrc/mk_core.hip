@@ -33,13 +33,16 @@ static int env_cap(const char *name, int dflt) {
     if (c < 1) c = 1;
     return c > MK_MAXP ? MK_MAXP : c;
 }
+// (MK_GRID_DYNAMIC: read the overrides at every call -- grid sweeps inside one process, tools/grid_sweep.py)
 int mk_cap_stream() {
+    static const bool dyn = getenv("MK_GRID_DYNAMIC") != nullptr;
     static int c = env_cap("MK_GRID_STREAM", 512);
-    return c;
+    return dyn ? env_cap("MK_GRID_STREAM", 512) : c;
 }
 int mk_cap_spmv() {
+    static const bool dyn = getenv("MK_GRID_DYNAMIC") != nullptr;
     static int c = env_cap("MK_GRID_SPMV", 1024);
-    return c;
+    return dyn ? env_cap("MK_GRID_SPMV", 1024) : c;
 }
 
 extern "C" int mk_version(void) { return MK_VERSION; }
