@@ -210,3 +210,41 @@ def test_cg_config2_n1e6_head_of_trajectory(golden):
     assert rel_hist_err(s.residHistory, d["p2d1000_cg_residHistory_exactdot"]) <= 1e-13
     assert np.max(np.abs(s.x[::997] - d["p2d1000_cg_x_sample"]) / np.abs(d["p2d1000_cg_x_sample"])) <= 1e-11
     assert np.allclose(s.x, 1.0, rtol=0, atol=1e-3)
+
+
+def test_placement_draws_change_nothing_but_the_vectors(monkeypatch):
+    """Large problems draw a few solver objects at set-up and keep the fastest (generic.DeviceRun._draw_placement); the
+    threshold is lowered here so that a small problem goes through it: iteration counts, histories and iterates are
+    bit for bit those of a run without draws, with and without a diagonal preconditioner, and nothing leaks."""
+    import ctypes
+    from pykrylov_amd import CG, DiagonalOperator, gallery
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t))
+        return f.value
+
+    op = gallery.poisson3d_varcoef(40)
+    n = op.shape[0]
+    rhs = op * np.ones(n)
+    dg = 1.0 / np.linspace(5.0, 7.0, n)
+    runs = {}
+    for draws in ("1", "3"):
+        monkeypatch.setenv("MK_PLACEMENT_DRAWS", draws)
+        monkeypatch.setenv("MK_PLACEMENT_MIN_MB", "0")
+        for precon in (None, DiagonalOperator(dg)):
+            s = CG(op, precon=precon) if precon is not None else CG(op)
+            s.solve(rhs, guess=0.5 * np.ones(n))
+            runs[(draws, precon is not None)] = (s.nMatvec, np.array(s.residHistory), s.x.copy())
+    for pre in (False, True):
+        a, b = runs[("1", pre)], runs[("3", pre)]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    import gc
+    gc.collect()
+    before = free_bytes()
+    for _ in range(5):
+        CG(op).solve(rhs)
+    gc.collect()
+    assert abs(free_bytes() - before) < 8 << 20
+    op.free()
