@@ -273,7 +273,8 @@ class DeviceRun(object):
             best_t = self._timed_passes(self.handle)
             for k in range(1, draws):
                 try:
-                    spacers.append(_lib.DeviceArray(((176 + 88 * k) << 20) // 8 + 512 * k, zero=False))
+                    sp_mb = int(os.environ.get('MK_PLACEMENT_SPACER_MB', '176'))
+                    spacers.append(_lib.DeviceArray(((sp_mb + (sp_mb // 2) * k) << 20) // 8 + 512 * k, zero=False))
                     h = ctypes.c_void_p()
                     _lib.check(self.lib.mk_solver_create(self.op.handle, ctypes.byref(self._params), ctypes.byref(h)))
                 except Exception:
