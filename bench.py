@@ -191,6 +191,57 @@ def cpu_baseline_all_cores(name, seconds_budget=9.0):
     return best
 
 
+def host_mem_available_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                return int(ln.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline_full_size(name, passes=4, threads=1):
+    """The CPU oracle MEASURED on the quoted workload itself (poisson3d-512-varcoef: 134 217 728 rows, 9.4e8 nonzeros,
+    11.8 GB of CSR arrays on the host + five 1 GiB vectors): `passes` passes of the reference's CG loop
+    (oracle/krylov_ref.cg: NumPy element-wise updates and np.dot on one thread, the C CSR product on `threads` OpenMP
+    threads) after one untimed pass.  The matrix is written by the C generator twin (oracle/csr_ref.c, pinned bit for bit
+    against the NumPy twin in tests/test_oracle_golden.py).  Runs in a child process so that the 17 GB are returned."""
+    if os.environ.get("BENCH_CHILD") != "full":
+        need = 24.0
+        have = host_mem_available_gb()
+        if have is not None and have < need:
+            return {"value": None, "extrapolated": None,
+                    "skipped": "host MemAvailable %.1f GB < %.0f GB needed for the 512^3 CSR arrays and vectors" % (have, need)}
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS="1", BENCH_CHILD="full")
+        code = ("import json,sys; sys.path.insert(0, %r); import bench; "
+                "print(json.dumps(bench.cpu_baseline_full_size(%r, %d, %d)))" % (ROOT, name, passes, threads))
+        try:
+            out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+            return json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:                               # a baseline must never take the bench line down
+            return {"value": None, "error": repr(e)[:300]}
+    from oracle import csr_ref, krylov_ref
+    m = int(name.split("-")[1])
+    t0 = time.perf_counter()
+    A = csr_ref.poisson3d_varcoef_c(m, seed=VARCOEF_SEED) if name.endswith("-varcoef") else None
+    assert A is not None, "full-size CPU baseline: only the variable-coefficient workload has a C generator"
+    t_gen = time.perf_counter() - t0
+    n = A.shape[0]
+    rhs = A.matvec(np.ones(n))
+    krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=1)          # untimed: first touch of every page
+    t0 = time.perf_counter()
+    out = krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=passes)
+    dt = time.perf_counter() - t0
+    assert out["nMatvec"] == passes and np.isfinite(out["residHistory"][-1])
+    return {"value": passes / dt, "unit": "iterations/s", "cores": threads, "kind": "port", "extrapolated": False,
+            "sample_rows": int(n), "sample_nnz": int(A.nnz), "seconds_per_pass": dt / passes,
+            "matrix_generation_seconds": t_gen,
+            "sample": "%d CG passes of %s itself (%d rows, %d nnz) after 1 untimed pass; NumPy updates and np.dot on one "
+                      "thread, C CSR product on %d OpenMP thread(s)" % (passes, name, n, A.nnz, threads),
+            "host_cpus": os.cpu_count(), "residual_after": float(out["residHistory"][-1])}
+
+
 # ======================================================================================
 # workloads
 # ======================================================================================
@@ -245,101 +296,212 @@ def colblocks(lib, op):
     return k.value
 
 
-def other_configs(lib, passes=400, warm=20):
-    """BASELINE configs[2] and configs[3] on one GPU: loop passes per second with the tolerances at zero so that exactly
-    `passes` passes run, the product kernel timed alone, and PHYSICAL rooflines: bytes the kernels have
-    to move in the storage format in use.  The reference-op-count figures are reported beside them as
-    throughputs in CSR units, not as fractions."""
+LOOP_BYTES = {
+    # bytes per pass BEYOND the products (each product priced at matrix data of its storage format + input once + output
+    # once), counted from the fused kernels of csrc/mk_*.hip; m = rows, n = columns of A
+    "bicgstab": lambda m, n: 136 * n, "cgs": lambda m, n: 128 * n, "tfqmr": lambda m, n: 256 * n,
+    "minres": lambda m, n: 96 * n, "symmlq": lambda m, n: 88 * n,
+    "lsqr": lambda m, n: 24 * m + 56 * n, "lsmr": lambda m, n: 24 * m + 72 * n,
+    "craig": lambda m, n: 64 * m + 72 * n, "craigmr": lambda m, n: 80 * m + 24 * n,
+}
+REF_LOOP_BYTES = {   # the reference's own op count per pass beyond the products, square solvers
+    "bicgstab": 224, "cgs": 232, "tfqmr": 368, "minres": 176, "symmlq": 168}
+
+
+def random_tall_csr(m, n, k=5, seed=11):
+    """Seeded m x n matrix with k entries per row for the least-squares loops: entry j of a row lies at a uniformly random
+    column of the j-th of k equal column ranges (so columns ascend and never repeat: canonical CSR by construction),
+    values standard normal.  Tall and random: well conditioned."""
+    rng = np.random.default_rng(seed)
+    w = n // k
+    cols = (rng.integers(0, w, size=(m, k)) + np.arange(k, dtype=np.int64)[None, :] * w).astype(np.int32)
+    data = rng.standard_normal((m, k))
+    indptr = (np.arange(m + 1, dtype=np.int64) * k).astype(np.int32)
+    return indptr, cols.reshape(-1), data.reshape(-1)
+
+
+def other_configs(lib, passes=400, warm=20, only=None):
+    """Every solver loop north_star names that is not CG, on one GPU: BASELINE configs[2] (BiCGSTAB) and configs[3]
+    (MINRES), CGS and TFQMR on the configs[2] matrix, SYMMLQ on the configs[3] matrix, LSQR / LSMR / CRAIG / CRAIG-MR on
+    a seeded 4e6 x 1e6 matrix with 5 nonzeros per row.  Per loop: passes per second with the tolerances at zero, each
+    product kernel of the pass timed alone (back-to-back launches, one HIP event pair), and PHYSICAL rooflines -- bytes the
+    kernels have to move in the storage format in use.  Loops that converge to the last bit within a few dozen passes
+    (everything but MINRES / SYMMLQ here) are timed on FINITE data: the run is re-set-up every `seg` passes, the first
+    `head` passes of a segment are untimed, the rest is timed with HIP events on the solver stream, and the residual is
+    asserted finite and positive at the end of every segment."""
     from pykrylov_amd import _lib, gallery
+    from pykrylov_amd.linop import CsrOperator
     from pykrylov_amd.generic import DeviceRun
     out = {}
 
-    def spmv_time(run, launches=200):
-        avg = ctypes.c_double(float("nan"))
-        _lib.check(lib.mk_solver_time_spmv(run.handle, launches, ctypes.byref(avg)))
-        return avg.value
+    def spmv_entry(us, b_fmt, b_csr, note=None):
+        d = {"avg_product_us": us, "bytes_per_launch": int(b_fmt), "achieved_GBs": b_fmt / us / 1e3,
+             "frac": b_fmt / us / 1e3 / HBM_PEAK_GBS, "csr_equivalent_GBs": b_csr / us / 1e3}
+        if note:
+            d["note"] = note
+        return d
 
-    # configs[2]: BiCGSTAB, random nonsymmetric diagonally dominant CSR, n = 1e6, ~5 nnz/row.  With threshold 0 the
-    # residual underflows to 0 after ~25 passes and the recurrence then divides 0 by 0 (as the reference would).  To
-    # time FINITE data the run is re-set-up every `seg` passes (setup and the first 2 passes of a segment untimed,
-    # segments timed with HIP events on the solver stream, `device_loop_ms`); the residual is asserted finite and
-    # positive at the end of every segment.
-    n = 1000000
-    op = gallery.random_diagdom(n, seed=1)
-    ones = _lib.DeviceArray.from_numpy(np.ones(n))
-    rhs = _lib.DeviceArray(n)
-    op.spmv_device(ones.ptr, rhs.ptr)
-    seg, head = 16, 2
-    run = DeviceRun(op, _lib.MK_BICGSTAB, rhs, None, abstol=0.0, reltol=0.0, matvec_max=1 << 60)
-    total_ms, done, resid_min = 0.0, 0, float("inf")
-    run.setup()
-    assert run.iterate(warm) == warm
-    while done < passes:
-        run.setup()
-        assert run.iterate(head) == head
-        assert run.iterate(seg - head) == seg - head
-        total_ms += run.timing()["iterate_ms"]
-        done += seg - head
-        rn = float(run.finish().residNorm)
-        assert np.isfinite(rn) and rn > 0.0, "configs[2] segment ended on non-finite data: %r" % rn
-        resid_min = min(resid_min, rn)
-    spmv_us = spmv_time(run)
-    run.close()
-    dt = total_ms * 1e-3
-    fmt = format_info(lib, op)
-    b_csr = spmv_bytes(n, n, op.nnz)
-    b_fmt = fmt["matrix_bytes_per_product"] + 16 * n
-    out["bicgstab-rand1m@1"] = {
-        "value": done / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / done, "steps": done,
-        "rows": n, "nnz": int(op.nnz), "matvecs_per_iteration": 2, "format": fmt, "column_blocks": colblocks(lib, op),
-        "data": "finite: re-set-up every %d passes, first %d of each segment untimed; smallest residual norm seen %.3e"
-                % (seg, head, resid_min),
-        "spmv": {"avg_product_us": spmv_us, "bytes_per_launch": b_fmt, "achieved_GBs": b_fmt / spmv_us / 1e3,
-                 "frac": b_fmt / spmv_us / 1e3 / HBM_PEAK_GBS, "csr_equivalent_GBs": b_csr / spmv_us / 1e3},
-        "iteration_roofline": {"bytes_per_iter": 2 * b_fmt + 136 * n,
-                               "frac": (2 * b_fmt + 136 * n) * done / dt / 1e9 / HBM_PEAK_GBS,
-                               "note": "2 products in the format in use + the 136 n bytes of the fused update kernels",
-                               "reference_op_count_bytes_per_iter": 2 * b_csr + 224 * n,
-                               "reference_op_count_GBs": (2 * b_csr + 224 * n) * done / dt / 1e9}}
-    op.free()
-    # configs[3]: MINRES, 2-D Laplacian m = 2000 (n = 4e6) with the keyword shift 1.5 (symmetric indefinite)
-    m = 2000
-    n = m * m
-    op = gallery.poisson2d(m)
-    ones = _lib.DeviceArray.from_numpy(np.ones(n))
-    rhs_h = np.empty(n)
-    rhs = _lib.DeviceArray(n)
-    op.spmv_device(ones.ptr, rhs.ptr)
-    rhs_h[:] = rhs.to_numpy() - 1.5
-    run = DeviceRun(op, _lib.MK_MINRES, rhs_h, None, shift=1.5, itnlim=1 << 60, rtol=0.0, etol=0.0, window=5)
-    run.setup()
-    assert run.iterate(warm) == warm
-    _lib.check(lib.mk_sync())
-    t0 = time.perf_counter()
-    done = run.iterate(passes)
-    _lib.check(lib.mk_sync())
-    dt = time.perf_counter() - t0
-    assert done == passes, (done, passes)
-    try:
-        spmv_us = spmv_time(run)
-    except Exception:                                        # (not wired for this solver: no kernel-alone figure)
-        spmv_us = None
-    run.close()
-    fmt = format_info(lib, op)
-    b_csr = spmv_bytes(n, n, op.nnz)
-    b_fmt = fmt["matrix_bytes_per_product"] + 16 * n
-    out["minres-shifted2d-2000@1"] = {
-        "value": passes / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / passes, "steps": passes,
-        "rows": n, "nnz": int(op.nnz), "shift": 1.5, "format": fmt,
-        "spmv": None if not spmv_us else {"avg_product_us": spmv_us, "bytes_per_launch": b_fmt + 24 * n,
-                                          "achieved_GBs": (b_fmt + 24 * n) / spmv_us / 1e3,
-                                          "frac": (b_fmt + 24 * n) / spmv_us / 1e3 / HBM_PEAK_GBS,
-                                          "note": "product + fused Lanczos step (reads r1, writes y and v: 24 n more)"},
-        "iteration_roofline": {"bytes_per_iter": b_fmt + 96 * n, "frac": (b_fmt + 96 * n) * passes / dt / 1e9 / HBM_PEAK_GBS,
-                               "note": "product in the format in use + the 96 n bytes of the fused kernels",
-                               "reference_op_count_bytes_per_iter": b_csr + 176 * n,
-                               "reference_op_count_GBs": (b_csr + 176 * n) * passes / dt / 1e9}}
-    op.free()
+    def segmented(run, passes, head=2, seg_try=(16, 12, 10, 8, 6, 4), lls=False):
+        """(passes timed, seconds, smallest residual seen, seg) on finite data; `run` is re-set-up per segment.  A segment
+        is good when the loop is still running at its end (with zero tolerances a halt means the machine-precision or
+        breakdown tests fired) and the residual it reports is finite (and positive, where the solver reports one: LSMR
+        reports ||r|| in aux[1], CRAIG-MR none)."""
+        def state():
+            r = run.finish()
+            vals = (float(r.residNorm), float(r.aux[0]), float(r.aux[1])) if lls else (float(r.residNorm),)
+            rn = max(vals) if lls else vals[0]
+            good = (not r.halted) and all(np.isfinite(v) for v in vals) and (lls or rn > 0.0)
+            return good, rn
+        seg = None
+        for cand in seg_try:
+            run.setup()
+            done = run.iterate(cand)
+            good, _ = state()
+            if done == cand and good:
+                seg = cand
+                break
+        assert seg is not None, "no segment length keeps the data finite"
+        total_ms, done_all, resid_min = 0.0, 0, float("inf")
+        while done_all < passes:
+            run.setup()
+            assert run.iterate(head) == head
+            assert run.iterate(seg - head) == seg - head
+            total_ms += run.timing()["iterate_ms"]
+            done_all += seg - head
+            good, rn = state()
+            assert good, "segment ended on non-finite data or a halted loop: %r" % rn
+            resid_min = min(resid_min, rn)
+        return done_all, total_ms * 1e-3, resid_min, seg
+
+    def entry(name, key, done, dt, m, n, nnz, fmt_a, prods, extra):
+        """prods: list of (label, avg_us, physical bytes, csr bytes) of the pass's product kernels."""
+        b_prod = sum(p[2] for p in prods)
+        b_csr = sum(p[3] for p in prods)
+        b_loop = LOOP_BYTES[key](m, n)
+        e = {"value": done / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / done, "steps": done,
+             "rows": m, "cols": n, "nnz": int(nnz), "matvecs_per_iteration": len(prods), "format": fmt_a,
+             "products": {p[0]: spmv_entry(p[1], p[2], p[3]) for p in prods if p[1]},
+             "iteration_roofline": {"bytes_per_iter": int(b_prod + b_loop),
+                                    "frac": (b_prod + b_loop) * done / dt / 1e9 / HBM_PEAK_GBS,
+                                    "achieved_GBs": (b_prod + b_loop) * done / dt / 1e9,
+                                    "note": "%d product(s) in the format in use + %d bytes of the fused update kernels"
+                                            % (len(prods), b_loop)}}
+        if key in REF_LOOP_BYTES:
+            ref = b_csr + REF_LOOP_BYTES[key] * n
+            e["iteration_roofline"]["reference_op_count_bytes_per_iter"] = int(ref)
+            e["iteration_roofline"]["reference_op_count_GBs"] = ref * done / dt / 1e9
+        e.update(extra)
+        out[name] = e
+
+    want = lambda k: only is None or k in only                # noqa: E731
+
+    # ---- configs[2] matrix: random nonsymmetric diagonally dominant CSR, n = 1e6, ~5 nnz/row -- BiCGSTAB, CGS, TFQMR
+    if want("bicgstab") or want("cgs") or want("tfqmr"):
+        n = 1000000
+        op = gallery.random_diagdom(n, seed=1)
+        ones = _lib.DeviceArray.from_numpy(np.ones(n))
+        rhs = _lib.DeviceArray(n)
+        op.spmv_device(ones.ptr, rhs.ptr)
+        for key, kind, label in (("bicgstab", _lib.MK_BICGSTAB, "bicgstab-rand1m@1"), ("cgs", _lib.MK_CGS, "cgs-rand1m@1"),
+                                 ("tfqmr", _lib.MK_TFQMR, "tfqmr-rand1m@1")):
+            if not want(key):
+                continue
+            run = DeviceRun(op, kind, rhs, None, abstol=0.0, reltol=0.0, matvec_max=1 << 60)
+            run.setup()
+            run.iterate(min(warm, 8))
+            done, dt, rmin, seg = segmented(run, passes)
+            us = [run.time_product(w) for w in (0, 1)]
+            run.close()
+            fmt = format_info(lib, op)
+            b_csr = spmv_bytes(n, n, op.nnz)
+            b_fmt = fmt["matrix_bytes_per_product"] + 16 * n
+            entry(label, key, done, dt, n, n, op.nnz, fmt,
+                  [("first (A p / A y)", us[0], b_fmt, b_csr), ("second (A z)", us[1], b_fmt, b_csr)],
+                  {"column_blocks": colblocks(lib, op),
+                   "spmv": spmv_entry(us[0], b_fmt, b_csr),
+                   "data": "finite: re-set-up every %d passes, first 2 of each segment untimed; smallest residual norm seen "
+                           "%.3e" % (seg, rmin)})
+        for b in (ones, rhs):
+            b.free()
+        op.free()
+
+    # ---- configs[3] matrix: 2-D Laplacian m = 2000 (n = 4e6), keyword shift 1.5 (symmetric indefinite) -- MINRES, SYMMLQ
+    if want("minres") or want("symmlq"):
+        mg = 2000
+        n = mg * mg
+        op = gallery.poisson2d(mg)
+        ones = _lib.DeviceArray.from_numpy(np.ones(n))
+        rhs = _lib.DeviceArray(n)
+        op.spmv_device(ones.ptr, rhs.ptr)
+        rhs_h = rhs.to_numpy() - 1.5
+        for key, kind, label, params, lanczos in (
+                ("minres", _lib.MK_MINRES, "minres-shifted2d-2000@1",
+                 dict(shift=1.5, itnlim=1 << 60, rtol=0.0, etol=0.0, window=5), 24),
+                ("symmlq", _lib.MK_SYMMLQ, "symmlq-shifted2d-2000@1",
+                 dict(shift=1.5, has_shift=1, matvec_max=1 << 60, rtol=0.0), 24)):
+            if not want(key):
+                continue
+            run = DeviceRun(op, kind, rhs_h, None, **params)
+            run.setup()
+            assert run.iterate(warm) == warm
+            _lib.check(lib.mk_sync())
+            t0 = time.perf_counter()
+            done = run.iterate(passes)
+            _lib.check(lib.mk_sync())
+            dt = time.perf_counter() - t0
+            assert done == passes, (key, done, passes)
+            rn = float(run.finish().residNorm)
+            assert np.isfinite(rn), (key, rn)
+            us = run.time_product(0)
+            run.close()
+            fmt = format_info(lib, op)
+            b_csr = spmv_bytes(n, n, op.nnz)
+            b_fmt = fmt["matrix_bytes_per_product"] + 16 * n
+            entry(label, key, done, dt, n, n, op.nnz, fmt, [("A y + fused Lanczos step", us, b_fmt + lanczos * n, b_csr)],
+                  {"shift": 1.5, "residual_norm_after": rn,
+                   "spmv": spmv_entry(us, b_fmt + lanczos * n, b_csr,
+                                      "product + fused Lanczos step (reads r1, writes y and v: %d n more)" % lanczos)})
+            # (the Lanczos step's bytes are inside the product entry: take them out of the loop's extra)
+            ir = out[label]["iteration_roofline"]
+            ir["bytes_per_iter"] = int(b_fmt + LOOP_BYTES[key](n, n))
+            ir["achieved_GBs"] = ir["bytes_per_iter"] * done / dt / 1e9
+            ir["frac"] = ir["achieved_GBs"] / HBM_PEAK_GBS
+            ir["note"] = "product in the format in use + the %d n bytes of the fused kernels" % (LOOP_BYTES[key](1, 1))
+        for b in (ones, rhs):
+            b.free()
+        op.free()
+
+    # ---- least squares: seeded 4e6 x 1e6, 5 nnz/row; A.T is a second device CSR (mk_csr_transpose)
+    if any(want(k) for k in ("lsqr", "lsmr", "craig", "craigmr")):
+        m, n = 4000000, 1000000
+        indptr, indices, data = random_tall_csr(m, n)
+        op = CsrOperator(indptr, indices, data, (m, n))
+        del indptr, indices, data
+        At = op.T
+        xs = _lib.DeviceArray.from_numpy(np.random.default_rng(12).standard_normal(n))
+        rhs = _lib.DeviceArray(m)
+        op.spmv_device(xs.ptr, rhs.ptr)                       # consistent system: b = A x*
+        xs.free()
+        for key, kind in (("lsqr", _lib.MK_LSQR), ("lsmr", _lib.MK_LSMR), ("craig", _lib.MK_CRAIG),
+                          ("craigmr", _lib.MK_CRAIGMR)):
+            if not want(key):
+                continue
+            run = DeviceRun(op, kind, rhs, None, transpose=At, itnlim=1 << 60, damp=0.0, atol=0.0, btol=0.0, conlim=0.0,
+                            etol=0.0, window=5)
+            done, dt, rmin, seg = segmented(run, max(120, passes // 2), lls=True)
+            us = [run.time_product(w) for w in (0, 1)]
+            run.close()
+            fa, ft = format_info(lib, op), format_info(lib, At)
+            ba = (fa["matrix_bytes_per_product"] + 8 * n + 8 * m, spmv_bytes(m, n, op.nnz))
+            bt = (ft["matrix_bytes_per_product"] + 8 * m + 8 * n, spmv_bytes(n, m, op.nnz))
+            entry("%s-rand4m-x-1m@1" % key, key, done, dt, m, n, op.nnz, fa,
+                  [("A v (+ u update, <u,u>)", us[0], ba[0], ba[1]), ("A.T u (+ v update, <v,v>)", us[1], bt[0], bt[1])],
+                  {"format_transpose": ft,
+                   "data": "finite: re-set-up every %d passes, first 2 of each segment untimed; smallest residual norm seen "
+                           "%.3e" % (seg, rmin)})
+        rhs.free()
+        At.free() if hasattr(At, "free") else None
+        op.free()
     return out
 
 
@@ -464,6 +626,24 @@ def main():
             barrier()
         timing = run.timing()
         res = run.finish()
+        # the line proves its own work: ||b - A x_k|| recomputed from the iterate with the plain product
+        # (one exchange + one product + one norm, all ranks), against the residual the recurrence carries (cg.py:131,146,154)
+        px = ctypes.c_void_p()
+        _lib.check(lib.mk_solver_x(run.handle, ctypes.byref(px)))
+        xext = _lib.DeviceArray(op.shape[1])
+        _lib.check(lib.mk_memcpy_d2d(xext.ptr, px.value, 8 * n_local))
+        if td is not None:
+            _lib.check(lib.mk_exchange(op.handle, xext.ptr))
+        axb = _lib.DeviceArray(n_local)
+        _lib.check(lib.mk_spmv(op.handle, xext.ptr, axb.ptr))
+        _lib.check(lib.mk_axpy(n_local, -1.0, rhs.ptr, axb.ptr))
+        sq = ctypes.c_double()
+        _lib.check(lib.mk_dot(n_local, axb.ptr, axb.ptr, ctypes.byref(sq)))
+        sqv = (ctypes.c_double * 1)(sq.value)
+        _lib.check(lib.mk_comm_allreduce_host(sqv, 1))
+        true_resid = float(np.sqrt(sqv[0]))
+        xext.free()
+        axb.free()
         comm = None
         if td is not None:
             last = ctypes.c_double()
@@ -495,9 +675,18 @@ def main():
         assert done == steps and done_w == warmup, (done, steps, done_w, warmup)
         assert np.isfinite(res.residNorm), "CG diverged"
         hist = run.history()
+        rel_gap = abs(true_resid - float(hist[-1])) / float(hist[0])
         info = dict(op_shape=op.shape, nnz=op.nnz, n_local=n_local, n_global=n_global, meta=meta, elapsed=elapsed,
                     timing=timing, resid_first=float(hist[0]), resid_last=float(hist[-1]), comm=comm,
-                    fmt=format_info(lib, op), steps=steps, launches=nl)
+                    fmt=format_info(lib, op), steps=steps, launches=nl, placement=dict(run.placement),
+                    residual={"first": float(hist[0]), "recurrence": float(hist[-1]), "true": true_resid,
+                              "rel_gap": rel_gap, "passes": int(res.nMatvec),
+                              "note": "true = ||b - A x_k|| recomputed from the iterate after the timed region with the "
+                                      "plain product; rel_gap = |true - recurrence| / ||r_0||, the line fails above 1e-10"})
+        info["residual"]["ok"] = bool(rel_gap <= 1e-10)
+        if not (rel_gap <= 1e-10) and workload == name:       # (the headline fails the line; extras carry ok = false)
+            raise SystemExit("bench.py: %s: recurrence residual %.6e but true residual %.6e (gap / r0 = %.2e > 1e-10): "
+                             "the timed kernels did not do CG's work" % (workload, hist[-1], true_resid, rel_gap))
         run.close()
         op.free()
         return info
@@ -585,7 +774,8 @@ def main():
         "roofline": roof,
         "iteration_roofline": it_roof,
         "device_loop_ms": tm["iterate_ms"],
-        "residual": {"first": info["resid_first"], "last": info["resid_last"]},
+        "residual": info["residual"],
+        "placement_draws": info["placement"],
     }
     if multi:
         # what actually carried the collectives (a silent host-staged fallback must not pass for an RCCL number)
@@ -606,7 +796,18 @@ def main():
         line["roofline"]["note_multi"] = ("N > 1: the SpMV kernel is not timed alone (each launch is preceded by an "
                                           "exchange); see iteration_roofline and exchange.*.comm")
     if rank == 0 and not multi and not args.no_cpu and not os.environ.get("BENCH_CHILD"):
-        line["cpu_baseline"] = cpu_baseline(name)
+        small = cpu_baseline(name)
+        line["cpu_baseline"] = small
+        if name == "poisson3d-512-varcoef":
+            # MEASURED at the quoted size; the 128^3 sample scaled by the rows ratio stays beside it
+            full1 = cpu_baseline_full_size(name, passes=4, threads=1)
+            if full1.get("value"):
+                full1["extrapolated_from_128cubed"] = small
+                line["cpu_baseline"] = full1
+                ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                line["cpu_baseline_all_cores"] = cpu_baseline_full_size(name, passes=4, threads=min(ncpu, 64))
+            else:
+                line["cpu_baseline"]["full_size_attempt"] = full1
         line["cpu_baseline_all_cores_extrapolated"] = cpu_baseline_all_cores(name)
     if not multi and name.startswith("poisson3d-512") and not args.no_extra:
         # the other BASELINE configs on one GPU, same measurement, reported beside the headline
@@ -621,7 +822,8 @@ def main():
             e_its, e_nnz, e_roof, e_it = roofline_of(exi, wname)
             extra[wname + "@1"] = {"value": e_its, "unit": "iterations/s", "steps": st, "warmup": wu,
                                    "ms_per_step": 1e3 * exi["elapsed"] / st, "roofline": e_roof,
-                                   "iteration_roofline": e_it, "storage_format": exi["fmt"]}
+                                   "iteration_roofline": e_it, "storage_format": exi["fmt"],
+                                   "residual": exi["residual"]}
         if "poisson3d-512@1" in extra:
             extra["poisson3d-512@1"]["note"] = ("constant-coefficient special case of the headline workload: rows AND "
                                                 "values compress to one byte per row (format 4), so the product moves "
@@ -632,6 +834,25 @@ def main():
                                       "of storage formats 6 / 7 / 8; CSR gathers take 1.25-1.36 ms per product here")
         extra.update(other_configs(lib))
         line["extra"] = extra
+        if "poisson3d-512@1" in extra:
+            # the LITERAL configs[4] matrix (constant coefficients) at top level, where the driver's parser keeps it
+            lit = extra["poisson3d-512@1"]
+            line["config_literal"] = {"workload": "CG poisson3d-512 (constant coefficients: diagonal 6, off-diagonals -1)",
+                                      "value": lit["value"], "unit": "iterations/s", "ms_per_step": lit["ms_per_step"],
+                                      "steps": lit["steps"], "roofline": {k: lit["roofline"][k] for k in
+                                                                          ("achieved", "peak", "unit", "frac", "bytes_per_launch",
+                                                                           "avg_launch_us", "traffic")},
+                                      "iteration_frac_of_hbm": lit["iteration_roofline"]["frac_of_aggregate_hbm"],
+                                      "residual_rel_gap": lit["residual"]["rel_gap"],
+                                      "storage_format": lit["storage_format"]["format"]}
+        # one flat summary of all ten solver loops (north_star's list): it/s and physical fraction of the HBM roofline
+        loops = {"cg": {"workload": name, "value": its, "iteration_frac": it_roof["frac_of_aggregate_hbm"]}}
+        for k, v in extra.items():
+            sk = k.split("-")[0]
+            if sk in LOOP_BYTES:
+                loops[sk] = {"workload": k, "value": v["value"], "iteration_frac": v["iteration_roofline"]["frac"],
+                             "product_us": {pk: pv["avg_product_us"] for pk, pv in v.get("products", {}).items()}}
+        line["solver_loops"] = loops
     if rank == 0:
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()

@@ -85,6 +85,12 @@ int mk_csr_from_coo(int64_t nrows, int64_t ncols, int64_t nentries, const int32_
                     const int32_t *cols_host, const double *vals_host, mk_csr **out);
 /* Copy the arrays back (any pointer may be NULL). */
 int mk_csr_download(const mk_csr *A, int32_t *indptr_host, int32_t *indices_host, double *data_host);
+/* The same for the rows [row_begin, row_end) only: indptr_host receives row_end - row_begin + 1 row pointers AS STORED
+ * (offsets into the whole matrix: subtract the first to index the slices), indices_host / data_host the entries
+ * indptr[row_begin] .. indptr[row_end).  Call once with NULL arrays for the row pointers to learn the sizes.  This is
+ * how a 512^3 matrix (11.8 GB of arrays) is checked against the oracle slab by slab (tests/test_gpu_full_size.py). */
+int mk_csr_download_rows(const mk_csr *A, int64_t row_begin, int64_t row_end, int32_t *indptr_host,
+                         int32_t *indices_host, double *data_host);
 /* B = A^T as a new canonical CSR built on the device (operator `.T`, linop.py:148-171;
  * feeds `A.T * u` of pykrylov/lls/lsqr.py:200,264). */
 int mk_csr_transpose(const mk_csr *A, mk_csr **out);
@@ -410,6 +416,11 @@ int mk_solver_timing(const mk_solver *s, double *iterate_ms, double *spmv_ms, in
  * each single launch would add ~3-6 us of marker overhead to a ~20 us kernel).  Destroys the product
  * vector of the current pass: call it after the timed iterations. */
 int mk_solver_time_spmv(mk_solver *s, int64_t launches, double *avg_us);
+/* The same for a chosen product of the pass: which = 0 the first (every solver; = mk_solver_time_spmv), 1 the second --
+ * BiCGSTAB's `A z` with its three fused dots (bicgstab.py:125), CGS's `A z` with `r -= alpha A z` (cgs.py:96-100),
+ * TFQMR's second `A z` (tfqmr.py:145-147), the least-squares solvers' `A.T * u` with the fused v update (lsqr.py:264).
+ * Launched without the loop gate.  MK_ERR_ARG if the solver has no such product. */
+int mk_solver_time_product(mk_solver *s, int which, int64_t launches, double *avg_us);
 /* One-shot convenience: setup + iterate(until halted) + finish. */
 int mk_solver_solve(mk_solver *s, const double *rhs_dev, const double *guess_dev, mk_result *res);
 

@@ -30,6 +30,11 @@ def _clib():
             lib.ref_csr_matvec.restype = None
             lib.ref_csr_transpose.argtypes = [ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 6
             lib.ref_csr_transpose.restype = None
+            lib.ref_poisson3d_indptr.argtypes = [ctypes.c_int64] * 5 + [ctypes.c_void_p]
+            lib.ref_poisson3d_indptr.restype = ctypes.c_int64
+            lib.ref_poisson3d_varcoef_fill.argtypes = ([ctypes.c_int64] * 3 + [ctypes.c_uint64] + [ctypes.c_int64] * 2
+                                                       + [ctypes.c_void_p] * 3)
+            lib.ref_poisson3d_varcoef_fill.restype = None
             _LIB = lib
         else:
             _LIB = False
@@ -173,15 +178,18 @@ def cell_field(cells, seed):
     return 0.5 + (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
 
 
-def poisson3d_varcoef(mx, my=None, mz=None, seed=7):
+def poisson3d_varcoef(mx, my=None, mz=None, seed=7, rows=None):
     """Variable-coefficient 7-point operator -div(k grad u), Dirichlet: the sparsity of `poisson3d`; off-diagonal
     entries are minus the harmonic means ((2 ka) kb) / (ka + kb) of the two cells' coefficients, the diagonal the
     left-to-right sum over the directions (-z, -y, -x, +x, +y, +z) of that mean, or of k(c) where the neighbour is
-    missing.  Twin of gen_poisson3d_varcoef (bit-identical arrays)."""
+    missing.  Twin of gen_poisson3d_varcoef (bit-identical arrays).  `rows=(a, b)`: only the rows [a, b) of the
+    matrix, as a (b - a) x n RefCsr with global column ids (how the 512^3 matrix is checked slab by slab)."""
     my = mx if my is None else my
     mz = mx if mz is None else mz
     n = mx * my * mz
-    idx = np.arange(n, dtype=np.int64)
+    a, b = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    assert 0 <= a <= b <= n
+    idx = np.arange(a, b, dtype=np.int64)
     gx, gy, gz = idx % mx, (idx // mx) % my, idx // (mx * my)
     kc = cell_field(idx, seed)
     dirs = ((gz > 0, -mx * my), (gy > 0, -mx), (gx > 0, -1), (gx < mx - 1, 1), (gy < my - 1, mx), (gz < mz - 1, mx * my))
@@ -190,10 +198,31 @@ def poisson3d_varcoef(mx, my=None, mz=None, seed=7):
         kb = cell_field(np.where(ok, idx + off, idx), seed)
         terms.append(np.where(ok, ((2.0 * kc) * kb) / (kc + kb), kc))
     diag = ((((terms[0] + terms[1]) + terms[2]) + terms[3]) + terms[4]) + terms[5]
-    parts = [(idx, idx, diag)]
+    parts = [(idx - a, idx, diag)]
     for (ok, off), t in zip(dirs, terms):
-        parts.append((idx[ok], idx[ok] + off, -t[ok]))
-    return from_coo(*[np.concatenate(c) for c in zip(*parts)], shape=(n, n))
+        parts.append((idx[ok] - a, idx[ok] + off, -t[ok]))
+    return from_coo(*[np.concatenate(c) for c in zip(*parts)], shape=(b - a, n))
+
+
+def poisson3d_varcoef_c(mx, my=None, mz=None, seed=7, rows=None):
+    """The same matrix (or row block) written straight into CSR arrays by the C twin (csr_ref.c
+    ref_poisson3d_varcoef_fill; OpenMP over rows): no COO triples, no sort -- what lets bench.py's CPU baseline hold
+    the full 512^3 problem.  Bit-identical to :func:`poisson3d_varcoef` (tests/test_oracle_golden.py)."""
+    lib = _clib()
+    assert lib, "oracle/libcsr_ref.so is not built (make -C oracle)"
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    n = mx * my * mz
+    a, b = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    indptr = np.empty(b - a + 1, dtype=np.int32)
+    nnz = lib.ref_poisson3d_indptr(mx, my, mz, a, b, indptr.ctypes.data)
+    assert nnz < 2 ** 31
+    indices = np.empty(nnz, dtype=np.int32)
+    data = np.empty(nnz, dtype=np.float64)
+    lib.ref_poisson3d_varcoef_fill(mx, my, mz, seed, a, b, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data)
+    A = RefCsr.__new__(RefCsr)
+    A.indptr, A.indices, A.data, A.shape, A._T = indptr, indices, data, (b - a, n), None
+    return A
 
 
 def stencil27(mx, my=None, mz=None, seed=0):

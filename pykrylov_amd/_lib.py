@@ -81,6 +81,7 @@ PROTOTYPES = {
     "mk_csr_shape": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64)]),
     "mk_csr_col_range": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
     "mk_csr_download": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "mk_csr_download_rows": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "mk_csr_from_coo": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),
     "mk_csr_transpose": (ctypes.c_int, [c_vp, P(c_vp)]),
     "mk_csr_compose": (ctypes.c_int, [c_vp, ctypes.c_int32, P(MkRowOp), P(c_vp)]),
@@ -134,6 +135,7 @@ PROTOTYPES = {
     "mk_solver_vector": (ctypes.c_int, [c_vp, ctypes.c_int, P(c_vp), P(c_i64)]),
     "mk_solver_timing": (ctypes.c_int, [c_vp, P(c_f64), P(c_f64), P(c_i64)]),
     "mk_solver_time_spmv": (ctypes.c_int, [c_vp, c_i64, P(c_f64)]),
+    "mk_solver_time_product": (ctypes.c_int, [c_vp, ctypes.c_int, c_i64, P(c_f64)]),
     "mk_solver_solve": (ctypes.c_int, [c_vp, c_vp, c_vp, P(MkResult)]),
 }
 

@@ -298,8 +298,10 @@ struct BicgstabSolver : mk_solver {
         return MK_OK;
     }
 
-    int enqueue_spmv_only() override {                     // (timing aid: the first product's kernel without its gate)
-        mk_launch_spmv(this, d_prec ? d_q : d_p, BEpi{d_r0, d_v}, false);
+    int enqueue_spmv_only(int which) override {            // (timing aid: a product's kernel without its gate)
+        if (which == 0) mk_launch_spmv(this, d_prec ? d_q : d_p, BEpi{d_r0, d_v}, false);
+        else if (which == 1) mk_launch_spmv(this, d_prec ? d_z : d_s, DEpi{d_s, d_r0, d_t}, false);
+        else return mk_fail(MK_ERR_ARG, "BiCGSTAB has two products per pass");
         return MK_OK;
     }
 

@@ -222,7 +222,8 @@ struct CgSolver : mk_solver {
         return MK_OK;
     }
 
-    int enqueue_spmv_only() override {
+    int enqueue_spmv_only(int which) override {
+        if (which != 0) return mk_fail(MK_ERR_ARG, "CG has one product per pass");
         if (A && mk_store_nt(A)) mk_launch_spmv(this, d_p, CgSpmvEpiT<true>{d_p, d_Ap, 0.0}, false);
         else mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0}, false);
         return MK_OK;

@@ -232,6 +232,13 @@ struct CgsSolver : mk_solver {
         return MK_OK;
     }
 
+    int enqueue_spmv_only(int which) override {            // (timing aid: a product's kernel without its gate)
+        if (which == 0) mk_launch_spmv(this, d_prec ? d_y : d_p, BEpi{d_r0, d_v}, false);
+        else if (which == 1) mk_launch_spmv(this, d_z, DEpi{d_scal, d_r0, d_r, 0.0}, false);
+        else return mk_fail(MK_ERR_ARG, "CGS has two products per pass");
+        return MK_OK;
+    }
+
     int enqueue_pass() override {
         const int par = (int)(it & 1);
         double *yin = d_prec ? d_y : d_p;

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <atomic>
+#include <mutex>
 #include <thread>
 
 #include "mk_solver.h"
@@ -160,8 +161,13 @@ int stager_threads() {
 }
 
 // returns MK_OK, or -1 when the caller should use the plain copy
+std::mutex g_stager_mu;
+
 int staged_copy(void *dst, const void *src, size_t bytes, bool h2d) {
     if (bytes < 4 * MK_COPY_PIECE) return -1;
+    // ctypes releases the GIL: a second host thread that arrives while the pinned buffers are in use takes the plain copy
+    std::unique_lock<std::mutex> hold(g_stager_mu, std::try_to_lock);
+    if (!hold.owns_lock()) return -1;
     const int nt = stager_threads();
     if (nt == 0) return -1;
     if (hipStreamSynchronize(mk_ctx().stream) != hipSuccess) return -1;
@@ -650,6 +656,30 @@ extern "C" int mk_csr_download(const mk_csr *A, int32_t *indptr, int32_t *indice
     int rc = MK_OK;
     if (indices && A->nnz) rc = mk_download(indices, A->d_indices, sizeof(int32_t) * (size_t)A->nnz, false);
     if (rc == MK_OK && data && A->nnz) rc = mk_download(data, A->d_data, sizeof(double) * (size_t)A->nnz, false);
+    if (rc != MK_OK) return rc;
+    MK_HIP(hipStreamSynchronize(st));
+    return MK_OK;
+}
+
+extern "C" int mk_csr_download_rows(const mk_csr *A, int64_t row_begin, int64_t row_end, int32_t *indptr,
+                                    int32_t *indices, double *data) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr);
+    MK_ARG(row_begin >= 0 && row_begin <= row_end && row_end <= A->nrows);
+    if (A->comp_kind || A->host_fn)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_download_rows: the operand has no matrix of its own");
+    hipStream_t st = mk_ctx().stream;
+    int32_t ends[2] = {0, 0};
+    MK_HIP(hipMemcpyAsync(&ends[0], A->d_indptr + row_begin, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MK_HIP(hipMemcpyAsync(&ends[1], A->d_indptr + row_end, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (indptr)
+        MK_HIP(hipMemcpyAsync(indptr, A->d_indptr + row_begin, sizeof(int32_t) * (size_t)(row_end - row_begin + 1),
+                              hipMemcpyDeviceToHost, st));
+    MK_HIP(hipStreamSynchronize(st));
+    const size_t cnt = (size_t)(ends[1] - ends[0]);
+    int rc = MK_OK;
+    if (indices && cnt) rc = mk_download(indices, A->d_indices + ends[0], sizeof(int32_t) * cnt, false);
+    if (rc == MK_OK && data && cnt) rc = mk_download(data, A->d_data + ends[0], sizeof(double) * cnt, false);
     if (rc != MK_OK) return rc;
     MK_HIP(hipStreamSynchronize(st));
     return MK_OK;

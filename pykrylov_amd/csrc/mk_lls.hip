@@ -1078,7 +1078,8 @@ struct LlsSolver : mk_solver {
     double *vL() const { return d_v + off; }
     const double *dnL() const { return d_dn ? d_dn + off : nullptr; }
     int gather_v() { return sliced ? mk_comm_allgather(vL(), d_v, cnt, stream) : (int)MK_OK; }
-    int sum_x() { return sliced ? allreduce(SLOT_X, 1) : (int)MK_OK; }
+    // (only LSQR's ||dk||^2 and LSMR's ||x||^2 live in SLOT_X: the CRAIG kernels produce no such partial sums)
+    int sum_x() { return (sliced && (kind == MK_LSQR || kind == MK_LSMR)) ? allreduce(SLOT_X, 1) : (int)MK_OK; }
 
     // <u, Mu> is an m-space inner product: its partial sums are added across the ranks
     int sum_uu() { return dist ? allreduce(SLOT_UU, 1) : (int)MK_OK; }
@@ -1179,6 +1180,15 @@ struct LlsSolver : mk_solver {
         if (d_dn) mk_launch_stream(this, OpScaleNv{d_scal, d_scal + S_BLK, 0, d_Nv, 0.0, false}, nl);   // lsqr.py:209
         if (kind == MK_CRAIG || kind == MK_CRAIGMR)
             mk_launch_stream(this, OpInitM{d_scal, kind, d_u, d_d, d_r, 0, 0}, m);
+        return MK_OK;
+    }
+
+    int enqueue_spmv_only(int which) override {            // (timing aid: a product's kernel without its gate; one GPU)
+        if (dist) return mk_fail(MK_ERR_UNSUPPORTED, "product timing of the least-squares solvers is single-GPU");
+        const double *blk = d_scal + S_BLK + (int)(it & 1) * BLK;
+        if (which == 0) mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0});
+        else if (which == 1) mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, d_dn, d_Nv, 0.0});
+        else return mk_fail(MK_ERR_ARG, "the least-squares solvers have two products per pass (A v, A' u)");
         return MK_OK;
     }
 

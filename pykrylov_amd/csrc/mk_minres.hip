@@ -347,7 +347,8 @@ struct MinresSolver : mk_solver {
         return MK_OK;
     }
 
-    int enqueue_spmv_only() override {                     // (timing aid: the product kernel of a pass without its gate;
+    int enqueue_spmv_only(int which) override {            // (timing aid: the product kernel of a pass without its gate;
+        if (which != 0) return mk_fail(MK_ERR_ARG, "MINRES has one product per pass");
         const int par = (int)(it & 1);                     //  writes v and t of the current pass, which the next pass
         const double *blk = d_scal + S_BLK + par * BLK;    //  overwrites anyway)
         double *r1 = d_r[it & 1], *r2 = d_r[(it + 1) & 1];

@@ -86,7 +86,9 @@ struct mk_solver {
     virtual bool takes_precon() const { return false; }
     // enqueue only the solver's (fused) SpMV kernel, exactly as a loop pass launches it; used to time
     // that kernel back to back.  Overwrites the product vector and its partial sums.
-    virtual int enqueue_spmv_only() { return mk_fail(MK_ERR_UNSUPPORTED, "SpMV timing is not wired for this solver"); }
+    // `which`: 0 = the first product of a pass, 1 = the second (BiCGSTAB / CGS / TFQMR: the product on z; least squares:
+    // the A' u product with its fused v update); run without its gate.
+    virtual int enqueue_spmv_only(int which = 0) { return mk_fail(MK_ERR_UNSUPPORTED, "SpMV timing is not wired for this solver"); }
 
     int init_common(const mk_csr *A_, const mk_params *p);
     int alloc_vec(double **out, int64_t len);

@@ -432,13 +432,17 @@ extern "C" int mk_solver_vector(const mk_solver *s, int index, const double **v_
 }
 
 extern "C" int mk_solver_time_spmv(mk_solver *s, int64_t launches, double *avg_us) {
-    MK_ARG(s && launches > 0 && avg_us);
-    if (!s->is_setup) return mk_fail(MK_ERR_STATE, "mk_solver_time_spmv before mk_solver_setup");
-    int rc = s->enqueue_spmv_only();                       // one untimed launch first
+    return mk_solver_time_product(s, 0, launches, avg_us);
+}
+
+extern "C" int mk_solver_time_product(mk_solver *s, int which, int64_t launches, double *avg_us) {
+    MK_ARG(s && launches > 0 && avg_us && which >= 0);
+    if (!s->is_setup) return mk_fail(MK_ERR_STATE, "mk_solver_time_product before mk_solver_setup");
+    int rc = s->enqueue_spmv_only(which);                  // one untimed launch first
     if (rc != MK_OK) return rc;
     MK_HIP(hipEventRecord(s->ev0, s->stream));
     for (int64_t k = 0; k < launches; ++k)
-        if ((rc = s->enqueue_spmv_only()) != MK_OK) return rc;
+        if ((rc = s->enqueue_spmv_only(which)) != MK_OK) return rc;
     MK_HIP(hipEventRecord(s->ev1, s->stream));
     MK_HIP(hipEventSynchronize(s->ev1));
     MK_HIP(hipGetLastError());

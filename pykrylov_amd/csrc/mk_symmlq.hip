@@ -561,6 +561,15 @@ struct SymmlqSolver : mk_solver {
         return MK_OK;
     }
 
+    int enqueue_spmv_only(int which) override {            // (timing aid: the product kernel of a pass without its gate)
+        if (which != 0) return mk_fail(MK_ERR_ARG, "SYMMLQ has one product per pass");
+        const double *blk = d_scal + S_BLK + (int)(it & 1) * BLK;
+        double *r1 = d_r[it & 1], *r2 = d_r[(it + 1) & 1];
+        double *y = d_prec ? d_y : r2;
+        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, prm.has_shift, 0.0, 0.0}, false);
+        return MK_OK;
+    }
+
     int enqueue_pass() override {
         const int par = (int)(it & 1);
         const double *blk = d_scal + S_BLK + par * BLK;

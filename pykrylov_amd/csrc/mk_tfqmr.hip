@@ -323,6 +323,14 @@ struct TfqmrSolver : mk_solver {
         return allreduce(SLOT_SIGMA, 1);
     }
 
+    int enqueue_spmv_only(int which) override {            // (timing aid: a product's kernel without its gate)
+        double *zs = zsrc();
+        if (which == 0) mk_launch_spmv(this, zs, EpiP4{d_scal, zs, d_r0, d_u, d_w, d_d, 0.0, 0.0}, false);
+        else if (which == 1) mk_launch_spmv(this, zs, EpiP6<false>{d_r0, d_u, d_v}, false);
+        else return mk_fail(MK_ERR_ARG, "TFQMR has two products per pass");
+        return MK_OK;
+    }
+
     int enqueue_pass() override {
         const int par = (int)(it & 1);
         const double k = (double)(it + 1);

@@ -81,11 +81,6 @@ class KrylovMethod(object):
             sh = self._host_shell = HostOperatorShell(self.op)
         return sh
 
-    def _no_precon(self, precon):
-        if precon is not None:
-            raise NotImplementedError('%s: preconditioners are not available on the device path yet'
-                                      % self.__class__.__name__)
-
     def _device_precon(self, precon):
         """How the device loop applies ``precon * r`` (generic.py:76; cg.py:91-92, bicgstab.py:96-99, ...):
 
@@ -158,7 +153,13 @@ class DeviceRun(object):
         self.lib = _lib.init()
         self.op = op
         self.d_prec = None
-        n = getattr(op, 'local_size', None) or op.shape[1]     # row-partitioned operator: local rows
+        # `transpose`: the device operator A.T the least-squares kinds need (mk_solver_set_transpose); their rhs has
+        # nrows(A) entries.  `placement_draws`: see _draws().
+        transpose = params.pop('transpose', None)
+        draws = params.pop('placement_draws', None)
+        if draws is not None:
+            self.placement_draws = int(draws)
+        n = getattr(op, 'local_size', None) or (op.shape[0] if transpose is not None else op.shape[1])
         self.n = n
         # rhs / guess: host arrays (copied to HBM) or DeviceArray objects already resident there
         self._borrowed = [b for b in (rhs, guess) if isinstance(b, _lib.DeviceArray)]
@@ -177,6 +178,14 @@ class DeviceRun(object):
         self._params = p
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.mk_solver_create(op.handle, ctypes.byref(p), ctypes.byref(self.handle)))
+        self.transpose = transpose
+        if transpose is not None:
+            try:
+                _lib.check(self.lib.mk_solver_set_transpose(self.handle, transpose.handle))
+            except Exception:
+                self.lib.mk_solver_destroy(self.handle)
+                self.handle = ctypes.c_void_p()
+                raise
         self.host_precon = None
         self.device_precon = None
         if isinstance(precon_diag, DevicePrecon):
@@ -218,6 +227,7 @@ class DeviceRun(object):
             _lib.check(self.lib.mk_solver_set_precon_diag(self.handle, self.d_prec.ptr))
         self.result = _lib.MkResult()
         self._setup_done = False
+        self.placement = {"count": 1, "chosen": 0, "per_draw_ms_per_pass": [], "probe_seconds": 0.0, "passes_per_draw": 0}
 
     def _check(self, rc):
         if rc != 0 and hasattr(self.op, 'raise_pending'):
@@ -227,18 +237,21 @@ class DeviceRun(object):
             raise err
         _lib.check(rc)
 
-    # Placement draws.  How fast the fused update kernels run on a large problem depends on where the
-    # solver's vectors happen to lie in HBM -- a property of the allocations, constant for their lifetime, 3-6 % of a CG
-    # pass at 512^3 -- and nothing predicts it but running the loop.  For problems whose vectors exceed the Infinity Cache
-    # the first set-up therefore draws a few solver objects (each allocates its own vectors; spacer allocations in
-    # between keep the draws apart), runs a dozen passes on each and keeps the fastest.  The passes are real passes of
-    # the loop on the real data; the kept object is set up again afterwards, so nothing of the probe survives but the
-    # choice.  MK_PLACEMENT_DRAWS=1 turns it off.  Single-GPU runs without host callbacks only.
+    # Placement draws -- OPT-IN since round 4 (MK_PLACEMENT_DRAWS=k > 1, or `placement_draws=k` on the
+    # DeviceRun).  How fast the fused update kernels run on a large problem depends on where the solver's vectors happen
+    # to lie in HBM -- a property of the allocations, constant for their lifetime, 3-6 % of a CG pass at 512^3.  With
+    # draws on, the first set-up creates k solver objects (each allocates its own vectors; spacer allocations in between
+    # keep the draws apart), runs 4 + 12 real passes on each and keeps the fastest; the kept object is set up again
+    # afterwards, so nothing of the probe survives but the choice.  A draw costs about 0.2 s and 4 GB (transient) at
+    # 512^3 and pays back only after thousands of passes, which is why it is not the default: a solve that converges in
+    # ~100 passes would get slower.  What was drawn is recorded in `self.placement`.
     def _draws(self):
         if self._setup_done or getattr(self, '_drawn', False):
             return 1
-        env = os.environ.get('MK_PLACEMENT_DRAWS')
-        want = int(env) if env else 4
+        want = getattr(self, 'placement_draws', None)
+        if want is None:
+            env = os.environ.get('MK_PLACEMENT_DRAWS')
+            want = int(env) if env else 1
         min_mb = float(os.environ.get('MK_PLACEMENT_MIN_MB', '256'))      # (tests lower it to draw on small problems)
         if want <= 1 or 8 * self.n <= min_mb * 1024 * 1024:
             return 1
@@ -250,6 +263,8 @@ class DeviceRun(object):
         return min(want, 8)
 
     def _apply_precon(self, handle):
+        if getattr(self, 'transpose', None) is not None:
+            _lib.check(self.lib.mk_solver_set_transpose(handle, self.transpose.handle))
         if self.device_precon is not None:
             _lib.check(self.lib.mk_solver_set_precon_csr(handle, self.device_precon.dev.handle))
         if self.d_prec is not None:
@@ -257,20 +272,23 @@ class DeviceRun(object):
 
     def _timed_passes(self, handle, warm=4, passes=12):
         g = None if self.d_guess is None else self.d_guess.ptr
-        _lib.check(self.lib.mk_solver_setup(handle, self.d_rhs.ptr, g))
+        self._check(self.lib.mk_solver_setup(handle, self.d_rhs.ptr, g))
         done = ctypes.c_int64(0)
-        _lib.check(self.lib.mk_solver_iterate(handle, warm, ctypes.byref(done)))
-        _lib.check(self.lib.mk_sync())
+        self._check(self.lib.mk_solver_iterate(handle, warm, ctypes.byref(done)))
+        self._check(self.lib.mk_sync())
         t0 = time.perf_counter()
-        _lib.check(self.lib.mk_solver_iterate(handle, passes, ctypes.byref(done)))
-        _lib.check(self.lib.mk_sync())
+        self._check(self.lib.mk_solver_iterate(handle, passes, ctypes.byref(done)))
+        self._check(self.lib.mk_sync())
         return (time.perf_counter() - t0) / max(1, done.value) if done.value == passes else float('inf')
 
     def _draw_placement(self, draws):
         self._drawn = True
         spacers, best, best_t = [], self.handle, None
+        t_probe = time.perf_counter()
+        per_draw, chosen = [], 0
         try:
             best_t = self._timed_passes(self.handle)
+            per_draw.append(1e3 * best_t)
             for k in range(1, draws):
                 try:
                     sp_mb = int(os.environ.get('MK_PLACEMENT_SPACER_MB', '176'))
@@ -285,15 +303,18 @@ class DeviceRun(object):
                 except Exception:
                     self.lib.mk_solver_destroy(h)
                     break
+                per_draw.append(1e3 * t)
                 if t < 0.99 * best_t:
                     self.lib.mk_solver_destroy(best)
-                    best, best_t = h, t
+                    best, best_t, chosen = h, t, k
                 else:
                     self.lib.mk_solver_destroy(h)
         finally:
             self.handle = best
             for sp in spacers:
                 sp.free()
+            self.placement = {"count": len(per_draw), "chosen": chosen, "per_draw_ms_per_pass": per_draw,
+                              "probe_seconds": time.perf_counter() - t_probe, "passes_per_draw": 16}
 
     def setup(self):
         draws = self._draws()
@@ -336,6 +357,13 @@ class DeviceRun(object):
         out = np.empty(n, dtype=np.float64)
         _lib.check(self.lib.mk_solver_history(self.handle, out.ctypes.data, n))
         return out
+
+    def time_product(self, which=0, launches=200):
+        """Average duration (us) of the pass's product kernel `which` (0 first, 1 second / A.T), launched back to
+        back without its gate and bracketed by one HIP event pair.  Destroys the loop's vectors: call it last."""
+        avg = ctypes.c_double(float('nan'))
+        _lib.check(self.lib.mk_solver_time_product(self.handle, int(which), int(launches), ctypes.byref(avg)))
+        return avg.value
 
     def timing(self):
         it_ms, sp_ms, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()

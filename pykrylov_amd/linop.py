@@ -667,6 +667,20 @@ class CsrOperator(LinearOperator):
                                              data.ctypes.data))
         return indptr, indices, data
 
+    def csr_rows(self, row_begin, row_end):
+        """Download rows ``[row_begin, row_end)``: ``(indptr, indices, data)`` with the row pointers rebased to 0 (global
+        column ids).  How a matrix too large for the host is compared with the oracle slab by slab."""
+        cnt = int(row_end) - int(row_begin)
+        indptr = np.empty(cnt + 1, dtype=np.int32)
+        _lib.check(self._lib.mk_csr_download_rows(self._handle, int(row_begin), int(row_end), indptr.ctypes.data,
+                                                  None, None))
+        nz = int(indptr[-1]) - int(indptr[0])
+        indices = np.empty(nz, dtype=np.int32)
+        data = np.empty(nz, dtype=np.float64)
+        _lib.check(self._lib.mk_csr_download_rows(self._handle, int(row_begin), int(row_end), None,
+                                                  indices.ctypes.data, data.ctypes.data))
+        return indptr - indptr[0], indices, data
+
     def free(self):
         if getattr(self, '_handle', None):
             try:

@@ -475,3 +475,23 @@ def test_stencil27_twin_against_a_brute_force_construction():
         assert np.array_equal(A.to_dense(), D)
         assert np.array_equal(D, D.T) and np.linalg.eigvalsh(D).min() > 0
         assert np.all(np.diff(A.indices[A.indptr[0]:A.indptr[1]]) > 0)
+
+
+@pytest.mark.parametrize("dims,rows", [((8, 6, 5), None), ((8, 6, 5), (37, 141)), ((16, 16, 16), None),
+                                       ((5, 7, 3), (0, 105)), ((12, 9, 4), (108, 324))])
+def test_varcoef_row_blocks_and_c_generator_twin(dims, rows):
+    """`poisson3d_varcoef(rows=(a, b))` is the row block of the whole matrix, and the C generator (csr_ref.c, what
+    bench.py's cpu_baseline holds the 512^3 problem with) writes the same arrays bit for bit."""
+    whole = csr_ref.poisson3d_varcoef(*dims, seed=7)
+    a, b = rows if rows else (0, whole.shape[0])
+    blk = csr_ref.poisson3d_varcoef(*dims, seed=7, rows=rows)
+    lo, hi = whole.indptr[a], whole.indptr[b]
+    assert blk.shape == (b - a, whole.shape[1])
+    assert np.array_equal(blk.indptr, whole.indptr[a:b + 1] - lo)
+    assert np.array_equal(blk.indices, whole.indices[lo:hi]) and np.array_equal(blk.data, whole.data[lo:hi])
+    x = np.random.default_rng(3).standard_normal(whole.shape[1])
+    assert np.array_equal(blk.matvec(x), whole.matvec(x)[a:b])
+    c = csr_ref.poisson3d_varcoef_c(*dims, seed=7, rows=rows)
+    assert c.shape == blk.shape
+    assert np.array_equal(c.indptr, blk.indptr) and np.array_equal(c.indices, blk.indices)
+    assert np.array_equal(c.data, blk.data)
