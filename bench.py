@@ -243,6 +243,31 @@ def cpu_baseline_full_size(name, passes=4, threads=1):
 
 
 # ======================================================================================
+# N > 1 validates itself against a committed N = 1 device run (SURVEY.md 8e "P > 1 vs P = 1")
+# ======================================================================================
+PARITY_PASSES = 60
+DEV_HIST = os.path.join(ROOT, "tests", "golden", "dev_hist_512.npz")   # device-generated (tools/make_dev_hist.py)
+
+
+def rel_hist_err(h, href):
+    """Parity metric of SURVEY.md 7.4-4: max |h - href| / max(href, 1e-4 href[0])."""
+    h, href = np.asarray(h, dtype=float), np.asarray(href, dtype=float)
+    if h.shape != href.shape:
+        return float("inf")
+    return float(np.max(np.abs(h - href) / np.maximum(href, 1e-4 * href[0])))
+
+
+def n1_history(workload):
+    """Residual history of the first PARITY_PASSES CG passes of `workload` as ONE MI355X produced it (rhs = A 1, x0 = 0);
+    None when the fixture holds no run of this workload."""
+    if not os.path.exists(DEV_HIST):
+        return None
+    z = np.load(DEV_HIST, allow_pickle=False)
+    key = "hist_" + workload.replace("-", "_")
+    return np.array(z[key]) if key in z.files else None
+
+
+# ======================================================================================
 # workloads
 # ======================================================================================
 def build_workload(name, world, exchange):
@@ -523,6 +548,8 @@ def main():
     ap.add_argument("--one-device", action="store_true",
                     help="test aid: every rank on GPU 0 (RCCL refuses that, which exercises the host-staged fallback)")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--parity", action="store_true",
+                    help="N = 1: also run the 60-pass parity segment against tests/golden/dev_hist_512.npz (always on for N > 1)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="host: collectives staged through host memory over gloo, all ranks on GPU 0 -- a smoke test "
                          "of the N > 1 path on a single-GPU box, not a measurement")
@@ -602,12 +629,32 @@ def main():
         if td is not None:
             td.barrier()
 
-    def run_cg(workload, steps, warmup, stride, exchange="halo", spmv_launches=None, comm_probe=False):
+    def run_cg(workload, steps, warmup, stride, exchange="halo", spmv_launches=None, comm_probe=False, parity=False):
         op, n_global, meta = build_workload(workload, world, exchange)
         n_local = getattr(op, "local_size", None) or op.shape[1]
         ones = _lib.DeviceArray.from_numpy(np.ones(op.shape[1]))
         rhs = _lib.DeviceArray(n_local)
         op.spmv_device(ones.ptr, rhs.ptr)                     # rhs = A * 1 (test_diagdom.py:78-79 convention)
+        parity_info = None
+        href = n1_history(workload) if parity else None
+        if parity:
+            # the same PARITY_PASSES passes ONE GPU ran when the fixture was made: partitioning changes the summation order
+            # of the dots (per-rank partial sums, all-reduced) and nothing else, so the history must agree to 1e-12
+            prun = DeviceRun(op, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=PARITY_PASSES, check_curvature=1)
+            pres = prun.run()
+            ph = prun.history()
+            prun.close()
+            parity_info = {"passes": int(pres.nMatvec), "fixture": os.path.relpath(DEV_HIST, ROOT),
+                           "fixture_has_workload": href is not None}
+            if href is not None:
+                err = rel_hist_err(ph, href)
+                parity_info.update({"rel_hist_err": err, "bit_equal": bool(np.array_equal(ph, href)),
+                                    "tolerance": 1e-12, "ok": bool(err <= 1e-12),
+                                    "resid_first": float(ph[0]), "resid_last": float(ph[-1])})
+                if not err <= 1e-12:
+                    raise SystemExit("bench.py: N = %d history of %s is %.2e from the committed N = 1 device history "
+                                     "(> 1e-12): the partitioned run does not reproduce the single-GPU one"
+                                     % (world_size, workload, err))
         # tolerances 0: never converges, so exactly `steps` passes run inside the timed region
         run = DeviceRun(op, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=1 << 60,
                         check_curvature=1, spmv_event_stride=stride)
@@ -649,8 +696,11 @@ def main():
             last = ctypes.c_double()
             _lib.check(lib.mk_csr_comm_last_us(op.handle, ctypes.byref(last)))
             comm = {"last_overlapped_halo_group_us": last.value}
+            comm["device_loop_ms_per_step"] = timing["iterate_ms"] / max(1, steps)
             if comm_probe:
+                # this rank's product kernel alone (all tiles in one launch, no exchange in front of it), and
                 # the collectives alone, back to back on the library stream (every rank takes part)
+                comm["product_alone_us"] = run.time_product(0, 50)
                 ex_us, ar_us = ctypes.c_double(), ctypes.c_double()
                 xbuf = _lib.DeviceArray(op.shape[1])
                 _lib.check(lib.mk_comm_time_exchange(op.handle, xbuf.ptr, 20, ctypes.byref(ex_us)))
@@ -678,8 +728,8 @@ def main():
         rel_gap = abs(true_resid - float(hist[-1])) / float(hist[0])
         info = dict(op_shape=op.shape, nnz=op.nnz, n_local=n_local, n_global=n_global, meta=meta, elapsed=elapsed,
                     timing=timing, resid_first=float(hist[0]), resid_last=float(hist[-1]), comm=comm,
-                    fmt=format_info(lib, op), steps=steps, launches=nl, placement=dict(run.placement),
-                    residual={"first": float(hist[0]), "recurrence": float(hist[-1]), "true": true_resid,
+                    fmt=format_info(lib, op), steps=steps, launches=nl, placement=dict(run.placement), parity=parity_info,
+                    residual={"first": float(hist[0]), "last": float(hist[-1]), "recurrence": float(hist[-1]), "true": true_resid,
                               "rel_gap": rel_gap, "passes": int(res.nMatvec),
                               "note": "true = ||b - A x_k|| recomputed from the iterate after the timed region with the "
                                       "plain product; rel_gap = |true - recurrence| / ||r_0||, the line fails above 1e-10"})
@@ -747,7 +797,8 @@ def main():
 
     multi = world_size > 1
     first_mode = "halo" if (not multi or args.exchange in ("both", "halo")) else "allgather"
-    info = run_cg(name, args.steps, args.warmup, args.event_stride, exchange=first_mode, comm_probe=multi)
+    info = run_cg(name, args.steps, args.warmup, args.event_stride, exchange=first_mode, comm_probe=multi,
+                  parity=(multi or args.parity))
     elapsed = info["elapsed"]
     tm = info["timing"]
     n_g = info["n_global"]
@@ -777,10 +828,24 @@ def main():
         "residual": info["residual"],
         "placement_draws": info["placement"],
     }
+    line["parity_vs_n1"] = info["parity"]
     if multi:
         # what actually carried the collectives (a silent host-staged fallback must not pass for an RCCL number)
         line["transport"] = {"kind": {0: "none", 1: "rccl", 2: "host-staged"}[tkind.value],
                              "rccl_ranks_seen": tranks.value, "halo_communicator_split": bool(tsplit.value)}
+        if transport_used == "rccl" and not (tkind.value == 1 and tranks.value == world_size):
+            raise SystemExit("bench.py: asked for RCCL over %d ranks but the communicator reports kind %d with %d ranks"
+                             % (world_size, tkind.value, tranks.value))
+        # what one rank's kernels were budgeted at when its slab was run alone on one GPU (profiles/r03_slab_budget.txt):
+        # only the 8-way split of the 512^3 problem has a budget
+        budget = None
+        if world_size == 8 and name.startswith("poisson3d-512"):
+            budget = ({"kernels_per_pass_us": 443, "spmv_interior_us": 244, "spmv_boundary_us": 26, "update_xp_us": 106,
+                       "update_r_us": 62, "pack_us": 4.5} if name.endswith("-varcoef") else
+                      {"kernels_per_pass_us": 300, "spmv_interior_us": 108, "spmv_boundary_us": 18, "update_xp_us": 101,
+                       "update_r_us": 68, "pack_us": 4.5})
+            budget["source"] = "profiles/r03_slab_budget.txt (rank 3's slab alone on one GPU, rocprofv3 kernel trace)"
+        line["per_rank_budget"] = budget
         ex = {first_mode: {"value": its, "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
                            "comm": info["comm"]}}
         if args.exchange == "both":

@@ -216,6 +216,7 @@ def attach_exchange(op, mode, n_local, n_halo, send_count=None, recv_count=None,
                                        None if si is None or si.size == 0 else si.ctypes.data))
     op.local_size = int(n_local)
     op.halo_size = int(n_halo)
+    op.exchange_mode = int(mode)                              # 0 halo ([own | received] columns), 1 all-gather
     return op
 
 

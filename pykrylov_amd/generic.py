@@ -109,8 +109,10 @@ class KrylovMethod(object):
             raise TypeError('%s: precon must support `precon * vector`; got %r'
                             % (self.__class__.__name__, type(precon).__name__))
         if getattr(self.op, 'local_size', None) is not None:
-            raise NotImplementedError('%s: on a row-partitioned operator only diagonal preconditioners are available'
-                                      % self.__class__.__name__)
+            raise NotImplementedError('%s: on a row-partitioned operator a preconditioner must be rank local and live on '
+                                      'the device: a DiagonalOperator slice, or a device matrix / composite of the local '
+                                      'size (e.g. pykrylov_amd.tools.block_jacobi(op, bs) of the partitioned operator); '
+                                      'host callables are not called back across ranks' % self.__class__.__name__)
         return HostPrecon(precon)
 
     def _logging(self):

@@ -94,7 +94,23 @@ def block_jacobi(op, block_size):
     from .linop import CsrOperator
     indptr, indices, data = op.to_csr_arrays()
     n = op.shape[0]
-    if op.shape[0] != op.shape[1]:
+    nloc = getattr(op, 'local_size', None)
+    if nloc is not None:
+        # row-partitioned operator (pykrylov_amd.dist): the RANK-LOCAL preconditioner -- blocks of this rank's diagonal
+        # block only (its columns are numbered [own | received], so owned columns are those below the local size);
+        # blocks never straddle ranks, the result has no exchange plan and is applied without communication
+        n = int(nloc)
+        if getattr(op, 'exchange_mode', 0) == 1:              # all-gather layout: column = n_local + GLOBAL column
+            c0 = int(op.row_range[0])
+            indices = indices.astype(np.int64) - n - c0       # owned columns -> 0 .. n-1, everything else outside
+            own = (indices >= 0) & (indices < n)
+        else:
+            own = indices < n
+        rows_all = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+        counts = np.bincount(rows_all[own], minlength=n)
+        indices, data = indices[own], data[own]
+        indptr = np.concatenate([[0], np.cumsum(counts)])
+    elif op.shape[0] != op.shape[1]:
         raise ValueError('block_jacobi needs a square operator')
     bs = int(block_size)
     if bs < 1:
@@ -118,4 +134,4 @@ def block_jacobi(op, block_size):
     r, c, v = r[keep], c[keep], v[keep]
     ip = np.zeros(n + 1, dtype=np.int64)
     ip[1:] = np.cumsum(np.bincount(r, minlength=n))
-    return CsrOperator(ip, c, v, (n, n), symmetric=bool(op.symmetric))
+    return CsrOperator(ip, c, v, (n, n), symmetric=bool(getattr(op, 'symmetric', False)))

@@ -102,6 +102,79 @@ def main():
                                               x_err=float(np.linalg.norm(x - r["x"]) / np.linalg.norm(r["x"])))
         op.free()
 
+    # ---- rank-local block-Jacobi preconditioners as DEVICE operators on partitioned matrices:
+    # tools.block_jacobi of the partitioned operator inverts the blocks of this rank's diagonal block; the oracle applies
+    # the same block-diagonal matrix (all ranks' blocks side by side) through its scalar CSR loop
+    from pykrylov_amd.tools import block_jacobi
+    bs = 4
+
+    def local_bj(R, c0, c1):
+        """NumPy twin of tools.block_jacobi for the diagonal block [c0, c1) of the RefCsr R."""
+        nl = c1 - c0
+        rows = np.repeat(np.arange(R.shape[0], dtype=np.int64), np.diff(R.indptr))
+        cols = R.indices.astype(np.int64)
+        sel = (rows >= c0) & (rows < c1) & (cols >= c0) & (cols < c1)
+        r, c, v = rows[sel] - c0, cols[sel] - c0, R.data[sel]
+        nblk = (nl + bs - 1) // bs
+        inblk = (r // bs) == (c // bs)
+        blocks = np.zeros((nblk, bs, bs))
+        blocks[r[inblk] // bs, r[inblk] % bs, c[inblk] % bs] = v[inblk]
+        tail = nl - (nblk - 1) * bs
+        if tail < bs:
+            k = np.arange(tail, bs)
+            blocks[nblk - 1, k, k] = 1.0
+        inv = np.linalg.inv(blocks)
+        rr = np.repeat(np.arange(nblk * bs, dtype=np.int64), bs)
+        cc = (rr // bs) * bs + np.tile(np.arange(bs, dtype=np.int64), nblk * bs)
+        vv = inv.reshape(-1)
+        keep = (rr < nl) & (cc < nl)
+        return csr_ref.from_coo(rr[keep], cc[keep], vv[keep], (nl, nl))
+
+    def oracle_precon(R, ranges):
+        blocks = [(c0, c1, local_bj(R, c0, c1)) for c0, c1 in ranges]
+        return lambda v: np.concatenate([P.matvec(v[c0:c1]) for c0, c1, P in blocks])
+
+    P2 = csr_ref.poisson2d(37)
+    n2 = P2.shape[0]
+    rhs_p = P2.matvec(np.ones(n2))
+    for mode in ("halo", "allgather"):
+        for name, cls, fn, R, rhs_r, kw in (
+                ("bicgstab", BiCGSTAB, kr.bicgstab, B, rhs_b, dict(matvec_max=200)),
+                ("cgs", CGS, kr.cgs, B, rhs_b, dict(matvec_max=200)),
+                ("tfqmr", TFQMR, kr.tfqmr, B, rhs_b, dict(matvec_max=200)),
+                ("cg", CG, kr.cg, P2, rhs_p, dict(matvec_max=40))):
+            op, ranges = dist.partition_host_csr(world, R.indptr, R.indices, R.data, R.shape[0], mode=mode)
+            c0, c1 = ranges[rank]
+            M = block_jacobi(op, bs)                         # rank local, on the device
+            assert M.shape == (c1 - c0, c1 - c0)
+            mi, mj, mv = M.to_csr_arrays()
+            Mref = local_bj(R, c0, c1)
+            assert np.array_equal(mi, Mref.indptr) and np.array_equal(mj, Mref.indices) and np.array_equal(mv, Mref.data)
+            s = cls(op, reltol=1e-8, precon=M)
+            s.solve(rhs_r[c0:c1], **kw)
+            r = fn(R, rhs_r, reltol=1e-8, precon=oracle_precon(R, ranges), **kw)
+            x = gather_x(world, s.x)
+            ent = dict(nMatvec=int(s.nMatvec), ref=int(r["nMatvec"]), hist_err=0.0,
+                       x_err=float(np.linalg.norm(x - r["x"]) / np.linalg.norm(r["x"])))
+            if name == "cg":
+                ent["hist_err"] = rel_hist_err(s.residHistory, r["residHistory"])
+            out["%s_bjacobi/%s" % (name, mode)] = ent
+            M.free()
+            op.free()
+        # MINRES with the SPD block-Jacobi of the 2-D Laplacian
+        op, ranges = dist.partition_host_csr(world, P2.indptr, P2.indices, P2.data, n2, mode=mode)
+        c0, c1 = ranges[rank]
+        M = block_jacobi(op, bs)
+        s = Minres(op)                                       # (a `solve` keyword in the reference, minres.py:121)
+        s.solve(rhs_p[c0:c1], show=False, check=False, etol=0.0, rtol=1e-10, precon=M)
+        r = kr.minres(P2, rhs_p, check=False, etol=0.0, rtol=1e-10, precon=oracle_precon(P2, ranges))
+        x = gather_x(world, s.x)
+        out["minres_bjacobi/" + mode] = dict(nMatvec=int(s.itn), ref=int(r["itn"]),
+                                             hist_err=rel_hist_err(s.residHistory, r["residHistory"]),
+                                             x_err=float(np.linalg.norm(x - r["x"]) / np.linalg.norm(r["x"])))
+        M.free()
+        op.free()
+
     # ---- CG on a partitioned 27-point operator: every rank's slab takes a wide storage format (rows of 27 entries),
     # interior / boundary launches and the halo windows included
     S = csr_ref.stencil27(64, 12, 9, seed=5)

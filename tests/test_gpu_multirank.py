@@ -32,6 +32,8 @@ def test_partitioned_solvers_on_one_gpu(nranks):
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     out = json.loads(line[len("RESULT "):])
     assert len(out) >= 10, sorted(out)
+    # rank-local block-Jacobi preconditioners applied on the device: all six square solvers' hook
+    assert sum(k.split("/")[0].endswith("_bjacobi") for k in out) == 10, sorted(out)
     lls_keys = [k for k in out if k.startswith("lls_")]
     assert len(lls_keys) == 12 and sum(k.endswith("_sliced") for k in lls_keys) == 6, lls_keys
     for k in lls_keys:
@@ -42,7 +44,8 @@ def test_partitioned_solvers_on_one_gpu(nranks):
     for key, r in out.items():
         # partitioning changes the summation order of the dots (per-rank partials), nothing else: same counts on
         # these well-conditioned problems, 1e-12 on histories and iterates
-        if key.split("/")[0] in ("bicgstab", "cgs", "tfqmr", "bicgstab_precon"):
+        if key.split("/")[0] in ("bicgstab", "cgs", "tfqmr", "bicgstab_precon", "bicgstab_bjacobi", "cgs_bjacobi",
+                                 "tfqmr_bjacobi"):
             # these stop on a tolerance after ~20 passes (reltol 1e-8): the count may move by one product with the
             # summation order, and with it the last update of x
             assert abs(r["nMatvec"] - r["ref"]) <= 1 and r["x_err"] <= 1e-7, (key, r)
@@ -82,7 +85,13 @@ def test_bench_two_rank_path_smoke(launcher):
     assert line["n_gpus"] == 2 and line["steps"] == 12 and line["value"] > 0 and line["scaling"] == "strong"
     assert line["config"]["rows"] == 64 ** 3 and line["residual"]["last"] < line["residual"]["first"]
     assert line["roofline"]["bound"] == "hbm"
+    # the N > 1 line validates itself: the first 60 passes against the committed single-GPU device history (1e-12), and
+    # the true residual ||b - A x_k|| (exchange + product + all-reduced norm) against the recurrence's after the timed region
+    par = line["parity_vs_n1"]
+    assert par["fixture_has_workload"] and par["ok"] and par["passes"] == 60 and par["rel_hist_err"] <= 1e-12, par
+    assert line["residual"]["ok"] and line["residual"]["rel_gap"] <= 1e-10, line["residual"]
     ex = line["exchange"]
+    assert ex["halo"]["comm"]["per_rank"][0]["product_alone_us"] > 0
     assert set(ex) == {"halo", "allgather"} and ex["allgather"]["value"] > 0
     assert len(ex["halo"]["comm"]["per_rank"]) == 2 and ex["halo"]["comm"]["per_rank"][1]["exchange_alone_us"] > 0
     assert "host-staged gloo" in line["config"]["parallelism"]

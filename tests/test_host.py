@@ -328,3 +328,19 @@ def test_integration_md_stub_matches_the_header():
         fields = [(n, getattr(ctypes, t) * int(k) if k else getattr(ctypes, t)) for n, t, k in got]
         stub = type(cls, (ctypes.Structure,), {"_fields_": fields})
         assert ctypes.sizeof(stub) == ctypes.sizeof(ref)
+
+
+def test_device_history_fixture_for_the_multi_gpu_line():
+    """tests/golden/dev_hist_512.npz (device-generated on ONE MI355X by tools/make_dev_hist.py) is what bench.py's N > 1
+    line compares its first 60 passes with: it must hold both 512^3 workloads and the 64^3 twins the smoke test uses."""
+    import bench
+    z = np.load(bench.DEV_HIST, allow_pickle=False)
+    assert int(z["passes"]) == bench.PARITY_PASSES == 60 and int(z["seed"]) == bench.VARCOEF_SEED
+    for wl in ("poisson3d-512-varcoef", "poisson3d-512", "poisson3d-64-varcoef", "poisson3d-64"):
+        h = bench.n1_history(wl)
+        assert h is not None and h.shape == (61,) and np.isfinite(h).all() and h[-1] < h[0]
+    # ||A 1||^2 of the constant-coefficient matrix is an integer (faces 1, edges 4, corners 9): exact in any order
+    for m in (64, 512):
+        assert bench.n1_history("poisson3d-%d" % m)[0] == np.sqrt(6.0 * (m - 2) ** 2 + 48.0 * (m - 2) + 72.0)
+    assert bench.n1_history("poisson2d-1000") is None
+    assert abs(bench.rel_hist_err([4.0, 2.0], [4.0, 2.0 + 2e-12]) - 1e-12) < 1e-15
