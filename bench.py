@@ -614,7 +614,8 @@ def main():
                 sys.stderr.write("bench.py: " + transport_note + "\n")
 
     if args.only_other_configs:
-        json_out.write(json.dumps(other_configs(lib)) + "\n")
+        only = os.environ.get("BENCH_ONLY_LOOPS")            # (profiling aid: comma-separated solver keys)
+        json_out.write(json.dumps(other_configs(lib, only=only.split(",") if only else None)) + "\n")
         return
     name = args.workload
     if name == "auto":
@@ -630,6 +631,11 @@ def main():
             td.barrier()
 
     def run_cg(workload, steps, warmup, stride, exchange="halo", spmv_launches=None, comm_probe=False, parity=False):
+        arena_vecs = int(os.environ.get("BENCH_ARENA_VECTORS", "0"))
+        if arena_vecs > 0 and world.nranks == 1 and workload.startswith("poisson3d-"):
+            # placement experiment: the loop's vectors come from ONE block reserved BEFORE the matrix
+            mm = int(workload.split("-")[1])
+            _lib.check(lib.mk_arena_reserve(arena_vecs * (8 * mm ** 3 + (4 << 20))))
         op, n_global, meta = build_workload(workload, world, exchange)
         n_local = getattr(op, "local_size", None) or op.shape[1]
         ones = _lib.DeviceArray.from_numpy(np.ones(op.shape[1]))

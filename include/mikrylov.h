@@ -52,6 +52,12 @@ int mk_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int mk_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int mk_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
 int mk_memset(void *dst_dev, int byte, size_t bytes);
+/* Vector arena: ONE device allocation of `bytes` from which the solvers created afterwards carve their loop vectors
+ * (2 MiB granules) instead of allocating each with hipMalloc; a solver that finds no room falls back to hipMalloc.
+ * Meant to be called BEFORE a large matrix is built: how fast the fused update kernels stream depends on where the
+ * vectors lie in HBM relative to each other, and a fresh device places them better than a device that
+ * already holds 20 GB of matrix.  bytes = 0 releases the arena.  MK_ERR_STATE while vectors of it are in use. */
+int mk_arena_reserve(size_t bytes);
 
 /* Profiling aid: stream `bytes` of device memory with `width` (4, 8 or 16) bytes per lane, reading
  * (write = 0) or writing (write = 1).  Known byte counts to calibrate rocprofv3 FETCH_SIZE / WRITE_SIZE. */
@@ -198,7 +204,7 @@ int mk_csr_set_format(mk_csr *A, int fmt);
 int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_windowed, int32_t *lds_chunks,
                        int32_t *dict_size, int64_t *matrix_bytes_per_product);
 /* Column blocks (off by default; block_kb > 0 turns them on for A, 0 off, -1 = environment MK_COLBLOCK_KB): a
- * plain-CSR matrix (format 0) whose x vector is longer than two blocks is additionally stored as K <= 8 column blocks of
+ * plain-CSR matrix (format 0) whose x vector is longer than two blocks is additionally stored as K <= 16 column blocks of
  * block_kb KiB of x each; its products run block after block with the running row sums carried from one launch to the
  * next, which is the same left-to-right sum (same bits), each block gathering from a slice of x that fits an XCD's L2.
  * Measured slower than the single launch on 5-nonzero rows: an option, not the default.

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "mk_memcpy_d2h": (ctypes.c_int, [c_vp, c_vp, c_sz]),
     "mk_memcpy_d2d": (ctypes.c_int, [c_vp, c_vp, c_sz]),
     "mk_memset": (ctypes.c_int, [c_vp, ctypes.c_int, c_sz]),
+    "mk_arena_reserve": (ctypes.c_int, [c_sz]),
     "mk_calib_stream": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, ctypes.c_int]),
     "mk_csr_create": (ctypes.c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)]),
     "mk_csr_destroy": (ctypes.c_int, [c_vp]),

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(MK_BLOCK) void sell_fill_slots(int64_t nrows, int64
 }
 
 // ------------------------------------------------------------------------------------------------ column blocks
-constexpr int CB_MAX = 8;
+constexpr int CB_MAX = 16;
 struct CbPtrs {
     int32_t *indptr[CB_MAX];
     int32_t *indices[CB_MAX];
@@ -528,6 +528,19 @@ int64_t colblock_bytes(const mk_csr *A) {
         const char *e = getenv("MK_COLBLOCK_KB");
         return e ? atoll(e) * 1024 : (int64_t)0;
     }();
+    static const bool env_set = getenv("MK_COLBLOCK_KB") != nullptr;
+    if (A->want_cb_kb < 0 && !env_set) {
+        // AUTOMATIC (round 4): long rows gathered from an x several times the chip's L2 capacity -- the transposed operator
+        // of a tall least-squares problem (lls/lsqr.py:264: 1e6 rows of ~20 entries over 4e6 columns, x = 32 MB) pulls a
+        // 64-byte sector through the fabric for nearly every nonzero on the gather path (350 us per product), and its
+        // tiles are too long for the resident-tile format.  In 4 MiB column blocks the same product takes 232 us (LSQR
+        // 1 665 -> 2 050 passes per second, gpurun_out of tools/r04_cb.sh): with ~20 entries per row the 24 B per row and
+        // block of carried sums are small beside the sectors saved.  (5 entries per row: slower, see cblocks_build.)
+        const int64_t xbytes = 8 * A->x_len();
+        const bool long_rows = A->nrows > 0 && A->nnz >= 12 * A->nrows;
+        if (long_rows && xbytes >= ((int64_t)16 << 20) && A->ex.mode < 0) return (int64_t)4 << 20;
+        return 0;
+    }
     const int64_t b = A->want_cb_kb >= 0 ? (int64_t)A->want_cb_kb * 1024 : env;
     return b < 0 ? 0 : b;
 }
@@ -928,6 +941,18 @@ int plan_build(const mk_csr *A) {
         if (rc < 0) return fail("value dictionary");
         if (rc == 0) {                                       // too many distinct values: windows with raw values
             if (want >= 5) pattern_plan(A, P, true);         // ... in pattern order when the rows follow patterns (fmt 5)
+            if (P.fmt == 5 && P.covered == A->ntiles && getenv("MK_FREE_CSR") && atoi(getenv("MK_FREE_CSR")) > 0 &&
+                !A->alias && A->ex.mode < 0) {
+                // EXPERIMENT (placement): no product of a fully covered format-5 matrix reads the CSR
+                // values or columns again -- give their 12 bytes per nonzero back before the solver allocates its vectors.
+                // (download / transpose / partitioning of such a matrix fail afterwards: measurement only.)
+                mk_csr *M = const_cast<mk_csr *>(A);
+                hipStreamSynchronize(mk_ctx().stream);
+                hipFree(M->d_indices);
+                hipFree(M->d_data);
+                M->d_indices = nullptr;
+                M->d_data = nullptr;
+            }
             return MK_OK;
         }
         P.fmt = 2;

@@ -35,6 +35,10 @@ struct MkContext {
     // pinned staging for scalar read-backs
     double *h_scratch = nullptr;     // MK_MAXP * MK_NDOT doubles
     double *d_scratch = nullptr;
+    // vector arena (mk_arena_reserve): one allocation made BEFORE the matrix, from which solvers carve their vectors
+    char *arena = nullptr;
+    size_t arena_size = 0, arena_off = 0;
+    int arena_live = 0;              // vectors carved and not yet returned
 };
 
 MkContext &mk_ctx();

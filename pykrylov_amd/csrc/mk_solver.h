@@ -59,6 +59,7 @@ struct mk_solver {
     MkStatus *h_status = nullptr;   // pinned
     double *h_scal = nullptr;       // pinned, MK_NSCAL
     std::vector<double *> vecs;     // owned device vectors
+    std::vector<double *> arena_vecs;   // ... carved from the context's vector arena (mk_arena_reserve): returned, not freed
     std::vector<double> hist;       // drained history (host)
     std::vector<double> hist2;      // second channel (MINRES: direct-error estimates)
     bool use_hist2 = false;

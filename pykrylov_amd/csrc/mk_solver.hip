@@ -75,6 +75,14 @@ mk_solver::~mk_solver() {
     if (h_pout) hipHostFree(h_pout);
     if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
     for (double *v : vecs) hipFree(v);
+    if (!arena_vecs.empty()) {                               // the arena is reusable once its last vector is back
+        MkContext &c = mk_ctx();
+        c.arena_live -= (int)arena_vecs.size();
+        if (c.arena_live <= 0) {
+            c.arena_live = 0;
+            c.arena_off = 0;
+        }
+    }
     for (hipEvent_t e : spmv_ev) hipEventDestroy(e);
     hipFree(d_scal);
     hipFree(d_part);
@@ -89,10 +97,37 @@ mk_solver::~mk_solver() {
 
 int mk_solver::alloc_vec(double **out, int64_t len) {
     double *p = nullptr;
-    MK_HIP(hipMalloc((void **)&p, sizeof(double) * (size_t)(len > 0 ? len : 1) + 16));
-    MK_HIP(hipMemsetAsync(p, 0, sizeof(double) * (size_t)(len > 0 ? len : 1) + 16, stream));
-    vecs.push_back(p);
+    const size_t bytes = sizeof(double) * (size_t)(len > 0 ? len : 1) + 16;
+    MkContext &c = mk_ctx();
+    const size_t step = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);   // 2 MiB granules
+    if (c.arena && c.arena_off + step <= c.arena_size) {     // carved from the arena reserved before the matrix
+        p = reinterpret_cast<double *>(c.arena + c.arena_off);
+        c.arena_off += step;
+        c.arena_live += 1;
+        arena_vecs.push_back(p);
+    } else {
+        MK_HIP(hipMalloc((void **)&p, bytes));
+        vecs.push_back(p);
+    }
+    MK_HIP(hipMemsetAsync(p, 0, bytes, stream));
     *out = p;
+    return MK_OK;
+}
+
+extern "C" int mk_arena_reserve(size_t bytes) {
+    MK_REQUIRE_INIT();
+    MkContext &c = mk_ctx();
+    if (c.arena_live > 0) return mk_fail(MK_ERR_STATE, "mk_arena_reserve: %d vectors of the current arena are still in use", c.arena_live);
+    if (c.arena) {
+        MK_HIP(hipStreamSynchronize(c.stream));
+        MK_HIP(hipFree(c.arena));
+        c.arena = nullptr;
+        c.arena_size = c.arena_off = 0;
+    }
+    if (bytes == 0) return MK_OK;
+    MK_HIP(hipMalloc((void **)&c.arena, bytes));
+    c.arena_size = bytes;
+    c.arena_off = 0;
     return MK_OK;
 }
 

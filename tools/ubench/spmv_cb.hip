@@ -182,6 +182,130 @@ __global__ __launch_bounds__(BLOCK) void cb_res(int T, int K, int n, int W, cons
     }
 }
 
+// reg  : round 4.  Rows of <= RW entries held in REGISTERS, RT tiles per workgroup at once; the phase loop is static: in
+//        phase k a lane issues the gathers of all its entries whose column lies in slice k at once, waits once, adds in
+//        column order.  ING = 0: a lane loads its own row straight from the CSR arrays (strided, cached); 1: through LDS.
+// soft XCD-local barrier: performance hint only (bounded spin), counters only grow: target = epoch * (workgroups per XCD)
+__device__ __forceinline__ void soft_barrier(unsigned* cnt, int which, unsigned target) {
+    if (threadIdx.x == 0) {
+        unsigned* c = cnt + (which * 8 + (blockIdx.x & 7)) * 32;           // one 128-byte line per counter
+        __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && wall_clock64() - t0 < 3000) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+}
+template <int RT, int RW, int OCC, int ING = 0>
+__global__ __launch_bounds__(BLOCK, OCC) void cb_reg(int T, int K, int n, int W, const int* __restrict__ ip,
+                                                 const int* __restrict__ cols, const double* __restrict__ vals,
+                                                 const double* __restrict__ x, double* __restrict__ y, long long* __restrict__ ts,
+                                                 unsigned* sb = nullptr, unsigned epoch = 0, int sbmode = 0) {
+    unsigned off[RT][RW];
+    if (ts && threadIdx.x == 0) ts[blockIdx.x] = wall_clock64();
+    double v[RT][RW], sum[RT];
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(x), 0, 0x7fffffff, 0x00020000);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (ING == 0) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int t = blockIdx.x + i * gridDim.x;
+        const long r = (long)t * ROWS + threadIdx.x;
+        sum[i] = 0.0;
+        int cur = 0, fin = 0;
+        if (t < T && r < n) { cur = ip[r]; fin = ip[r + 1]; }
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const bool has = cur + j < fin;
+            const int idx = has ? cur + j : 0;
+            const unsigned cc = (unsigned)cols[idx] << 3;
+            const double vv = vals[idx];
+            off[i][j] = has ? cc : 0xffffffffu;
+            v[i][j] = has ? vv : 0.0;
+        }
+    }
+    } else {
+    // staged as the library does (mk_spmv_fmt3r.h): columns of the RT tiles stay in LDS, values pass through a staging area
+    int* lc = (int*)smem;                                    // [RT][RCAP]
+    double* lv = (double*)(lc + (RT - 1) * RCAP);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int cur[RT], len[RT], base[RT], cnt[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int t = blockIdx.x + i * gridDim.x;
+        sum[i] = 0.0; cur[i] = len[i] = base[i] = cnt[i] = 0;
+#pragma unroll
+        for (int j = 0; j < RW; ++j) v[i][j] = 0.0;
+        if (t < T) {
+            const int row0 = t * ROWS, rowe = min(n, row0 + ROWS);
+            const int e0 = ip[row0], e1 = ip[rowe];
+            base[i] = e0 & ~3; cnt[i] = e1 - base[i];
+            const int lastv = (cnt[i] > 0) ? ((cnt[i] - 1) & ~1) : 0;
+            for (int c0 = wv * 128; c0 < cnt[i]; c0 += 4 * 128) {
+                int j = c0 + 2 * lane; j = j < lastv ? j : lastv;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vals + base[i] + j),
+                                                 (__attribute__((address_space(3))) void*)(lv + c0), 16, 0, 0);
+            }
+            const int r = row0 + threadIdx.x;
+            if (r < n) { cur[i] = ip[r] - base[i]; len[i] = ip[r + 1] - base[i] - cur[i]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < RW; ++j) { const double vv = lv[(j < len[i]) ? cur[i] + j : 0]; v[i][j] = (j < len[i]) ? vv : 0.0; }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int last = (cnt[i] > 0) ? ((cnt[i] - 1) & ~3) : 0;
+        for (int c0 = wv * 256; c0 < cnt[i]; c0 += 4 * 256) {
+            int j = c0 + 4 * lane; j = j < last ? j : last;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cols + base[i] + j),
+                                             (__attribute__((address_space(3))) void*)(lc + i * RCAP + c0), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+            off[i][j] = (j < len[i]) ? (unsigned)lc[i * RCAP + cur[i] + j] << 3 : 0xffffffffu;
+    }
+    for (int k = 0; k < K; ++k) {
+        if (sb && (k == 0 || sbmode == 2)) soft_barrier(sb, k, epoch * (gridDim.x / 8));
+        if (ts && threadIdx.x == 0) ts[(size_t)(k + 1) * gridDim.x + blockIdx.x] = wall_clock64();
+        const unsigned o_lo = (unsigned)(k * W) << 3;
+        const unsigned o_hi = (k + 1 < K) ? (unsigned)((k + 1) * W) << 3 : 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            double xv[RW];
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                const bool in = off[i][j] >= o_lo && off[i][j] < o_hi;
+                xv[j] = 0.0;
+                if (in) {
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    const u2 w = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(xres, (int)off[i][j], 0, 0));
+                    xv[j] = __builtin_bit_cast(double, w);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                const bool in = off[i][j] >= o_lo && off[i][j] < o_hi;
+                const double tt = sum[i] + v[i][j] * xv[j];
+                sum[i] = in ? tt : sum[i];
+            }
+        }
+    }
+    if (ts && threadIdx.x == 0) ts[(size_t)(K + 1) * gridDim.x + blockIdx.x] = wall_clock64();
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int t = blockIdx.x + i * gridDim.x;
+        const long r = (long)t * ROWS + threadIdx.x;
+        if (t < T && r < n) y[r] = sum[i];
+    }
+}
+
 // gath : the raw cost of the gathers alone: out[lane] = sum of x[idx[j]] over a grid-stride range (no values, no rows)
 template <int U>
 __global__ __launch_bounds__(BLOCK) void gath(long nnz, const int* __restrict__ idx, const double* __restrict__ x, double* __restrict__ out) {
@@ -303,6 +427,49 @@ int main(int argc, char** argv) {
             CK(hipFuncSetAttribute((const void*)cb_res<TW, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             float ms = timeit([&] { hipLaunchKernelGGL((cb_res<TW, U>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy); }, reps); \
             CK(hipGetLastError()); check("res"); printf("K=%2d res%d  grid=%4d tiles/wg=%d : %7.1f us  %5.2f TB/s (frac %.3f)\n", K, U, G, TW, ms * 1e3, alg / ms / 1e9, alg / ms / 1e9 / 8.0); }
+#define RUNREG(RT, OCC, G) { CK(hipMemset(dy, 0, 8L * n)); \
+            float ms = timeit([&] { hipLaunchKernelGGL((cb_reg<RT, 5, OCC>), dim3(G), dim3(BLOCK), 0, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, (long long*)nullptr); }, reps); \
+            CK(hipGetLastError()); check("reg"); printf("K=%2d reg   grid=%4d tiles/wg=%d occ=%d : %7.1f us  %5.2f TB/s (frac %.3f)\n", K, G, RT, OCC, ms * 1e3, alg / ms / 1e9, alg / ms / 1e9 / 8.0); }
+        if (getenv("REG_TS")) {   // per-workgroup wall-clock stamps (100 MHz) at kernel start, at every phase start and at the end
+            const int G = g2; std::vector<long long> h((size_t)(K + 2) * G); long long* dts; CK(hipMalloc(&dts, 8 * h.size()));
+            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((cb_reg<2, 5, 8>), dim3(G), dim3(BLOCK), 0, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, dts);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(h.data(), dts, 8 * h.size(), hipMemcpyDeviceToHost));
+            long long t0 = h[0]; for (int b = 0; b < G; ++b) t0 = std::min(t0, h[b]);
+            for (int k = 0; k < K + 2; ++k) { long long lo = 1LL << 62, hi = 0; double av = 0; for (int b = 0; b < G; ++b) { long long v = h[(size_t)k * G + b] - t0; lo = std::min(lo, v); hi = std::max(hi, v); av += v; }
+                printf("  stamp %d: min %.2f us  mean %.2f us  max %.2f us\n", k, lo / 100.0, av / G / 100.0, hi / 100.0); }
+            CK(hipFree(dts)); }
+#define RUNREGL(RT, OCC, G) { CK(hipMemset(dy, 0, 8L * n)); const size_t lds = (size_t)(RT + 1) * RCAP * 4; \
+            CK(hipFuncSetAttribute((const void*)cb_reg<RT, 5, OCC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            float ms = timeit([&] { hipLaunchKernelGGL((cb_reg<RT, 5, OCC, 1>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, (long long*)nullptr); }, reps); \
+            CK(hipGetLastError()); check("regL"); printf("K=%2d regL  grid=%4d tiles/wg=%d occ=%d : %7.1f us  %5.2f TB/s (frac %.3f)\n", K, G, RT, OCC, ms * 1e3, alg / ms / 1e9, alg / ms / 1e9 / 8.0); }
+        if (getenv("REG_TS")) {
+            const int G = g2; std::vector<long long> h((size_t)(K + 2) * G); long long* dts; CK(hipMalloc(&dts, 8 * h.size()));
+            const size_t lds = (size_t)3 * RCAP * 4;
+            CK(hipFuncSetAttribute((const void*)cb_reg<2, 5, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((cb_reg<2, 5, 8, 1>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, dts);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(h.data(), dts, 8 * h.size(), hipMemcpyDeviceToHost));
+            long long t0 = h[0]; for (int b = 0; b < G; ++b) t0 = std::min(t0, h[b]);
+            for (int k = 0; k < K + 2; ++k) { long long lo = 1LL << 62, hi = 0; double av = 0; for (int b = 0; b < G; ++b) { long long v = h[(size_t)k * G + b] - t0; lo = std::min(lo, v); hi = std::max(hi, v); av += v; }
+                printf("  regL stamp %d: min %.2f us  mean %.2f us  max %.2f us\n", k, lo / 100.0, av / G / 100.0, hi / 100.0); }
+            CK(hipFree(dts)); }
+#define RUNREGS(RT, OCC, G0, MODE) { const int G = (G0 + 7) / 8 * 8; CK(hipMemset(dy, 0, 8L * n)); const size_t lds = (size_t)(RT + 1) * RCAP * 4; \
+            CK(hipFuncSetAttribute((const void*)cb_reg<RT, 5, OCC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            unsigned* dsb; CK(hipMalloc(&dsb, 4 * 32 * 8 * 64)); CK(hipMemset(dsb, 0, 4 * 32 * 8 * 64)); unsigned ep = 0; \
+            float ms = timeit([&] { ++ep; hipLaunchKernelGGL((cb_reg<RT, 5, OCC, 1>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, (long long*)nullptr, dsb, ep, MODE); }, reps); \
+            CK(hipGetLastError()); check("regS"); printf("K=%2d regS%d grid=%4d tiles/wg=%d occ=%d : %7.1f us  %5.2f TB/s (frac %.3f)\n", K, MODE, G, RT, OCC, ms * 1e3, alg / ms / 1e9, alg / ms / 1e9 / 8.0); CK(hipFree(dsb)); }
+        if (getenv("REG_TS")) for (int mode = 1; mode <= 2; ++mode) {
+            const int G = (g2 + 7) / 8 * 8; std::vector<long long> h((size_t)(K + 2) * G); long long* dts; CK(hipMalloc(&dts, 8 * h.size()));
+            const size_t lds = (size_t)3 * RCAP * 4;
+            unsigned* dsb; CK(hipMalloc(&dsb, 4 * 32 * 8 * 64)); CK(hipMemset(dsb, 0, 4 * 32 * 8 * 64));
+            for (unsigned rep = 1; rep <= 3; ++rep) hipLaunchKernelGGL((cb_reg<2, 5, 8, 1>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, dts, dsb, rep, mode);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(h.data(), dts, 8 * h.size(), hipMemcpyDeviceToHost));
+            long long t0 = h[0]; for (int b = 0; b < G; ++b) t0 = std::min(t0, h[b]);
+            for (int k = 0; k < K + 2; ++k) { long long lo = 1LL << 62, hi = 0; double av = 0; for (int b = 0; b < G; ++b) { long long v = h[(size_t)k * G + b] - t0; lo = std::min(lo, v); hi = std::max(hi, v); av += v; }
+                printf("  regS%d stamp %d: min %.2f us  mean %.2f us  max %.2f us\n", mode, k, lo / 100.0, av / G / 100.0, hi / 100.0); }
+            CK(hipFree(dts)); CK(hipFree(dsb)); }
+        if (getenv("REG_ONLY") || getenv("REG")) { RUNREGS(2, 8, g2, 1) RUNREGS(2, 8, g2, 2) RUNREGS(4, 4, g4, 1) RUNREGS(4, 4, g4, 2) RUNREGS(1, 8, 2048, 1) RUNREGS(1, 8, 2048, 2)
+        RUNREGL(1, 8, g1) RUNREGL(2, 8, g2) RUNREGL(4, 4, g4) RUNREG(1, 8, g1) RUNREG(2, 8, g2) RUNREG(2, 4, g2) RUNREG(4, 4, g4) RUNREG(4, 2, g4) }
+        if (getenv("REG_ONLY")) { CK(hipFree(dseg)); CK(hipFree(dcols)); CK(hipFree(dvals)); CK(hipFree(dro)); continue; }
         RUNRES(1, 1, g1) RUNRES(1, 2, g1) RUNRES(2, 1, g2) RUNRES(2, 2, g2) RUNRES(4, 1, g4) RUNRES(4, 2, g4)
         if (getenv("RES_ONLY")) { CK(hipFree(dseg)); CK(hipFree(dcols)); CK(hipFree(dvals)); CK(hipFree(dro)); continue; }
         RUN(cb_lane, 1, g1, "lane") RUN(cb_lane, 2, g2, "lane") RUN(cb_lane, 4, g4, "lane")
