@@ -295,6 +295,9 @@ extern "C" int mk_csr_set_exchange(mk_csr *A, int mode, int64_t n_local, int64_t
                                    const int64_t *recv_count, const int32_t *send_idx_host) {
     MK_REQUIRE_INIT();
     MK_ARG(A && (mode == 0 || mode == 1) && n_local >= 0 && n_halo >= 0);
+    if (A->comp_kind || A->host_fn)                          // (composites and shells have no arrays to split into tiles)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_set_exchange: only a plain device matrix can carry an exchange plan "
+                       "(partition the operands of a composite, not the composite)");
     MK_ARG(n_local == A->nrows);
     MK_ARG(n_local + n_halo == A->ncols);     // columns are already remapped to [local | halo]
     MkExchange &ex = A->ex;
@@ -370,6 +373,8 @@ extern "C" int mk_csr_localize(mk_csr *A, int mode, int64_t col_begin, int64_t c
                                int64_t *halo_lo, int64_t *halo_hi) {
     MK_REQUIRE_INIT();
     MK_ARG(A && (mode == 0 || mode == 1) && col_begin >= 0 && col_begin <= col_end && col_end <= A->ncols);
+    if (A->comp_kind || A->host_fn)
+        return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_localize: only a plain device matrix has columns to renumber");
     MK_ARG(col_end - col_begin == A->nrows);
     hipStream_t st = mk_ctx().stream;
     const int64_t n_local = A->nrows;

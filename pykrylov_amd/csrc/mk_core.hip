@@ -536,7 +536,7 @@ extern "C" int mk_csr_create_reduced(const mk_csr *A, int64_t nrows, const int32
 }
 
 // an operand loses one dependent; if its owner has destroyed it in the meantime, it goes now
-static void mk_release_operand(const mk_csr *B) {
+void mk_release_operand(const mk_csr *B) {
     if (!B) return;
     B->dependents -= 1;
     if (B->dependents <= 0 && B->doomed) mk_csr_destroy(const_cast<mk_csr *>(B));

@@ -801,6 +801,13 @@ bool pattern_plan(const mk_csr *A, MkPlan &P, bool raw) {
         if (!ok) {
             hipFree(d_ptab);
             hipFree(d_pinfo);
+            if (raw) {                                       // (the value blocks sell_build stored just above)
+                hipFree(P.d_sval);
+                hipFree(P.d_sdesc);
+                P.d_sval = nullptr;
+                P.d_sdesc = nullptr;
+                P.sell_entries = 0;
+            }
             return cleanup();
         }
         P.d_ptab = d_ptab;

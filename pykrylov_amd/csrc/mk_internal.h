@@ -197,6 +197,7 @@ struct mk_csr {
 };
 
 int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out);
+void mk_release_operand(const mk_csr *B);   // a borrower lets go: the matrix is destroyed now if its owner already asked for it
 void mk_csr_plan_reset(const mk_csr *A);    // drop the windowed format (it is rebuilt on the next product)
 
 // grid sizes -------------------------------------------------------------------------

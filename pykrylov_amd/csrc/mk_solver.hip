@@ -3,6 +3,7 @@
 
 int mk_solver::init_common(const mk_csr *A_, const mk_params *p) {
     A = A_;
+    A->dependents += 1;              // (borrowed for the solver's lifetime: destroying A meanwhile is deferred)
     prm = *p;
     n = A->ex.mode >= 0 ? A->ex.n_local : A->nrows;
     const bool rectangular_ok = prm.kind >= MK_LSQR;
@@ -68,6 +69,10 @@ int mk_solver::host_precon(const double *in_dev, double *out_dev, bool force) {
 }
 
 mk_solver::~mk_solver() {
+    if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
+    if (precon_op) mk_release_operand(precon_op);
+    if (At) mk_release_operand(At);
+    if (A) mk_release_operand(A);
     hipFree(d_ones);
     hipFree(d_ptmp);
     hipFree(d_nohalt);
@@ -288,6 +293,8 @@ extern "C" int mk_solver_create(const mk_csr *A, const mk_params *params, mk_sol
 extern "C" int mk_solver_set_transpose(mk_solver *s, const mk_csr *At) {
     MK_ARG(s && At);
     MK_ARG(At->nrows == s->A->ncols && At->ncols == s->A->nrows && At->nnz == s->A->nnz);
+    if (s->At) mk_release_operand(s->At);
+    At->dependents += 1;
     s->At = At;
     return MK_OK;
 }
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(MK_BLOCK) void mk_fill_kernel(double *v, int64_t n,
 
 extern "C" int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void *user) {
     MK_ARG(s);
+    if (s->precon_op) mk_release_operand(s->precon_op);
     s->precon_op = nullptr;
     if (!fn) {
         s->precon_fn = nullptr;
@@ -344,6 +352,7 @@ extern "C" int mk_solver_set_precon_callback(mk_solver *s, mk_precon_fn fn, void
 extern "C" int mk_solver_set_precon_csr(mk_solver *s, const mk_csr *M) {
     MK_ARG(s);
     if (!M) {
+        if (s->precon_op) mk_release_operand(s->precon_op);
         s->precon_op = nullptr;
         s->precon_fn = nullptr;
         s->d_prec = nullptr;
@@ -365,6 +374,8 @@ extern "C" int mk_solver_set_precon_csr(mk_solver *s, const mk_csr *M) {
         MK_HIP(hipMalloc((void **)&s->d_nohalt, 2 * sizeof(int)));
         MK_HIP(hipMemsetAsync(s->d_nohalt, 0, 2 * sizeof(int), s->stream));
     }
+    M->dependents += 1;
+    if (s->precon_op) mk_release_operand(s->precon_op);
     s->precon_op = M;
     s->precon_fn = mk_precon_on_device;                      // (marks "general preconditioner" at the call sites)
     s->precon_user = nullptr;

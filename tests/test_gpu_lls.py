@@ -92,8 +92,11 @@ def test_lls_bit_exact_with_emulated_dot_order(golden, tag, solver, btag, damp, 
 
 @pytest.mark.parametrize("tag,solver,btag,damp,etol", list(cases()))
 def test_lls_vs_golden(golden, tag, solver, btag, damp, etol):
-    """Against the reference's own run (np.dot order): same istop / iteration count, x to 1e-10 relative (the
-    bidiagonalisation loses orthogonality like every Lanczos process; these runs are short enough)."""
+    """Against the reference's own run (np.dot order): same istop family, iteration count within one, x to 1e-5 relative
+    and the norm estimates to 1e-2 -- the fixtures stop at etol = 1e-6 on an ESTIMATE of the direct error, so x is only
+    determined to about that accuracy, and the Golub-Kahan vectors of any two summation orders drift apart like every
+    Lanczos process.  The tight statements are elsewhere: bit equality with the oracle in the device's summation order
+    (test above) and <= 1e-12 against the order-independent anchor with etol = 0 (tests/test_gpu_anchors.py)."""
     d = golden("lls_random.npz")
     A = golden_csr(d, tag + "_A_")
     b = d[tag + "_b_" + btag]
