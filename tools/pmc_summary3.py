@@ -16,7 +16,7 @@ WORKLOADS = [("varcoef", "poisson3d-512-varcoef@1", "CG, 512^3 variable coeffici
              ("p2d", "poisson2d-1000@1", "CG, 2-D n = 1e6"),
              ("s27c", "stencil27-256@1", "CG, 27-point stencil 256^3, constant coefficients (format 8)"),
              ("s27v", "stencil27-256-varcoef@1", "CG, 27-point stencil 256^3, variable coefficients (format 7)"),
-             ("others", None, "BiCGSTAB random n = 1e6 and MINRES shifted 2-D n = 4e6")]
+             ("others", None, "the nine other solver loops: BiCGSTAB / CGS / TFQMR (random n = 1e6), MINRES / SYMMLQ (shifted 2-D n = 4e6), LSQR / LSMR / CRAIG / CRAIG-MR (random 4e6 x 1e6)")]
 
 
 def main():
