@@ -77,6 +77,7 @@ struct MkCsrView {
     int allwin;              // every tile of the matrix has windows (no tile ever takes the gather path)
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
+    int rt_reg;              // fmt 3: rows of <= 5 entries -- a second tile per workgroup rides in registers (mk_spmv_fmt3r.h)
     // column-blocked products (fmt 0, 3): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
     const double *sum_in;
     // matrix-free operators (host callback): cb_mode 1 = materialise the product's input vector (`vin[j] = xin(x[j])`,
@@ -240,6 +241,7 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.rt_cap = P->rt_cap;
         v.rt_k = P->rt_k;
         v.rt_w = P->rt_w;
+        v.rt_reg = P->rt_reg;
     } else if (v.fmt) {
         v.wchunks = P->wchunks;
         v.ndict = P->ndict;
@@ -521,12 +523,14 @@ __device__ __forceinline__ void mk_load_meta(const MkCsrView &A, int64_t p, int6
 #include "mk_spmv_fmt1.h"
 #include "mk_spmv_fmt24.h"
 #include "mk_spmv_fmt3.h"
+#include "mk_spmv_fmt3r.h"
 #include "mk_spmv_fmt5.h"
 #include "mk_spmv_fmtw.h"
 
 constexpr int MK_FMT_WIDE = 7;                       // template values of the wide kernels (6 = format 5, non-temporal):
 constexpr int MK_FMT_WIDE_DICT = 8;                  // 7 streams values (fmt 6, 7), 8 takes them from the dictionary (fmt 8),
 constexpr int MK_FMT_WIDE_NT = 9;                    // 9 = 7 with non-temporal loads of the streams
+constexpr int MK_FMT_PAIR = 10;                      // format 3 with a second tile per workgroup in registers (rows <= 5 entries)
 
 template <int FMT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
@@ -534,6 +538,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     if constexpr (FMT == 0) mk_spmv_tiles_fmt0<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 1) mk_spmv_tiles_fmt1<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 3) mk_spmv_tiles_fmt3<PROG>(A, x, epi, prod, xw, acc);
+    else if constexpr (FMT == MK_FMT_PAIR) mk_spmv_tiles_fmt3r<5, PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == MK_FMT_WIDE || FMT == MK_FMT_WIDE_DICT || FMT == MK_FMT_WIDE_NT)
         mk_spmv_tiles_wide<FMT == MK_FMT_WIDE_DICT, FMT == MK_FMT_WIDE_NT, PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT >= 5) mk_spmv_tiles_fmt5<PROG, FMT == 6>(A, x, epi, prod, xw, acc);
@@ -548,13 +553,13 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3) ? 8 : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
     extern __shared__ __attribute__((aligned(16))) double mk_smem[];
     double *prod = mk_smem;
-    double *xw = (FMT == 2 || FMT >= 4) ? mk_smem : mk_smem + MK_PROD_LDS;
+    double *xw = (FMT == 2 || (FMT >= 4 && FMT < 10)) ? mk_smem : mk_smem + MK_PROD_LDS;
     __shared__ double s4[4];
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -642,8 +647,12 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
                                gate, halt, partials);
     } else if (v.fmt == 3) {                                 // the tile's values and columns
         lds = (size_t)v.rt_cap * 12;
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 3>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
-                           halt, partials);
+        if (v.rt_reg && !v.tiles)
+            hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PAIR>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi,
+                               gate, halt, partials);
+        else
+            hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 3>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
+                               halt, partials);
     } else if (v.fmt == 2)
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 2>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi, gate,
                            halt, partials);

@@ -602,14 +602,19 @@ int cblocks_build(const mk_csr *A) {
 // longest tile stream (nonzeros of 256 rows, counted from the 4-aligned start the kernels copy from)
 __global__ __launch_bounds__(MK_BLOCK) void tile_extent_kernel(const int32_t *__restrict__ indptr, int64_t nrows,
                                                                int64_t ntiles, int *__restrict__ out) {
-    int mx = 0;
+    int mx = 0, mrow = 0;
     for (int64_t t = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; t < ntiles; t += (int64_t)gridDim.x * MK_BLOCK) {
         const int64_t r0 = t * MK_ROWS_PER_TILE;
         const int64_t r1 = (r0 + MK_ROWS_PER_TILE < nrows) ? r0 + MK_ROWS_PER_TILE : nrows;
         const int len = indptr[r1] - (indptr[r0] & ~3);
         mx = len > mx ? len : mx;
     }
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        const int len = indptr[r + 1] - indptr[r];
+        mrow = len > mrow ? len : mrow;
+    }
     atomicMax(out, mx);
+    atomicMax(out + 1, mrow);                                // longest row
 }
 
 // fmt 3: a matrix that stays on plain CSR, whose x is longer than an XCD's L2 (4 MiB; the gather path still wins up
@@ -624,13 +629,14 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     if (!forced && (xbytes <= 5 * (1 << 20) || getenv("MK_NO_RESIDENT"))) return MK_OK;   // (crossover measured at 650 k rows x 5)
     if (A->ex.mode >= 0 && !forced) return MK_OK;            // (partitioned matrices: their x slices are short already)
     hipStream_t st = mk_ctx().stream;
-    int *d_max = nullptr, h_max = 0;
-    if (hipMalloc((void **)&d_max, sizeof(int)) != hipSuccess) return MK_OK;
-    hipMemsetAsync(d_max, 0, sizeof(int), st);
+    int *d_max = nullptr, h_mm[2] = {0, 0};
+    int &h_max = h_mm[0];
+    if (hipMalloc((void **)&d_max, 2 * sizeof(int)) != hipSuccess) return MK_OK;
+    hipMemsetAsync(d_max, 0, 2 * sizeof(int), st);
     int grid = (int)((A->ntiles + MK_BLOCK - 1) / MK_BLOCK);
     grid = grid > 1024 ? 1024 : grid;
     hipLaunchKernelGGL(tile_extent_kernel, dim3(grid), dim3(MK_BLOCK), 0, st, A->d_indptr, A->nrows, A->ntiles, d_max);
-    const bool ok = hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+    const bool ok = hipMemcpyAsync(h_mm, d_max, 2 * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
                     hipStreamSynchronize(st) == hipSuccess;
     hipFree(d_max);
     if (!ok || h_max < 1) return MK_OK;
@@ -644,6 +650,12 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     P.rt_cap = cap;
     P.rt_k = (int)k;
     P.rt_w = (int)((A->x_len() + k - 1) / k);
+    // short rows and more tiles than resident workgroups: pairs of tiles, the second one in registers (mk_spmv_fmt3r.h).
+    // MK_RT_REG=0 keeps one tile per step (A/B measurements).
+    P.max_row = h_mm[1];
+    static const char *ereg = getenv("MK_RT_REG");
+    const int allow = ereg ? atoi(ereg) : 1;
+    P.rt_reg = (allow >= 1 && h_mm[1] <= 5 && A->ntiles > MK_MAXP && 8 * A->x_len() < ((int64_t)1 << 31)) ? 1 : 0;
     return MK_OK;
 }
 

@@ -134,6 +134,8 @@ struct MkPlan {
     int rt_cap = 0;                // LDS capacity per tile in nonzeros (max tile stream length rounded up to 256)
     int rt_k = 1;                  // column phases
     int rt_w = 0;                  // columns per phase
+    int rt_reg = 0;                // rows of <= 5 entries and more tiles than resident workgroups: pairs of tiles (mk_spmv_fmt3r.h)
+    int max_row = 0;               // longest row (entries) of the matrix
     // column blocks (plain-CSR matrices whose x does not fit an XCD's L2): A = [A_0 | A_1 | ...] by column range,
     // each block a CSR matrix over all rows; a product runs block after block with the running row sums carried
     std::vector<struct mk_csr *> cblocks;

@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_$TAG
+OUT=/tmp/prof_$TAG          # (raw rocprofv3 output stays on the box: gpurun_out/ is capped at 64 MiB)
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 declare -A CMD
@@ -38,4 +38,9 @@ rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/cal_1 -o cal -- python $R/tools/pmc_ca
 rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/cal_2 -o cal -- python $R/tools/pmc_calibrate.py > $OUT/cal_write.log 2>&1
 cd $R
 python tools/pmc_summary3.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt
+KEEP=$R/gpurun_out/prof_$TAG
+rm -rf $KEEP; mkdir -p $KEEP
+cp $OUT/summary.txt $OUT/spmv_traffic.json $OUT/bench_trace_*.json $KEEP/ 2>/dev/null
+for d in $OUT/trace_*; do [ -d "$d" ] && for f in $(find $d -name "*kernel_stats.csv"); do cp $f $KEEP/$(basename $d)_kernel_stats.csv; done; done
+cp $OUT/*.err $KEEP/ 2>/dev/null
+tail -n 60 $OUT/summary.txt

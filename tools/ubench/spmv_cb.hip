@@ -306,6 +306,84 @@ __global__ __launch_bounds__(BLOCK, OCC) void cb_reg(int T, int K, int n, int W,
     }
 }
 
+// pair : the library's round-4 kernel (mk_spmv_fmt3r.h): tile A in LDS walked with a cursor, tile B (the workgroup's next
+//        tile) in registers with static exec-masked gathers issued before A's walk.  PAIR = 0: tile A only (= the library's
+//        format-3 kernel, one tile per step).  Stamps: 0 start, 1 after B's ingest, 2 after A's ingest, 3 .. K + 2 phase ends.
+template <int PAIR>
+__global__ __launch_bounds__(BLOCK, 8) void cb_pair(int T, int K, int n, int W, const int* __restrict__ ip,
+                                                    const int* __restrict__ cols, const double* __restrict__ vals,
+                                                    const double* __restrict__ x, double* __restrict__ y, long long* __restrict__ ts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* lv = (double*)smem;
+    int* lc = (int*)(lv + RCAP);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(x), 0, 0x7fffffff, 0x00020000);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    auto ingest = [&](int t, int& cur, int& fin) {
+        const int row0 = t * ROWS, rowe = min(n, row0 + ROWS);
+        const int e0 = ip[row0], e1 = ip[rowe];
+        const int base = e0 & ~3, cnt = e1 - base;
+        const int last = (cnt > 0) ? ((cnt - 1) & ~3) : 0;
+        for (int c0 = wv * 256; c0 < cnt; c0 += 4 * 256) {
+            int j = c0 + 4 * lane; j = j < last ? j : last;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cols + base + j),
+                                             (__attribute__((address_space(3))) void*)(lc + c0), 16, 0, 0);
+        }
+        const int lastv = (cnt > 0) ? ((cnt - 1) & ~1) : 0;
+        for (int c0 = wv * 128; c0 < cnt; c0 += 4 * 128) {
+            int j = c0 + 2 * lane; j = j < lastv ? j : lastv;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vals + base + j),
+                                             (__attribute__((address_space(3))) void*)(lv + c0), 16, 0, 0);
+        }
+        cur = fin = 0;
+        const int r = row0 + threadIdx.x;
+        if (r < rowe) { cur = ip[r] - base; fin = ip[r + 1] - base; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    int stampi = 0;
+    auto stamp = [&]() { if (ts && threadIdx.x == 0 && stampi < 16) ts[(size_t)stampi * gridDim.x + blockIdx.x] = wall_clock64(); ++stampi; };
+    for (int pos = blockIdx.x; pos < T; pos += (PAIR ? 2 : 1) * gridDim.x) {
+        const bool first = (pos == (int)blockIdx.x);
+        if (first) stamp();
+        unsigned ob[5]; double vb[5]; double sumb = 0.0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { ob[j] = 0xffffffffu; vb[j] = 0.0; }
+        const int posb = pos + gridDim.x;
+        const bool has_b = PAIR && posb < T;
+        if (has_b) {
+            int cur, fin; ingest(posb, cur, fin);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { const bool has = cur + j < fin; const int idx = has ? cur + j : 0; const unsigned cc = (unsigned)lc[idx] << 3; const double vv = lv[idx]; ob[j] = has ? cc : 0xffffffffu; vb[j] = has ? vv : 0.0; }
+            __syncthreads();
+        }
+        if (first) stamp();
+        int cur, fin; double sum = 0.0;
+        ingest(pos, cur, fin);
+        if (first) stamp();
+        for (int k = 0; k < K; ++k) {
+            const int c1 = (k + 1 < K) ? (k + 1) * W : 0x7fffffff;
+            const unsigned o_lo = (unsigned)(k * W) << 3, o_hi = (k + 1 < K) ? (unsigned)c1 << 3 : 0xffffffffu;
+            double xb[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { xb[j] = 0.0; if (PAIR && ob[j] >= o_lo && ob[j] < o_hi) { const u2 w = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(xres, (int)ob[j], 0, 0)); xb[j] = __builtin_bit_cast(double, w); } }
+            for (;;) {
+                int ca = 0x7fffffff;
+                if (cur < fin) ca = lc[cur];
+                const bool oa = ca < c1;
+                if (oa) { sum += lv[cur] * x[ca]; cur += 1; }
+                if (!__any(oa)) break;
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { const bool in = ob[j] >= o_lo && ob[j] < o_hi; const double t = sumb + vb[j] * xb[j]; sumb = in ? t : sumb; }
+            if (first) stamp();
+        }
+        { const long r = (long)pos * ROWS + threadIdx.x; if (r < n) y[r] = sum; }
+        if (has_b) { const long r = (long)posb * ROWS + threadIdx.x; if (r < n) y[r] = sumb; }
+        __syncthreads();
+    }
+}
+
 // gath : the raw cost of the gathers alone: out[lane] = sum of x[idx[j]] over a grid-stride range (no values, no rows)
 template <int U>
 __global__ __launch_bounds__(BLOCK) void gath(long nnz, const int* __restrict__ idx, const double* __restrict__ x, double* __restrict__ out) {
@@ -457,6 +535,22 @@ int main(int argc, char** argv) {
             unsigned* dsb; CK(hipMalloc(&dsb, 4 * 32 * 8 * 64)); CK(hipMemset(dsb, 0, 4 * 32 * 8 * 64)); unsigned ep = 0; \
             float ms = timeit([&] { ++ep; hipLaunchKernelGGL((cb_reg<RT, 5, OCC, 1>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, (long long*)nullptr, dsb, ep, MODE); }, reps); \
             CK(hipGetLastError()); check("regS"); printf("K=%2d regS%d grid=%4d tiles/wg=%d occ=%d : %7.1f us  %5.2f TB/s (frac %.3f)\n", K, MODE, G, RT, OCC, ms * 1e3, alg / ms / 1e9, alg / ms / 1e9 / 8.0); CK(hipFree(dsb)); }
+        if (getenv("PAIR")) for (int pair = 0; pair <= 1; ++pair) {
+            const int G = 2048; const size_t lds = (size_t)RCAP * 12; const int NS = K + 3;
+            std::vector<long long> h((size_t)16 * G); long long* dts; CK(hipMalloc(&dts, 8 * h.size())); CK(hipMemset(dts, 0, 8 * h.size()));
+            auto launch = [&](long long* t) { if (pair) hipLaunchKernelGGL((cb_pair<1>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, t);
+                                              else hipLaunchKernelGGL((cb_pair<0>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, t); };
+            CK(hipMemset(dy, 0, 8L * n));
+            float ms = timeit([&] { launch(nullptr); }, reps);
+            check("pair");
+            printf("K=%2d pair=%d grid=%4d : %7.1f us\n", K, pair, G, ms * 1e3);
+            for (int rep = 0; rep < 3; ++rep) launch(dts);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(h.data(), dts, 8 * h.size(), hipMemcpyDeviceToHost));
+            long long t0 = h[0]; for (int b = 0; b < G; ++b) t0 = std::min(t0, h[b]);
+            for (int k = 0; k < NS; ++k) { long long lo = 1LL << 62, hi = 0; double av = 0; for (int b = 0; b < G; ++b) { long long v = h[(size_t)k * G + b] - t0; lo = std::min(lo, v); hi = std::max(hi, v); av += v; }
+                printf("  pair=%d stamp %d: min %.2f us  mean %.2f us  max %.2f us\n", pair, k, lo / 100.0, av / G / 100.0, hi / 100.0); }
+            CK(hipFree(dts)); }
+        if (getenv("PAIR_ONLY")) { CK(hipFree(dseg)); CK(hipFree(dcols)); CK(hipFree(dvals)); CK(hipFree(dro)); continue; }
         if (getenv("REG_TS")) for (int mode = 1; mode <= 2; ++mode) {
             const int G = (g2 + 7) / 8 * 8; std::vector<long long> h((size_t)(K + 2) * G); long long* dts; CK(hipMalloc(&dts, 8 * h.size()));
             const size_t lds = (size_t)3 * RCAP * 4;
