@@ -78,6 +78,11 @@ struct MkCsrView {
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
     int rt_reg;              // fmt 3: rows of <= 5 entries -- a second tile per workgroup rides in registers (mk_spmv_fmt3r.h)
+    // ... and a product of MANY pair steps per workgroup runs as one launch per step (mk_spmv_launch_blocks): step0 / nsteps
+    // select the steps of this launch (nsteps 0: all), the per-lane accumulators of the fused dots travel through `carry`
+    int step0, nsteps;
+    double *carry;
+    int carry_in, carry_out;
     // column-blocked products (fmt 0, 3): the row sums start from sum_in[r] instead of +0.0 (null: +0.0)
     const double *sum_in;
     // matrix-free operators (host callback): cb_mode 1 = materialise the product's input vector (`vin[j] = xin(x[j])`,
@@ -168,6 +173,11 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
     if (getenv("MK_GRID_SPMV") || A->host_fn) return g;
     const MkPlan *P = mk_csr_plan(A);
     int64_t cap = mk_cap_spmv();
+    if (P && P->cblocks.size() >= 2 && P->cblocks[0]->plan.fmt == 3 && A->ex.mode < 0) {   // column blocks as resident tiles
+        int g3 = (int)(A->ntiles > MK_MAXP ? MK_MAXP : A->ntiles);
+        if (g3 >= 8) g3 -= g3 % 8;
+        return g3;
+    }
     if (P && P->fmt == 3) {                                  // as many as fit at once with one tile in LDS each
         int g3 = (int)(A->ntiles > MK_MAXP ? MK_MAXP : A->ntiles);
         if (g3 >= 8) g3 -= g3 % 8;
@@ -242,6 +252,7 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.rt_k = P->rt_k;
         v.rt_w = P->rt_w;
         v.rt_reg = P->rt_reg;
+        v.carry = P->d_carry;
     } else if (v.fmt) {
         v.wchunks = P->wchunks;
         v.ndict = P->ndict;
@@ -578,6 +589,12 @@ __global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 :
     double acc[Epi::NACC > 0 ? Epi::NACC : 1];
 #pragma unroll
     for (int d = 0; d < (Epi::NACC > 0 ? Epi::NACC : 1); ++d) acc[d] = 0.0;
+    if constexpr (FMT == 10 && Epi::NACC > 0) {
+        if (A.carry_in) {                                           // a later step of a product split into launches
+#pragma unroll
+            for (int d = 0; d < Epi::NACC; ++d) acc[d] = A.carry[((size_t)d * gridDim.x + blockIdx.x) * MK_BLOCK + threadIdx.x];
+        }
+    }
     if constexpr (FMT == 0 && !PROG) {
         if (A.cb_mode == 1) {                                       // matrix-free operator: the callback's input
             for (int64_t j = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; j < A.xlen; j += (int64_t)gridDim.x * MK_BLOCK)
@@ -597,6 +614,15 @@ __global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 :
         }
     } else {
         mk_spmv_tiles<FMT, PROG>(A, x, epi, prod, xw, acc);
+    }
+    if constexpr (FMT == 10) {
+        if (A.carry_out) {                                          // not the last step: the accumulators travel on
+            if constexpr (Epi::NACC > 0) {
+#pragma unroll
+                for (int d = 0; d < Epi::NACC; ++d) A.carry[((size_t)d * gridDim.x + blockIdx.x) * MK_BLOCK + threadIdx.x] = acc[d];
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int d = 0; d < Epi::NACC; ++d) {
@@ -841,7 +867,27 @@ static inline void mk_spmv_launch_blocks(const mk_csr *A, int grid, hipStream_t 
     const MkPlan *P = mk_csr_plan(A);
     const size_t K = (P && A->ex.mode < 0) ? P->cblocks.size() : 0;
     if (K < 2) {
-        mk_spmv_launch_view(mk_view(A), grid, st, x, epi, gate, next(), partials);
+        MkCsrView v = mk_view(A);
+        // Format 3, pair kernel, many steps per workgroup (4e6 rows: 3.8): over the steps the workgroups of an XCD drift out of
+        // the lockstep the column phases live on, until every gather pulls its own sector through the fabric (1.38 GB per
+        // product for 0.31 GB of data).  One LAUNCH per step re-aligns them for the price of a kernel boundary: the first
+        // launch evaluates the gate with its side effects, the others repeat its decision, the per-lane accumulators of the
+        // fused dots travel through a carry buffer (same additions in the same order: same bits), the last launch reduces.
+        const int64_t per = 2 * (int64_t)grid;
+        const int64_t steps = (v.ntl + per - 1) / per;
+        if (v.fmt == 3 && v.rt_reg && !v.tiles && v.carry && v.map == 0 && steps >= 2 && steps <= 64 && Epi::NACC <= MK_CARRY_SLOTS) {
+            for (int64_t k = 0; k < steps; ++k) {
+                MkCsrView w = v;
+                w.step0 = (int)k;
+                w.nsteps = 1;
+                w.carry_in = k > 0;
+                w.carry_out = k + 1 < steps;
+                w.part = k ? 2 : 1;
+                mk_spmv_launch_view(w, grid, st, x, epi, gate, next(), partials);
+            }
+            return;
+        }
+        mk_spmv_launch_view(v, grid, st, x, epi, gate, next(), partials);
         return;
     }
     for (size_t k = 0; k < K; ++k) {
@@ -850,6 +896,13 @@ static inline void mk_spmv_launch_blocks(const mk_csr *A, int grid, hipStream_t 
         v.indptr = B->d_indptr;
         v.indices = B->d_indices;
         v.data = B->d_data;
+        if (B->plan.fmt == 3) {                              // (resident tiles, one phase: mk_format.hip cblocks_build)
+            v.fmt = 3;
+            v.rt_cap = B->plan.rt_cap;
+            v.rt_k = B->plan.rt_k;
+            v.rt_w = B->plan.rt_w;
+            v.rt_reg = 0;
+        }
         v.sum_in = k ? P->d_cbsum : nullptr;
         v.part = k ? 2 : 1;                                  // the gate's side effects happen in the first launch only
         if (k + 1 < K) {

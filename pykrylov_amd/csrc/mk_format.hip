@@ -497,6 +497,7 @@ void plan_free(MkPlan &P) {
     for (mk_csr *B : P.cblocks) mk_csr_destroy(B);
     P.cblocks.clear();
     hipFree(P.d_cbsum);
+    hipFree(P.d_carry);
     hipFree(P.d_slots);
     hipFree(P.d_wg);
     hipFree(P.d_wn);
@@ -544,6 +545,8 @@ int64_t colblock_bytes(const mk_csr *A) {
     const int64_t b = A->want_cb_kb >= 0 ? (int64_t)A->want_cb_kb * 1024 : env;
     return b < 0 ? 0 : b;
 }
+
+int resident_plan(const mk_csr *A, MkPlan &P, bool forced);
 
 // Column blocks for a plain-CSR matrix (scattered columns) whose x is more than two blocks long.  OFF by default:
 // measured on BASELINE configs[2] (random n = 1e6, 5 nnz/row; x = 8 MB against 4 MiB of L2 per XCD) a product costs
@@ -595,6 +598,27 @@ int cblocks_build(const mk_csr *A) {
     MK_HIP(hipMalloc((void **)&P.d_cbsum, sizeof(double) * (size_t)(A->nrows > 0 ? A->nrows : 1)));
     MK_HIP(hipStreamSynchronize(st));
     MK_HIP(hipGetLastError());
+    // Round 4: a block's rows are short (a long row cut into K pieces) and its columns span one slice of x that an L2 holds, so
+    // its launch takes the resident-tile kernel of format 3 with ONE phase -- the tile's (column, value) stream by DMA into LDS,
+    // lane t walks row t with a cursor, running sums in from / out to the carry vector -- instead of the gather path's two
+    // staged passes per 2 048 nonzeros: the lls `A' u` product 231 -> measured in DESIGN.md 3.1-6.  All blocks or none (one grid).
+    static const char *ecb = getenv("MK_CB_RESIDENT");
+    if (!ecb || atoi(ecb) > 0) {
+        bool all = true;
+        for (mk_csr *B : P.cblocks) {
+            B->plan = MkPlan();
+            B->plan.built = true;
+            if (resident_plan(B, B->plan, true) != MK_OK || B->plan.fmt != 3) all = false;
+            B->plan.rt_k = 1;                                // (the block's columns ARE one slice)
+            B->plan.rt_w = (int)(B->x_len() > 0x7fffffff ? 0x7fffffff : B->x_len());
+            B->plan.rt_reg = 0;
+        }
+        if (!all)
+            for (mk_csr *B : P.cblocks) {
+                B->plan = MkPlan();
+                B->plan.built = true;
+            }
+    }
     return MK_OK;
 }
 
@@ -656,6 +680,10 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     static const char *ereg = getenv("MK_RT_REG");
     const int allow = ereg ? atoi(ereg) : 1;
     P.rt_reg = (allow >= 1 && h_mm[1] <= 5 && A->ntiles > MK_MAXP && 8 * A->x_len() < ((int64_t)1 << 31)) ? 1 : 0;
+    static const char *estep = getenv("MK_RT_STEPPED");
+    if (P.rt_reg && A->ntiles > 2 * (int64_t)MK_MAXP && (!estep || atoi(estep) > 0)) {
+        if (hipMalloc((void **)&P.d_carry, sizeof(double) * MK_CARRY_SLOTS * MK_MAXP * MK_BLOCK) != hipSuccess) P.d_carry = nullptr;
+    }
     return MK_OK;
 }
 

@@ -21,6 +21,7 @@ constexpr int MK_ROWS_PER_TILE = 256; // SpMV: one row per thread in the row-sum
 constexpr int MK_SPMV_TILE = 2048;    // SpMV: products staged in LDS per pass (16 KiB)
 constexpr int MK_NSCAL = 160;         // device scalar file per solver
 constexpr int MK_NDOT = 6;           // reduction slots per solver (MK_MAXP doubles each)
+constexpr int MK_CARRY_SLOTS = 4;     // fused dots whose per-lane accumulators a stepped product carries between its launches
 
 // --------------------------------------------------------------------------------------
 // host context
@@ -136,6 +137,7 @@ struct MkPlan {
     int rt_w = 0;                  // columns per phase
     int rt_reg = 0;                // rows of <= 5 entries and more tiles than resident workgroups: pairs of tiles (mk_spmv_fmt3r.h)
     int max_row = 0;               // longest row (entries) of the matrix
+    double *d_carry = nullptr;     // per-lane accumulators of fused dots between the launches of a stepped product
     // column blocks (plain-CSR matrices whose x does not fit an XCD's L2): A = [A_0 | A_1 | ...] by column range,
     // each block a CSR matrix over all rows; a product runs block after block with the running row sums carried
     std::vector<struct mk_csr *> cblocks;

@@ -58,7 +58,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt3r(const MkCsrView &A, const do
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    for (; pos < end; pos += 2 * stride) {
+    pos += (int64_t)A.step0 * 2 * stride;                  // (a product split into one launch per step: mk_spmv_launch_blocks)
+    for (int step = 0; pos < end && (A.nsteps == 0 || step < A.nsteps); pos += 2 * stride, ++step) {
         // ---- tile B (the later one) first: through LDS into registers
         const int64_t posb = pos + stride;
         const bool has_b = posb < end;                   // (workgroup uniform)

@@ -178,3 +178,30 @@ def test_automatic_column_blocks_for_long_rows_over_a_long_x():
     assert nb.value == 0
     opb.free()
     op.free()
+
+
+@pytest.mark.parametrize("solver", ["bicgstab", "tfqmr"])
+def test_stepped_product_n2300000_bit_exact(solver):
+    """8 985 tiles = 2.2 pair steps per workgroup, tile order 0: the product runs as ONE LAUNCH PER STEP (the workgroups are
+    re-aligned by the kernel boundary, the per-lane accumulators of the fused dots travel through a carry buffer).  Same
+    additions in the same order: counts, residual norms and the iterate bit for bit against the oracle run in the device's
+    summation order -- the statement of tests/test_gpu_bitexact_full.py for a matrix large enough to be stepped."""
+    from pykrylov_amd import BiCGSTAB, TFQMR, CsrOperator, gallery
+    from oracle import gpu_order
+    indptr, indices, data, shape = gallery.random_diagdom_csr(2300000, seed=3)
+    n = shape[0]
+    op = CsrOperator(indptr, indices, data, shape)
+    A = csr_ref.RefCsr(indptr, indices, data, shape)
+    x = np.random.default_rng(2).standard_normal(n)
+    assert np.array_equal(op * x, A.matvec(x))
+    rhs = op * np.ones(n)
+    geo = gpu_order.launch_geometry(op)
+    assert fmt_of(op)[0] == 3 and geo == (2048, 0) and (n + 255) // 256 > 2 * 2048 * 2
+    cls, fn = (BiCGSTAB, kr.bicgstab) if solver == "bicgstab" else (TFQMR, kr.tfqmr)
+    s = cls(op, reltol=1e-10)
+    s.solve(rhs)
+    ref = fn(A, rhs, reltol=1e-10, red=kr.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES[solver], geo)))
+    assert s.nMatvec == ref["nMatvec"] and s.converged == ref["converged"]
+    assert s.residNorm0 == ref["residNorm0"] and s.residNorm == ref["residNorm"]
+    assert np.array_equal(s.x, ref["x"])
+    op.free()

@@ -54,6 +54,18 @@ __global__ __launch_bounds__(256) void xp_prod(OpXP op, long n, const int* flag)
     for (long q = g + S; q < npair; q += S) { OpXP::Regs r; op.load2(2 * q, r); op.apply2(r); op.store2(2 * q, r); }
 }
 
+// phased (round 4): never two write streams at once.  The vectors are cut into regions of `rv` 16-byte elements; all workgroups
+// sweep a region twice -- first x += a p (reads p, x; writes x), then p = b p - r (reads r, p again: from the caches; writes p) --
+// so at any time the chip writes ONE array.  No barrier between the sweeps (approximate, like the column phases of format 3).
+__global__ __launch_bounds__(256) void xp_phased(const d2v* __restrict__ r, d2v* __restrict__ x, d2v* __restrict__ p, double a, double b, long nv, long rv) {
+    const long S = (long)gridDim.x * 256, g = (long)blockIdx.x * 256 + threadIdx.x;
+    for (long r0 = 0; r0 < nv; r0 += rv) {
+        const long r1 = min(nv, r0 + rv);
+        for (long i = r0 + g; i < r1; i += S) { const d2v pv = p[i], xv = x[i]; d2v nx; nx.x = xv.x + a * pv.x; nx.y = xv.y + a * pv.y; x[i] = nx; }
+        for (long i = r0 + g; i < r1; i += S) { const d2v pv = p[i], rr = r[i]; d2v np; np.x = b * pv.x - rr.x; np.y = b * pv.y - rr.y; p[i] = np; }
+    }
+}
+
 template <class F> float timeit(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -77,6 +89,11 @@ int main(int argc, char** argv) {
         float ms = timeit([&] { hipLaunchKernelGGL(xp_prod, dim3(g), dim3(256), 0, 0, OpXP{r, p, x, 1e-9, 0.5}, n, flag); }, reps);
         printf("production structure grid=%4d : %7.1f us  %.2f TB/s\n", g, ms * 1e3, 40.0 * n / ms / 1e9);
     }
+    for (long mb : {4L, 16L, 64L, 256L, 1024L}) for (int g : {512, 1024, 2048}) {
+        float ms = timeit([&] { hipLaunchKernelGGL(xp_phased, dim3(g), dim3(256), 0, 0, (const d2v*)r, (d2v*)x, (d2v*)p, 1e-9, 0.5, nv, (mb << 20) / 16); }, reps);
+        printf("phased, regions of %4ld MB per vector, grid=%4d : %7.1f us  %.2f TB/s (of the 40 n bytes)\n", mb, g, ms * 1e3, 40.0 * n / ms / 1e9);
+    }
+    if (getenv("PHASED_ONLY")) return 0;
     RUN(1, 0, 0, 0) RUN(2, 0, 0, 0) RUN(4, 0, 0, 0)
     RUN(1, 0, 1, 0) RUN(1, 1, 1, 0) RUN(2, 1, 1, 0) RUN(1, 1, 0, 0)
     RUN(1, 0, 0, 1) RUN(2, 0, 0, 1) RUN(2, 1, 1, 1)
