@@ -856,6 +856,9 @@ class _BlockCsrOperator(CsrOperator):
             self._owner._nMatvec += delta
             for b in self.__dict__.get('_parts', ()):
                 b._nMatvec += delta
+                orig = b.__dict__.get('_count_owner')         # a Diagonal / Identity block seen through its device form
+                if orig is not None:
+                    orig._nMatvec += delta
 
     _nMatvec = property(_get_count, _set_count)
 
@@ -887,6 +890,7 @@ def device_block(blk):
         if _is_complex(np.asarray(diag).dtype):
             return None
         cached = CsrOperator(np.arange(n + 1), np.arange(n), diag, (n, n), symmetric=True)
+        cached._count_owner = blk                             # (products are counted on the block the caller made)
         blk.__dict__['_device_diag_csr'] = cached
     return cached
 

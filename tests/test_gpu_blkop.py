@@ -76,6 +76,7 @@ def test_saddle_point_minres_runs_without_host_callbacks(monkeypatch):
     # products are counted on the block operator and on every block, once per product of the solve
     k = s.nMatvec
     assert K.nMatvec - counts0[0] >= k and A.nMatvec - counts0[1] >= k and B.nMatvec - counts0[2] >= k
+    assert D.nMatvec - counts0[4] >= k                       # ... on the DiagonalOperator block too, not on its device form
     # destroying a block while the composite is alive is deferred: the composite keeps working
     A.free()
     assert np.array_equal(dev * x, want)
