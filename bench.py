@@ -548,6 +548,7 @@ def main():
     ap.add_argument("--one-device", action="store_true",
                     help="test aid: every rank on GPU 0 (RCCL refuses that, which exercises the host-staged fallback)")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the 60-pass parity segment of the 512^3 workloads")
     ap.add_argument("--parity", action="store_true",
                     help="N = 1: also run the 60-pass parity segment against tests/golden/dev_hist_512.npz (always on for N > 1)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
@@ -804,7 +805,7 @@ def main():
     multi = world_size > 1
     first_mode = "halo" if (not multi or args.exchange in ("both", "halo")) else "allgather"
     info = run_cg(name, args.steps, args.warmup, args.event_stride, exchange=first_mode, comm_probe=multi,
-                  parity=(multi or args.parity))
+                  parity=(multi or args.parity or (name in ("poisson3d-512-varcoef", "poisson3d-512") and not args.no_parity)))
     elapsed = info["elapsed"]
     tm = info["timing"]
     n_g = info["n_global"]

@@ -3,7 +3,7 @@
 O=gpurun_out/r4e; mkdir -p $O
 run() { # name, env...
   name=$1; shift
-  env "$@" python bench.py --no-cpu --no-extra --steps 300 --warmup 30 > $O/$name.json 2> $O/$name.err
+  env "$@" python bench.py --no-cpu --no-extra --no-parity --steps 300 --warmup 30 > $O/$name.json 2> $O/$name.err
   python - <<PY
 import json
 try:

@@ -1,7 +1,7 @@
 #!/bin/bash
 O=gpurun_out/r4l; mkdir -p $O
 run() { name=$1; shift
-  env "$@" python bench.py --no-cpu --no-extra --steps 200 --warmup 20 > $O/$name.json 2> $O/$name.err
+  env "$@" python bench.py --no-cpu --no-extra --no-parity --steps 200 --warmup 20 > $O/$name.json 2> $O/$name.err
   python - <<PY
 import json
 try:
