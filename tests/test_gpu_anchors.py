@@ -124,3 +124,24 @@ def test_least_squares_against_exact_dots(golden, solver):
     print("%s 2000 x 1500, etol = 0, %d passes: x device vs anchor %.2e, np.dot vs anchor %.2e" % (solver, passes, xdev, xref))
     assert xdev <= 1e-12, xdev
     op.free()
+
+
+def test_symmlq_full_run_against_exact_dots():
+    """SYMMLQ (the other Lanczos loop) on the 2-D Poisson matrix m = 300, the whole run: iterate, residual norm, product count."""
+    from pykrylov_amd import Symmlq, gallery
+    m = 300
+    A = csr_ref.poisson2d(m)
+    n = m * m
+    rhs = A.matvec(np.ones(n))
+    anchor = kr.symmlq(A, rhs, rtol=1e-10, red=exact())
+    blas = kr.symmlq(A, rhs, rtol=1e-10)
+    op = gallery.poisson2d(m)
+    s = Symmlq(op)
+    s.solve(rhs, rtol=1e-10)
+    assert s.nMatvec == anchor["nMatvec"] == blas["nMatvec"] and s.istop == anchor["istop"]
+    xdev, xref = relerr(s.x, anchor["x"]), relerr(blas["x"], anchor["x"])
+    rdev = abs(float(s.residNorm) - anchor["residNorm"]) / np.linalg.norm(rhs)
+    print("SYMMLQ 2-D Poisson m = 300, all %d products: x device vs anchor %.2e, np.dot vs anchor %.2e; residual norm / |b|: "
+          "device %.2e" % (s.nMatvec, xdev, xref, rdev))
+    assert xdev <= 1e-12 and rdev <= 1e-12, (xdev, rdev)
+    op.free()

@@ -344,3 +344,16 @@ def test_device_history_fixture_for_the_multi_gpu_line():
         assert bench.n1_history("poisson3d-%d" % m)[0] == np.sqrt(6.0 * (m - 2) ** 2 + 48.0 * (m - 2) + 72.0)
     assert bench.n1_history("poisson2d-1000") is None
     assert abs(bench.rel_hist_err([4.0, 2.0], [4.0, 2.0 + 2e-12]) - 1e-12) < 1e-15
+
+
+def test_bench_least_squares_matrix_is_canonical_csr():
+    """bench.random_tall_csr (the 4e6 x 1e6 matrix of the least-squares loops, here small): sorted, distinct columns in range, k
+    entries per row, reproducible from the seed -- what CsrOperator requires of caller arrays."""
+    import bench
+    indptr, indices, data = bench.random_tall_csr(4000, 1000, k=5, seed=11)
+    assert np.array_equal(indptr, np.arange(4001) * 5) and indices.shape == data.shape == (20000,)
+    cols = indices.reshape(4000, 5)
+    assert (np.diff(cols, axis=1) > 0).all() and cols.min() >= 0 and cols.max() < 1000
+    again = bench.random_tall_csr(4000, 1000, k=5, seed=11)
+    assert all(np.array_equal(a, b) for a, b in zip((indptr, indices, data), again))
+    assert set(bench.LOOP_BYTES) == {"bicgstab", "cgs", "tfqmr", "minres", "symmlq", "lsqr", "lsmr", "craig", "craigmr"}
