@@ -309,7 +309,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void cb_reg(int T, int K, int n, int W,
 // pair : the library's round-4 kernel (mk_spmv_fmt3r.h): tile A in LDS walked with a cursor, tile B (the workgroup's next
 //        tile) in registers with static exec-masked gathers issued before A's walk.  PAIR = 0: tile A only (= the library's
 //        format-3 kernel, one tile per step).  Stamps: 0 start, 1 after B's ingest, 2 after A's ingest, 3 .. K + 2 phase ends.
-template <int PAIR>
+template <int PAIR, int AUX = 0>
 __global__ __launch_bounds__(BLOCK, 8) void cb_pair(int T, int K, int n, int W, const int* __restrict__ ip,
                                                     const int* __restrict__ cols, const double* __restrict__ vals,
                                                     const double* __restrict__ x, double* __restrict__ y, long long* __restrict__ ts) {
@@ -366,12 +366,12 @@ __global__ __launch_bounds__(BLOCK, 8) void cb_pair(int T, int K, int n, int W, 
             const unsigned o_lo = (unsigned)(k * W) << 3, o_hi = (k + 1 < K) ? (unsigned)c1 << 3 : 0xffffffffu;
             double xb[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) { xb[j] = 0.0; if (PAIR && ob[j] >= o_lo && ob[j] < o_hi) { const u2 w = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(xres, (int)ob[j], 0, 0)); xb[j] = __builtin_bit_cast(double, w); } }
+            for (int j = 0; j < 5; ++j) { xb[j] = 0.0; if (PAIR && ob[j] >= o_lo && ob[j] < o_hi) { const u2 w = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(xres, (int)ob[j], 0, AUX)); xb[j] = __builtin_bit_cast(double, w); } }
             for (;;) {
                 int ca = 0x7fffffff;
                 if (cur < fin) ca = lc[cur];
                 const bool oa = ca < c1;
-                if (oa) { sum += lv[cur] * x[ca]; cur += 1; }
+                if (oa) { const u2 w = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(xres, ca << 3, 0, AUX)); sum += lv[cur] * __builtin_bit_cast(double, w); cur += 1; }
                 if (!__any(oa)) break;
             }
 #pragma unroll
@@ -535,6 +535,13 @@ int main(int argc, char** argv) {
             unsigned* dsb; CK(hipMalloc(&dsb, 4 * 32 * 8 * 64)); CK(hipMemset(dsb, 0, 4 * 32 * 8 * 64)); unsigned ep = 0; \
             float ms = timeit([&] { ++ep; hipLaunchKernelGGL((cb_reg<RT, 5, OCC, 1>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, (long long*)nullptr, dsb, ep, MODE); }, reps); \
             CK(hipGetLastError()); check("regS"); printf("K=%2d regS%d grid=%4d tiles/wg=%d occ=%d : %7.1f us  %5.2f TB/s (frac %.3f)\n", K, MODE, G, RT, OCC, ms * 1e3, alg / ms / 1e9, alg / ms / 1e9 / 8.0); CK(hipFree(dsb)); }
+        if (getenv("PAIR_AUX")) {   // cache policy of the gathers: aux bits of the buffer load (1 sc0, 2 nt, 16 sc1)
+            const int G = 2048; const size_t lds = (size_t)RCAP * 12;
+#define RUNAUX(P, AX) { CK(hipMemset(dy, 0, 8L * n)); float ms = timeit([&] { hipLaunchKernelGGL((cb_pair<P, AX>), dim3(G), dim3(BLOCK), lds, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy, (long long*)nullptr); }, reps); \
+                check("aux"); printf("K=%2d pair=%d aux=%2d : %7.1f us\n", K, P, AX, ms * 1e3); }
+            RUNAUX(0, 0) RUNAUX(0, 1) RUNAUX(0, 2) RUNAUX(0, 3) RUNAUX(0, 16) RUNAUX(0, 17) RUNAUX(0, 18)
+            RUNAUX(1, 0) RUNAUX(1, 1) RUNAUX(1, 2) RUNAUX(1, 3) RUNAUX(1, 16) RUNAUX(1, 17) RUNAUX(1, 18)
+        }
         if (getenv("PAIR")) for (int pair = 0; pair <= 1; ++pair) {
             const int G = 2048; const size_t lds = (size_t)RCAP * 12; const int NS = K + 3;
             std::vector<long long> h((size_t)16 * G); long long* dts; CK(hipMalloc(&dts, 8 * h.size())); CK(hipMemset(dts, 0, 8 * h.size()));
