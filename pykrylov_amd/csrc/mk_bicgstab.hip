@@ -22,10 +22,11 @@ struct BEpi {    // v = A p, fused <r0, v>
     static constexpr int NACC = 1, SLOT0 = SLOT_R0V;
     const double *r0;
     double *v;
+    int nt;            // the product vector goes past the caches (mk_store_stream, mk_solver.h)
     __device__ void prologue(double *) {}
     __device__ double xin(double x) const { return x; }
     __device__ void row(int64_t r, double s, double *acc) {
-        v[r] = s;
+        mk_store_stream(v + r, s, nt);
         acc[0] += r0[r] * s;
     }
 };
@@ -100,10 +101,11 @@ struct DEpi {    // t = A s, fused <t,s>, <t,t>, <r0,t>
     static constexpr int NACC = 3, SLOT0 = SLOT_TS;
     const double *s, *r0;
     double *t;
+    int nt;
     __device__ void prologue(double *) {}
     __device__ double xin(double x) const { return x; }
     __device__ void row(int64_t r, double sum, double *acc) {
-        t[r] = sum;
+        mk_store_stream(t + r, sum, nt);
         acc[0] += sum * s[r];
         acc[1] += sum * sum;
         acc[2] += r0[r] * sum;
@@ -299,8 +301,8 @@ struct BicgstabSolver : mk_solver {
     }
 
     int enqueue_spmv_only(int which) override {            // (timing aid: a product's kernel without its gate)
-        if (which == 0) mk_launch_spmv(this, d_prec ? d_q : d_p, BEpi{d_r0, d_v}, false);
-        else if (which == 1) mk_launch_spmv(this, d_prec ? d_z : d_s, DEpi{d_s, d_r0, d_t}, false);
+        if (which == 0) mk_launch_spmv(this, d_prec ? d_q : d_p, BEpi{d_r0, d_v, mk_store_nt(A)}, false);
+        else if (which == 1) mk_launch_spmv(this, d_prec ? d_z : d_s, DEpi{d_s, d_r0, d_t, mk_store_nt(A)}, false);
         else return mk_fail(MK_ERR_ARG, "BiCGSTAB has two products per pass");
         return MK_OK;
     }
@@ -311,14 +313,14 @@ struct BicgstabSolver : mk_solver {
         int rc;
         if (precon_fn && it > 0 && (rc = host_precon(d_p, d_q)) != MK_OK) return rc;   // q = precon * p  bicgstab.py:96-97
         if ((rc = exchange(qin)) != MK_OK) return rc;
-        mk_launch_spmv(this, qin, BEpi{d_r0, d_v}, true,
+        mk_launch_spmv(this, qin, BEpi{d_r0, d_v, mk_store_nt(A)}, true,
                        GateB{d_part, np_stream, d_scal, d_status, it == 0 ? 1 : 0, prm.matvec_max, nmv0 + 2 * it});
         if ((rc = allreduce(SLOT_R0V, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_r, d_v, d_s, d_prec, d_z, 0.0}, n);
         if ((rc = allreduce(SLOT_SS, 1)) != MK_OK) return rc;
         if (precon_fn && (rc = host_precon(d_s, d_z)) != MK_OK) return rc;     // z = precon * s       bicgstab.py:120-121
         if ((rc = exchange(zin)) != MK_OK) return rc;
-        mk_launch_spmv(this, zin, DEpi{d_s, d_r0, d_t}, true,
+        mk_launch_spmv(this, zin, DEpi{d_s, d_r0, d_t, mk_store_nt(A)}, true,
                        GateD{d_part, np_stream, d_scal, d_status, prm.matvec_max, nmv0 + 2 * it + 1});
         if ((rc = allreduce(SLOT_TS, 3)) != MK_OK) return rc;
         mk_launch_stream(this, OpF{d_part, np_spmv, d_scal, d_status, par, d_t, d_v, d_s, d_r, d_x, d_p, d_prec, d_q,

@@ -19,10 +19,11 @@ struct BEpi {    // v = A p, fused <r0, v>; the product is counted by its gate
     static constexpr int NACC = 1, SLOT0 = SLOT_SIGMA;
     const double *r0;
     double *v;
+    int nt;            // the product vector goes past the caches (mk_store_stream, mk_solver.h)
     __device__ void prologue(double *) {}
     __device__ double xin(double x) const { return x; }
     __device__ void row(int64_t r, double s, double *acc) {
-        v[r] = s;
+        mk_store_stream(v + r, s, nt);
         acc[0] += r0[r] * s;
     }
 };
@@ -233,7 +234,7 @@ struct CgsSolver : mk_solver {
     }
 
     int enqueue_spmv_only(int which) override {            // (timing aid: a product's kernel without its gate)
-        if (which == 0) mk_launch_spmv(this, d_prec ? d_y : d_p, BEpi{d_r0, d_v}, false);
+        if (which == 0) mk_launch_spmv(this, d_prec ? d_y : d_p, BEpi{d_r0, d_v, mk_store_nt(A)}, false);
         else if (which == 1) mk_launch_spmv(this, d_z, DEpi{d_scal, d_r0, d_r, 0.0}, false);
         else return mk_fail(MK_ERR_ARG, "CGS has two products per pass");
         return MK_OK;
@@ -245,7 +246,7 @@ struct CgsSolver : mk_solver {
         int rc;
         if (precon_fn && it > 0 && (rc = host_precon(d_p, d_y)) != MK_OK) return rc;   // y = precon * p   cgs.py:79-80
         if ((rc = exchange(yin)) != MK_OK) return rc;
-        mk_launch_spmv(this, yin, BEpi{d_r0, d_v}, true, CountGate{d_status, 2 * it});
+        mk_launch_spmv(this, yin, BEpi{d_r0, d_v, mk_store_nt(A)}, true, CountGate{d_status, 2 * it});
         if ((rc = allreduce(SLOT_SIGMA, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpC{d_part, np_spmv, d_scal, par, d_u, d_v, d_q, d_z, d_x, d_prec, 0.0, precon_fn ? 1 : 0}, n);
         if (precon_fn) {                                    // z = precon * (u + q) ; x += alpha z     cgs.py:88-94

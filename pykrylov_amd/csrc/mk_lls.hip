@@ -64,18 +64,19 @@ struct EpiU {        // Mu <- A v - alpha Mu ; u = M(Mu) ; <u, Mu>
     const double *dm;
     double *Mu;
     double alpha;
+    int nt;              // u (and Mu) go past the caches (vectors beyond the Infinity Cache; mk_store_stream, mk_solver.h)
     __device__ void prologue(double *) { alpha = blk[B_ALPHA]; }
     __device__ double xin(double x) const { return x; }
     __device__ void row(int64_t i, double sum, double *acc) {
         if (dm) {
             const double t = sum - alpha * Mu[i];                 // lsqr.py:252
-            Mu[i] = t;
+            mk_store_stream(Mu + i, t, nt);
             const double uu = dm[i] * t;                          // lsqr.py:254
-            u[i] = uu;
+            mk_store_stream(u + i, uu, nt);
             acc[0] += uu * t;                                     // lsqr.py:257
         } else {
             const double t = sum - alpha * u[i];                  // lsqr.py:252
-            u[i] = t;
+            mk_store_stream(u + i, t, nt);
             acc[0] += t * t;                                      // lsqr.py:257
         }
     }
@@ -1186,7 +1187,7 @@ struct LlsSolver : mk_solver {
     int enqueue_spmv_only(int which) override {            // (timing aid: a product's kernel without its gate; one GPU)
         if (dist) return mk_fail(MK_ERR_UNSUPPORTED, "product timing of the least-squares solvers is single-GPU");
         const double *blk = d_scal + S_BLK + (int)(it & 1) * BLK;
-        if (which == 0) mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0});
+        if (which == 0) mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0, mk_store_nt(A)});
         else if (which == 1) mk_launch_spmv_on(this, At, d_u, EpiV{d_scal, d_v, d_dn, d_Nv, 0.0});
         else return mk_fail(MK_ERR_ARG, "the least-squares solvers have two products per pass (A v, A' u)");
         return MK_OK;
@@ -1199,14 +1200,14 @@ struct LlsSolver : mk_solver {
         const int64_t itn = it + 1;
         // G1: u <- A v - alpha u, gated by what is left of the previous pass
         if (kind == MK_LSQR)
-            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0},
+            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0, mk_store_nt(A)},
                               lsqr::Gate{d_part, np_n, d_scal, d_status, it, itnlim, prm.atol});
         else if (kind == MK_LSMR)
-            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0},
+            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0, mk_store_nt(A)},
                               lsmr::Gate{d_part, np_n, d_scal, d_status, it, itnlim, prm.atol, prm.btol,
                                          prm.conlim > 0 ? 1.0 / prm.conlim : 0.0});
         else
-            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0}, craig::CountGate{d_status, it, itnlim});
+            mk_launch_spmv_on(this, A, d_v, EpiU{blk, d_u, d_dm, d_Mu, 0.0, mk_store_nt(A)}, craig::CountGate{d_status, it, itnlim});
         int rc = apply_M(false);
         if (rc != MK_OK) return rc;
         if ((rc = sum_uu()) != MK_OK) return rc;

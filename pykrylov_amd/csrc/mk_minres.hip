@@ -49,6 +49,7 @@ struct EpiK1 {
     double shift;
     int first;                // itn == 1: no r1 term (minres.py:242)
     double s, c;
+    int nt;                   // v and t go past the caches (vectors beyond the Infinity Cache; mk_store_stream)
     __device__ void prologue(double *) {
         s = 1.0 / blk[B_BETA];                                                // minres.py:236
         c = first ? 0.0 : blk[B_BETA] / blk[B_OLDB];                          // minres.py:243
@@ -56,19 +57,19 @@ struct EpiK1 {
     __device__ double xin(double yj) const { return s * yj; }                 // minres.py:237 on the fly
     __device__ void row(int64_t i, double sum, double *acc) {
         const double vv = s * r2[i];                                          // minres.py:237
-        v[i] = vv;
+        mk_store_stream(v + i, vv, nt);
         double tv = sum - shift * vv;                                         // minres.py:239-240
         if (!first) tv = tv - c * r1[i];                                      // minres.py:243
-        t[i] = tv;
+        mk_store_stream(t + i, tv, nt);
         acc[0] += vv * tv;                                                    // minres.py:245
     }
     // r2 IS the product's input vector: where the kernel holds xin(r2[i]) = s * r2[i] already (pattern format: the
     // diagonal entry's LDS slot) it passes it, and r2 is not streamed a second time
     __device__ void row_x(int64_t i, double sum, double vv, double *acc) {
-        v[i] = vv;
+        mk_store_stream(v + i, vv, nt);
         double tv = sum - shift * vv;                                         // minres.py:239-240
         if (!first) tv = tv - c * r1[i];                                      // minres.py:243
-        t[i] = tv;
+        mk_store_stream(t + i, tv, nt);
         acc[0] += vv * tv;                                                    // minres.py:245
     }
 };
@@ -352,7 +353,7 @@ struct MinresSolver : mk_solver {
         const int par = (int)(it & 1);                     //  writes v and t of the current pass, which the next pass
         const double *blk = d_scal + S_BLK + par * BLK;    //  overwrites anyway)
         double *r1 = d_r[it & 1], *r2 = d_r[(it + 1) & 1];
-        mk_launch_spmv(this, d_prec ? d_y : r2, EpiK1{blk, d_prec ? d_y : r2, r1, d_v, d_t, prm.shift, 0, 0.0, 0.0}, false);
+        mk_launch_spmv(this, d_prec ? d_y : r2, EpiK1{blk, d_prec ? d_y : r2, r1, d_v, d_t, prm.shift, 0, 0.0, 0.0, mk_store_nt(A)}, false);
         return MK_OK;
     }
 
@@ -367,7 +368,7 @@ struct MinresSolver : mk_solver {
         double *y = d_prec ? d_y : r2;                                         // minres.py:249
         int rc = exchange(y);
         if (rc != MK_OK) return rc;
-        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, it == 0 ? 1 : 0, 0.0, 0.0}, true,
+        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, it == 0 ? 1 : 0, 0.0, 0.0, mk_store_nt(A)}, true,
                        GateK1{d_status, it, prm.itnlim});
         if ((rc = allreduce(SLOT_ALFA, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpK2{d_part, np_spmv, d_scal, blk, r2, d_t, r1, d_prec, d_y, 0.0}, n);

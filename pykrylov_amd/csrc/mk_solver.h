@@ -202,6 +202,16 @@ struct MkOpDot {
     __device__ void one(int64_t i, double *acc) { acc[0] += a[i] * b[i]; }
 };
 
+// Product vectors of problems beyond the Infinity Cache are written once and read by the NEXT kernel from HBM: storing them
+// non-temporally keeps them from pushing the x windows out of the L2 (mk_store_nt, mk_device.h: -5 ... -7 % on the CG product
+// at 512^3).  CG carries the choice as a template parameter; the other loops' epilogues take it at run time through this
+// helper -- an inline-asm store in the `nt` branch, because the compiler merges `if (nt) nontemporal_store else store` into
+// ONE plain store (round 3's finding) -- so that no kernel is instantiated twice for it.  `nt` is launch uniform.
+__device__ __forceinline__ void mk_store_stream(double *p, double v, int nt) {
+    if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+
 struct MkPlainEpi {             // y = A x, nothing fused
     static constexpr int NACC = 0, SLOT0 = 0;
     double *y;

@@ -276,6 +276,7 @@ struct EpiK1 {
     double shift;
     int has_shift;
     double s, c;
+    int nt;                   // v and t go past the caches (mk_store_stream, mk_solver.h)
     __device__ void prologue(double *) {
         s = 1 / blk[B_BETA];                                                  // symmlq.py:300
         c = blk[B_BETA] / blk[B_OLDB];                                        // symmlq.py:304
@@ -283,11 +284,11 @@ struct EpiK1 {
     __device__ double xin(double yj) const { return s * yj; }
     __device__ void row(int64_t i, double sum, double *acc) {
         const double vv = s * r2[i];                                          // symmlq.py:301
-        v[i] = vv;
+        mk_store_stream(v + i, vv, nt);
         double tv = sum;
         if (has_shift) tv = tv - shift * vv;                                  // symmlq.py:303
         tv = tv - c * r1[i];                                                  // symmlq.py:304
-        t[i] = tv;
+        mk_store_stream(t + i, tv, nt);
         acc[0] += vv * tv;                                                    // symmlq.py:305
     }
 };
@@ -566,7 +567,7 @@ struct SymmlqSolver : mk_solver {
         const double *blk = d_scal + S_BLK + (int)(it & 1) * BLK;
         double *r1 = d_r[it & 1], *r2 = d_r[(it + 1) & 1];
         double *y = d_prec ? d_y : r2;
-        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, prm.has_shift, 0.0, 0.0}, false);
+        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, prm.has_shift, 0.0, 0.0, mk_store_nt(A)}, false);
         return MK_OK;
     }
 
@@ -577,7 +578,7 @@ struct SymmlqSolver : mk_solver {
         double *y = d_prec ? d_y : r2;                                         // symmlq.py:308-309
         int rc = exchange(y);
         if (rc != MK_OK) return rc;
-        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, prm.has_shift, 0.0, 0.0}, true,
+        mk_launch_spmv(this, y, EpiK1{blk, y, r1, d_v, d_t, prm.shift, prm.has_shift, 0.0, 0.0, mk_store_nt(A)}, true,
                        CountGate{d_status, 1 + it});
         if ((rc = allreduce(SLOT_A, 1)) != MK_OK) return rc;
         mk_launch_stream(this, OpK2{d_part, np_spmv, d_scal, blk, r2, d_t, r1, d_prec, d_y, 0.0}, n);
