@@ -778,7 +778,8 @@ def main():
                 tnote = "profiles/spmv_traffic.json was measured at another kernel build or format: not quoted"
         roof = {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpi> (SpMV + fused <p,Ap>), " + fmt["format_name"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_note": tnote,
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "traffic_bytes": (traffic or {}).get("bytes"), "traffic_note": tnote,
                 "bytes_per_launch": b_fmt, "avg_launch_us": spmv_us, "launches_timed": info["launches"],
                 "method": "one hipEvent pair around back-to-back launches on the solver stream",
                 "inloop_event_pair_us": inloop_us,
