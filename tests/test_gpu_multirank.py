@@ -56,7 +56,7 @@ def test_partitioned_solvers_on_one_gpu(nranks):
     assert out["cg27/halo"]["fmt"] >= 6 and out["cg27/allgather"]["fmt"] >= 6       # the slabs keep a wide format
 
 
-@pytest.mark.parametrize("launcher", ["self", "torchrun", "rccl-fallback", "self-varcoef"])
+@pytest.mark.parametrize("launcher", ["self", "torchrun", "rccl-fallback", "self-varcoef", "self-varcoef-8"])
 def test_bench_two_rank_path_smoke(launcher):
     """bench.py's N > 1 branch (per-rank matrix generation, gloo bootstrap, barrier / max-over-ranks timing, both
     exchange modes, comm timings, JSON line) with two ranks on GPU 0 over the host-staged transport: a smoke test of
@@ -67,8 +67,12 @@ def test_bench_two_rank_path_smoke(launcher):
         env.pop(k, None)
     args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--transport", "host",
             "--workload", "poisson3d-64", "--spmv-launches", "3"]
-    if launcher == "self-varcoef":                          # the default line's operator family, partitioned
+    nranks = 2
+    if launcher.startswith("self-varcoef"):                 # the default line's operator family, partitioned
         args[args.index("poisson3d-64")] = "poisson3d-64-varcoef"
+        if launcher.endswith("-8"):                         # ... over EIGHT ranks, the split the driver's scaling run ends on
+            nranks = 8
+            args[args.index("--gpus") + 1] = "8"
         launcher = "self"
     if launcher == "rccl-fallback":
         # RCCL requested with both ranks on GPU 0: ncclCommInitRank refuses, every rank falls back to the host-staged
@@ -82,7 +86,7 @@ def test_bench_two_rank_path_smoke(launcher):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 12 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["n_gpus"] == nranks and line["steps"] == 12 and line["value"] > 0 and line["scaling"] == "strong"
     assert line["config"]["rows"] == 64 ** 3 and line["residual"]["last"] < line["residual"]["first"]
     assert line["roofline"]["bound"] == "hbm"
     # the N > 1 line validates itself: the first 60 passes against the committed single-GPU device history (1e-12), and
@@ -93,7 +97,7 @@ def test_bench_two_rank_path_smoke(launcher):
     ex = line["exchange"]
     assert ex["halo"]["comm"]["per_rank"][0]["product_alone_us"] > 0
     assert set(ex) == {"halo", "allgather"} and ex["allgather"]["value"] > 0
-    assert len(ex["halo"]["comm"]["per_rank"]) == 2 and ex["halo"]["comm"]["per_rank"][1]["exchange_alone_us"] > 0
+    assert len(ex["halo"]["comm"]["per_rank"]) == nranks and ex["halo"]["comm"]["per_rank"][1]["exchange_alone_us"] > 0
     assert "host-staged gloo" in line["config"]["parallelism"]
     # the line says what carried the collectives: a host-staged fallback can never pass for an RCCL measurement
     assert line["transport"] == {"kind": "host-staged", "rccl_ranks_seen": 0, "halo_communicator_split": False}
