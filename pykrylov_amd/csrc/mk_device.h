@@ -77,6 +77,7 @@ struct MkCsrView {
     int allwin;              // every tile of the matrix has windows (no tile ever takes the gather path)
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
+    int rt_c0;               // first column of the phases (0; a column block's first column: its phases cover ITS slice of x)
     int rt_reg;              // fmt 3: rows of <= 5 entries -- a second tile per workgroup rides in registers (mk_spmv_fmt3r.h)
     // ... and a product of MANY pair steps per workgroup runs as one launch per step (mk_spmv_launch_blocks): step0 / nsteps
     // select the steps of this launch (nsteps 0: all), the per-lane accumulators of the fused dots travel through `carry`
@@ -901,6 +902,7 @@ static inline void mk_spmv_launch_blocks(const mk_csr *A, int grid, hipStream_t 
             v.rt_cap = B->plan.rt_cap;
             v.rt_k = B->plan.rt_k;
             v.rt_w = B->plan.rt_w;
+            v.rt_c0 = B->plan.rt_c0;
             v.rt_reg = 0;
         }
         v.sum_in = k ? P->d_cbsum : nullptr;

@@ -539,14 +539,21 @@ int64_t colblock_bytes(const mk_csr *A) {
         // block of carried sums are small beside the sectors saved.  (5 entries per row: slower, see cblocks_build.)
         const int64_t xbytes = 8 * A->x_len();
         const bool long_rows = A->nrows > 0 && A->nnz >= 12 * A->nrows;
-        if (long_rows && xbytes >= ((int64_t)16 << 20) && A->ex.mode < 0) return (int64_t)4 << 20;
+        if (long_rows && xbytes >= ((int64_t)16 << 20) && A->ex.mode < 0) return -((int64_t)8 << 20);   // (negative: automatic)
         return 0;
     }
     const int64_t b = A->want_cb_kb >= 0 ? (int64_t)A->want_cb_kb * 1024 : env;
     return b < 0 ? 0 : b;
 }
+static void cblocks_drop(MkPlan &P) {
+    for (mk_csr *B : P.cblocks) mk_csr_destroy(B);
+    P.cblocks.clear();
+    hipFree(P.d_cbsum);
+    P.d_cbsum = nullptr;
+}
 
 int resident_plan(const mk_csr *A, MkPlan &P, bool forced);
+constexpr int64_t RT_SLICE_BYTES = 3 << 19;              // a column phase of format 3: 1.5 MiB of x
 
 // Column blocks for a plain-CSR matrix (scattered columns) whose x is more than two blocks long.  OFF by default:
 // measured on BASELINE configs[2] (random n = 1e6, 5 nnz/row; x = 8 MB against 4 MiB of L2 per XCD) a product costs
@@ -555,9 +562,14 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced);
 // more than the 128-byte lines the blocked gathers no longer pull through the fabric.  Kept (mk_csr_set_colblocks,
 // MK_COLBLOCK_KB) because the mechanism -- carried row sums, gate / epilogue split over launches -- is exact and
 // the trade-off is different for wider rows.
-int cblocks_build(const mk_csr *A) {
+int cblocks_build(const mk_csr *A, int64_t blk_override = 0) {
     MkPlan &P = A->plan;
-    const int64_t blk = colblock_bytes(A);
+    // automatic blocks (colblock_bytes < 0): 8 MiB of x each -- the fewest blocks whose tiles still fit the resident-tile kernel
+    // on the transposed least-squares operator (4 blocks of ~5 entries per row: 176 us per product; 6 MiB 191, 4 MiB 208 us) --
+    // and 4 MiB if a tile of an 8 MiB block outgrows the LDS budget
+    int64_t blk = blk_override ? blk_override : colblock_bytes(A);
+    const bool automatic = blk < 0;
+    if (automatic) blk = -blk;
     if (blk <= 0 || A->ex.mode >= 0 || A->nnz == 0) return MK_OK;
     const int64_t xbytes = 8 * A->x_len();
     if (xbytes <= 2 * blk) return MK_OK;
@@ -605,13 +617,26 @@ int cblocks_build(const mk_csr *A) {
     static const char *ecb = getenv("MK_CB_RESIDENT");
     if (!ecb || atoi(ecb) > 0) {
         bool all = true;
-        for (mk_csr *B : P.cblocks) {
+        for (size_t bi = 0; bi < P.cblocks.size(); ++bi) {
+            mk_csr *B = P.cblocks[bi];
             B->plan = MkPlan();
             B->plan.built = true;
             if (resident_plan(B, B->plan, true) != MK_OK || B->plan.fmt != 3) all = false;
-            B->plan.rt_k = 1;                                // (the block's columns ARE one slice)
-            B->plan.rt_w = (int)(B->x_len() > 0x7fffffff ? 0x7fffffff : B->x_len());
+            // phases over the block's OWN slice of x (bw columns from b * bw), 1.5 MiB each: a slice larger than an L2's share
+            // is walked in lockstep like a whole format-3 matrix
+            const int64_t c0 = (int64_t)bi * bw;
+            int64_t kk = (8 * bw + RT_SLICE_BYTES - 1) / RT_SLICE_BYTES;
+            static const char *ecp = getenv("MK_CB_PHASES");
+            if (ecp && atoi(ecp) > 0) kk = atoi(ecp);
+            kk = kk < 1 ? 1 : (kk > 64 ? 64 : kk);
+            B->plan.rt_k = (int)kk;
+            B->plan.rt_w = (int)((bw + kk - 1) / kk);
+            B->plan.rt_c0 = (int)c0;
             B->plan.rt_reg = 0;
+        }
+        if (!all && automatic && blk > ((int64_t)4 << 20)) {  // a tile of some block is too long for LDS: smaller blocks
+            cblocks_drop(P);
+            return cblocks_build(A, -(blk / 2));
         }
         if (!all)
             for (mk_csr *B : P.cblocks) {
@@ -646,7 +671,6 @@ __global__ __launch_bounds__(MK_BLOCK) void tile_extent_kernel(const int32_t *__
 // to a CU: resident tiles, gathers ordered by column block (mk_device.h).  Slices of <= 1.5 MiB: measured best on
 // 1e6 x 5 random (BiCGSTAB's fused product: K = 4 / 6 / 8 -> 38.8 / 37.9 / 38.7 us, 50.6 us with one phase, 53 us on
 // the gather path; tools/ubench/spmv_cb.hip has the kernel variants that were tried).
-constexpr int64_t RT_SLICE_BYTES = 3 << 19;
 constexpr int RT_CAP_MAX = 2560;                             // 30 KB of LDS per workgroup
 int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     const int64_t xbytes = 8 * A->x_len();

@@ -135,6 +135,7 @@ struct MkPlan {
     int rt_cap = 0;                // LDS capacity per tile in nonzeros (max tile stream length rounded up to 256)
     int rt_k = 1;                  // column phases
     int rt_w = 0;                  // columns per phase
+    int rt_c0 = 0;                 // first column of phase 0 (a column block's first column; 0 otherwise)
     int rt_reg = 0;                // rows of <= 5 entries and more tiles than resident workgroups: pairs of tiles (mk_spmv_fmt3r.h)
     int max_row = 0;               // longest row (entries) of the matrix
     double *d_carry = nullptr;     // per-lane accumulators of fused dots between the launches of a stepped product

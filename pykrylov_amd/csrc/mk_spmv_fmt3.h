@@ -57,7 +57,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt3(const MkCsrView &A, const dou
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int k = 0; k < A.rt_k; ++k) {
-            const int c1 = (k + 1 < A.rt_k) ? (k + 1) * A.rt_w : 0x7fffffff;
+            const int c1 = (k + 1 < A.rt_k) ? A.rt_c0 + (k + 1) * A.rt_w : 0x7fffffff;
             for (;;) {
                 int ca = 0x7fffffff;
                 if (cur < fin) ca = lc[cur];

@@ -1,6 +1,6 @@
 """The least-squares workload of bench.py at its own size: the seeded 4e6 x 1e6 matrix with 5 entries per row.  Its products run
 on round 4's scattered-matrix paths -- `A v`: format 3, pair kernel, one launch per step (15 625 tiles = 3.8 steps per workgroup);
-`A' u`: 1e6 rows of ~20 entries over 32 MB of u, eight 4 MiB column blocks as resident tiles -- which the small fixtures never reach."""
+`A' u`: 1e6 rows of ~20 entries over 32 MB of u, four 8 MiB column blocks as resident tiles with their own column phases -- which the small fixtures never reach."""
 import ctypes
 
 import numpy as np
@@ -38,7 +38,7 @@ def test_both_products_bit_exact_and_on_the_round4_paths(tall):
     _lib.check(lib.mk_csr_format_info(op.handle, ctypes.byref(fmt), None, None, None, None))
     assert fmt.value == 3                                                  # (pair kernel, stepped: 15 625 tiles on 2 048 workgroups)
     _lib.check(lib.mk_csr_colblocks(At.handle, ctypes.byref(nb)))
-    assert nb.value == 8                                                   # 32 MB of u in 4 MiB blocks, chosen automatically
+    assert nb.value == 4                                                   # 32 MB of u in 8 MiB blocks, chosen automatically
     # adjoint identity on the device products
     lhs, rhs = float(np.dot(y, u)), float(np.dot(x, v))
     assert abs(lhs - rhs) <= 1e-12 * np.linalg.norm(y) * np.linalg.norm(u)

@@ -152,7 +152,7 @@ def test_pair_kernel_in_a_solver_loop_matches_the_oracle():
 
 def test_automatic_column_blocks_for_long_rows_over_a_long_x():
     """>= 12 entries per row gathered from >= 16 MB of x (the transposed operator of a tall least-squares problem): the product
-    runs in 4 MiB column blocks with carried row sums -- the same left-to-right sums, the same bits."""
+    runs in column blocks of 8 MiB of x (4 MiB if a tile does not fit LDS) with carried row sums -- the same left-to-right sums, the same bits."""
     from pykrylov_amd import _lib
     lib = _lib.init()
     m, ncols, k = 60000, 2200000, 16
@@ -165,7 +165,7 @@ def test_automatic_column_blocks_for_long_rows_over_a_long_x():
     y = op * x
     nb = ctypes.c_int32()
     _lib.check(lib.mk_csr_colblocks(op.handle, ctypes.byref(nb)))
-    assert nb.value >= 4, nb.value                              # 17.6 MB of x in 4 MiB blocks
+    assert nb.value >= 2, nb.value                              # 17.6 MB of x in 8 MiB blocks (4 MiB if a tile outgrows LDS)
     assert np.array_equal(y, A.matvec(x))
     _lib.check(lib.mk_csr_set_colblocks(op.handle, 0))          # off: one launch
     _lib.check(lib.mk_csr_colblocks(op.handle, ctypes.byref(nb)))
