@@ -648,7 +648,9 @@ def main():
             # the same PARITY_PASSES passes ONE GPU ran when the fixture was made: partitioning changes the summation order
             # of the dots (per-rank partial sums, all-reduced) and nothing else, so the history must agree to 1e-12
             prun = DeviceRun(op, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=PARITY_PASSES, check_curvature=1)
-            pres = prun.run()
+            prun.setup()                                      # (exactly PARITY_PASSES passes are enqueued: no halted launches
+            prun.iterate(PARITY_PASSES)                       #  behind them, which would dilute a profiler's per-kernel averages)
+            pres = prun.finish()
             ph = prun.history()
             prun.close()
             parity_info = {"passes": int(pres.nMatvec), "fixture": os.path.relpath(DEV_HIST, ROOT),
