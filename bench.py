@@ -7,26 +7,30 @@
 
 A "step" is one pass of the CG loop body (reference pykrylov/cg/cg.py:113-158: 1 SpMV, 2 dots,
 3 vector updates) on synthetic data resident in HBM.  Tolerances are set to zero so that exactly
-K passes run inside the timed region.  Rank 0 prints ONE JSON line.
+K passes run inside the timed region.
+
+OUTPUT.  Rank 0 prints ONE compact JSON line (<= 4096 bytes, `compact_line`): the contract keys, `config`, `roofline`
+(the SpMV kernel: physical bytes / HIP-event time), `iteration_frac`, `residual`, `parity_vs_n1`, `placement_draws`,
+`cpu_baseline`, the second workload as a block of the same shape (`second_workload`), and every other measured loop as
+[iterations/s, physical fraction] (`cg_other_workloads`, `solver_loops`).  Everything else -- per-product tables, notes,
+format descriptions, per-rank comm timings -- goes to bench_detail.json next to this file (BENCH_DETAIL overrides the path).
 
 Workloads (BASELINE.json `configs`):
-  poisson3d-512-varcoef  configs[4]  CG, 3-D 7-point Poisson 512^3 (1.34e8 rows, 9.4e8 nnz) with a VARIABLE coefficient
-                               field (-div(k grad u), harmonic-mean face coefficients, SPD, every stored value distinct),
-                               row-partitioned over N GPUs.  The default and the workload `value` and `roofline` are
-                               quoted on: no constant-coefficient compression applies, the product has to stream 8 bytes
-                               per nonzero -- this IS the CSR product north_star names.  It fits one GPU, so the 1/2/4/8
-                               series is one strong-scaling series over a fixed problem.
-  poisson3d-512          configs[4]  the same grid with constant coefficients (diagonal 6, off-diagonals -1): the special
-                               case whose rows and values compress to one byte per row (storage format 4); reported at
-                               N = 1 under "extra", with its own physical roofline.
-  poisson2d-1000         configs[1]  CG, 2-D 5-point Poisson, n = 1e6, one GPU; under "extra".
-  bicgstab-rand1m        configs[2]  BiCGSTAB, random nonsymmetric n = 1e6, ~5 nnz/row, one GPU; under "extra".
-  minres-shifted2d-2000  configs[3]  MINRES, shifted 2-D Laplacian n = 4e6, one GPU; under "extra".
+  poisson3d-512          configs[4]  CG, 3-D 7-point Poisson 512^3 (1.34e8 rows, 9.4e8 nnz; diagonal 6, off-diagonals -1),
+                               row-partitioned over N GPUs.  THE DEFAULT: `value`, `roofline` and `cpu_baseline` are
+                               quoted on it.  It fits one GPU, so the 1/2/4/8 series is one strong-scaling series over
+                               a fixed problem.  Rows and values compress to one byte per row (storage formats 4 / 9).
+  poisson3d-512-varcoef  configs[4]'s grid with a VARIABLE coefficient field (-div(k grad u), harmonic-mean face
+                               coefficients, SPD, every stored value distinct): no constant-coefficient compression applies,
+                               the product has to stream 8 bytes per nonzero.  `second_workload` at N = 1.
+  poisson2d-1000         configs[1]  CG, 2-D 5-point Poisson, n = 1e6, one GPU; `cg_other_workloads`.
+  bicgstab-rand1m        configs[2]  BiCGSTAB, random nonsymmetric n = 1e6, ~5 nnz/row, one GPU; `solver_loops`.
+  minres-shifted2d-2000  configs[3]  MINRES, shifted 2-D Laplacian n = 4e6, one GPU; `solver_loops`.
 
 Roofline convention (all figures PHYSICAL): `roofline.achieved` = bytes the kernel has to move in the storage format
 in use (matrix data of the format + x once + y once) / its average duration; `frac` = achieved / 8 TB/s, never above
 1 by construction.  The CSR-priced figure (12 nnz + 4 (n+1) + 8 ncols + 8 nrows over the same time) is
-reported beside it as `csr_equivalent_GBs` -- a throughput in CSR units, not a fraction of anything.
+in bench_detail.json as `csr_equivalent_GBs` -- a throughput in CSR units, not a fraction of anything.
 
 Multi-GPU: one process per GPU.  torch.distributed is used with the gloo backend ONLY, for the bootstrap
 (RCCL unique id, barriers, max over ranks of the elapsed time): the only RCCL instance in a process is the one
@@ -67,7 +71,121 @@ FMT_NAMES = {0: "csr (int32 columns + fp64 values, x gathered)",
                 "tile-sliced ELL order (10 B per nonzero)",
              7: "wide windowed tiles + row patterns (one byte per row) + fp64 values streamed in tile-sliced ELL order",
              8: "wide windowed tiles + value dictionary + row patterns (one byte per ROW, entries {offset, value} through "
-                "the scalar cache)"}
+                "the scalar cache)",
+             9: "z-marching pencils for 7-point-class stencils (one byte per ROW + value dictionary; every x entry loaded "
+                "once, the planes z-1, z, z+1 of a workgroup's cells ride in registers)"}
+
+
+SHORT_FMT = {0: "fmt0 csr, x gathered", 1: "fmt1 windowed tiles: u16 slots + f64 values",
+             2: "fmt2 windowed tiles + value dictionary (4 B/nnz)", 3: "fmt3 csr, LDS-resident tile, column phases",
+             4: "fmt4 pattern byte/row + value dictionary (0 B/nnz)", 5: "fmt5 pattern byte/row + streamed f64 values (8 B/nnz)",
+             6: "fmt6 wide tiles: u16 slots + f64 values (10 B/nnz)", 7: "fmt7 wide tiles: pattern byte/row + f64 values",
+             8: "fmt8 wide tiles: pattern byte/row + value dictionary", 9: "fmt9 z-marching pencils: pattern byte/row + value dictionary"}
+BASELINE_CONFIG = {
+    "poisson3d-512": "configs[4]: CG on 3-D 7-point Poisson 512^3 (diagonal 6, off-diagonals -1); fits one GPU, so the "
+                     "1/2/4/8 series is strong scaling over this fixed problem",
+    "poisson3d-512-varcoef": "configs[4]'s grid with a variable coefficient field (no constant-coefficient compression "
+                             "applies: the product streams 8 B per nonzero)",
+    "poisson2d-1000": "configs[1]", "bicgstab": "configs[2]", "minres": "configs[3]"}
+LINE_LIMIT = 4096              # bytes of the ONE JSON line on stdout; everything else goes to bench_detail.json
+
+
+def sig(v, n=6):
+    """Floats cut to n significant digits (the compact line has a byte budget); non-finite -> None."""
+    if isinstance(v, (bool, int, str)) or v is None:
+        return v
+    v = float(v)
+    return float("%.*g" % (n, v)) if np.isfinite(v) else None
+
+
+def _compact_roofline(r):
+    tb = r.get("traffic_bytes")
+    out = {"bound": r.get("bound", "hbm"), "kernel": str(r.get("kernel", ""))[:80], "achieved": sig(r.get("achieved")),
+           "peak": r.get("peak", HBM_PEAK_GBS), "unit": r.get("unit", "GB/s"), "frac": sig(r.get("frac"), 4),
+           "bytes_per_launch": r.get("bytes_per_launch"), "avg_launch_us": sig(r.get("avg_launch_us")),
+           "traffic": tb, "traffic_bytes": tb}
+    if tb and r.get("bytes_per_launch"):
+        out["traffic_ratio"] = sig(tb / float(r["bytes_per_launch"]), 4)
+    return out
+
+
+def _compact_cpu(c):
+    if not c:
+        return None
+    out = {k: sig(c.get(k)) for k in ("value", "unit", "cores", "kind", "extrapolated", "sample_rows")}
+    out["sample"] = str(c.get("sample", ""))[:96]
+    return out
+
+
+def _compact_cg(b):
+    """The compact form of one CG workload block (same shape for the headline and the second workload)."""
+    res, par = b.get("residual") or {}, b.get("parity_vs_n1")
+    out = {"workload": "CG " + b["workload"], "value": sig(b["value"]), "unit": "iterations/s", "steps": b["steps"],
+           "ms_per_step": sig(b["ms_per_step"]), "rows": b["rows"], "nnz": b["nnz"],
+           "storage_format": SHORT_FMT.get(b["storage_format"]["format"], str(b["storage_format"]["format"])),
+           "roofline": _compact_roofline(b["roofline"]),
+           "iteration_frac": sig(b["iteration_roofline"]["frac_of_aggregate_hbm"], 4),
+           "residual": {k: sig(res.get(k)) for k in ("true", "recurrence", "rel_gap", "ok")},
+           "parity_vs_n1": ({"ok": par.get("ok"), "rel_hist_err": sig(par.get("rel_hist_err"), 3), "passes": par.get("passes")}
+                            if par else None),
+           "placement_draws": {"count": (b.get("placement_draws") or {}).get("count", 1)}}
+    if b.get("cpu_baseline"):
+        out["cpu_baseline"] = _compact_cpu(b["cpu_baseline"])
+    if b.get("cpu_baseline_all_cores"):
+        out["cpu_baseline_all_cores"] = _compact_cpu(b["cpu_baseline_all_cores"])
+    return out
+
+
+def compact_line(detail):
+    """The ONE JSON object bench.py prints (<= LINE_LIMIT bytes): the driver's contract keys, the headline workload's
+    roofline / residual / parity / CPU baseline, the second workload as a block of the same shape, and every other
+    measured loop as [iterations/s, physical fraction of the HBM roofline].  Everything else is in bench_detail.json.
+    Pure function of the detail dict (tests/test_host.py runs it on canned details without a GPU)."""
+    name = detail["headline"]
+    head = _compact_cg(detail["workloads"][name])
+    line = {"metric": detail["metric"], "value": head["value"], "unit": "iterations/s", "n_gpus": detail["n_gpus"],
+            "steps": detail["steps"], "warmup": detail["warmup"], "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": detail["scaling"], "vs_baseline": None, "dtype": detail["dtype"],
+            "data": detail["data"],
+            "config": {"workload": head["workload"], "baseline_config": str(detail.get("baseline_config", ""))[:160],
+                       "solver": "cg", "rows": head["rows"], "nnz": head["nnz"], "rhs": "A*1, x0=0, tolerances 0",
+                       "parallelism": str(detail["parallelism"])[:200], "storage_format": head["storage_format"]}}
+    for k in ("roofline", "iteration_frac", "residual", "parity_vs_n1", "placement_draws", "cpu_baseline",
+              "cpu_baseline_all_cores"):
+        if k in head:
+            line[k] = head[k]
+    for wname, b in detail["workloads"].items():
+        if wname == name:
+            continue
+        if wname.startswith("poisson3d-512"):                 # the second workload: a block of the headline's shape
+            line["second_workload"] = _compact_cg(b)
+        else:                                                 # [iterations/s, SpMV physical frac, iteration physical frac]
+            line.setdefault("cg_other_workloads", {})[wname] = [sig(b["value"], 5), sig(b["roofline"]["frac"], 3),
+                                                                sig(b["iteration_roofline"]["frac_of_aggregate_hbm"], 3)]
+    if detail.get("solver_loops"):
+        loops = {"cg": [head["value"], head["iteration_frac"]]}
+        for k, v in detail["solver_loops"].items():
+            loops[k.split("@")[0]] = [sig(v["value"], 5), sig(v["iteration_roofline"]["frac"], 3)]
+        line["solver_loops"] = loops
+    if detail.get("transport"):
+        line["transport"] = detail["transport"]
+    if detail.get("exchange"):
+        ex = {}
+        for mode, e in detail["exchange"].items():
+            per = (e.get("comm") or {}).get("per_rank") or []
+            worst = {}
+            for key in ("product_alone_us", "exchange_alone_us", "allreduce_2048_doubles_us",
+                        "last_overlapped_halo_group_us", "device_loop_ms_per_step"):
+                vals = [p[key] for p in per if p and p.get(key) is not None]
+                if vals:
+                    worst[key] = sig(max(vals), 5)
+            ex[mode] = {"value": sig(e["value"]), "ms_per_step": sig(e["ms_per_step"]), "steps": e["steps"],
+                        "max_over_ranks": worst}
+        line["exchange"] = ex
+    if detail.get("per_rank_budget"):
+        line["per_rank_budget_us"] = detail["per_rank_budget"].get("kernels_per_pass_us")
+    line["detail"] = "bench_detail.json"
+    return line
 
 
 def spmv_bytes(nrows, ncols, nnz):
@@ -78,9 +196,12 @@ def spmv_bytes(nrows, ncols, nnz):
 def kernel_source_sha():
     """Fingerprint of the SpMV kernel sources: PMC traffic figures under profiles/ are only quoted while it matches."""
     h = hashlib.sha256()
-    for f in ("mk_device.h", "mk_format.hip", "mk_internal.h", "mk_spmv_fmt0.h", "mk_spmv_fmt1.h", "mk_spmv_fmt24.h",
-              "mk_spmv_fmt3.h", "mk_spmv_fmt5.h", "mk_spmv_fmtw.h"):
-        with open(os.path.join(ROOT, "pykrylov_amd", "csrc", f), "rb") as fh:
+    csrc = os.path.join(ROOT, "pykrylov_amd", "csrc")
+    # every header a product kernel is compiled from: the per-format headers (all of them, whatever is added later), the
+    # shared device code, the epilogues' stores (mk_solver.h) and the format builder
+    files = sorted(f for f in os.listdir(csrc) if f.startswith("mk_spmv_fmt") and f.endswith(".h"))
+    for f in ["mk_device.h", "mk_format.hip", "mk_internal.h", "mk_solver.h"] + files:
+        with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
@@ -201,45 +322,57 @@ def host_mem_available_gb():
     return None
 
 
-def cpu_baseline_full_size(name, passes=4, threads=1):
-    """The CPU oracle MEASURED on the quoted workload itself (poisson3d-512-varcoef: 134 217 728 rows, 9.4e8 nonzeros,
-    11.8 GB of CSR arrays on the host + five 1 GiB vectors): `passes` passes of the reference's CG loop
-    (oracle/krylov_ref.cg: NumPy element-wise updates and np.dot on one thread, the C CSR product on `threads` OpenMP
-    threads) after one untimed pass.  The matrix is written by the C generator twin (oracle/csr_ref.c, pinned bit for bit
-    against the NumPy twin in tests/test_oracle_golden.py).  Runs in a child process so that the 17 GB are returned."""
+def cpu_baseline_full_size(names, passes=3, threads=(1,)):
+    """The CPU oracle MEASURED on the quoted workloads themselves (poisson3d-512 / poisson3d-512-varcoef: 134 217 728 rows,
+    9.4e8 nonzeros, 11.8 GB of CSR arrays on the host + five 1 GiB vectors): per workload and thread count `passes` passes of
+    the reference's CG loop (oracle/krylov_ref.cg: NumPy element-wise updates and np.dot on one thread, the C CSR product
+    on OpenMP threads) after one untimed pass.  The matrices are written by the C generator twins (oracle/csr_ref.c,
+    pinned bit for bit against the NumPy twins in tests/test_oracle_golden.py).  One child process per thread count
+    (libgomp reads its thread count when it loads; the 17 GB are returned with the child).
+    Returns {workload: {str(threads): {...}}}."""
     if os.environ.get("BENCH_CHILD") != "full":
         need = 24.0
         have = host_mem_available_gb()
         if have is not None and have < need:
             return {"value": None, "extrapolated": None,
                     "skipped": "host MemAvailable %.1f GB < %.0f GB needed for the 512^3 CSR arrays and vectors" % (have, need)}
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS="1", BENCH_CHILD="full")
-        code = ("import json,sys; sys.path.insert(0, %r); import bench; "
-                "print(json.dumps(bench.cpu_baseline_full_size(%r, %d, %d)))" % (ROOT, name, passes, threads))
-        try:
-            out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-            return json.loads(out.stdout.strip().splitlines()[-1])
-        except Exception as e:                               # a baseline must never take the bench line down
-            return {"value": None, "error": repr(e)[:300]}
+        out = {}
+        for th in threads:
+            env = dict(os.environ, OMP_NUM_THREADS=str(th), OPENBLAS_NUM_THREADS="1", BENCH_CHILD="full")
+            code = ("import json,sys; sys.path.insert(0, %r); import bench; "
+                    "print(json.dumps(bench.cpu_baseline_full_size(%r, %d, (%d,))))" % (ROOT, list(names), passes, th))
+            try:
+                res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+                got = json.loads(res.stdout.strip().splitlines()[-1])
+            except Exception as e:                           # a baseline must never take the bench line down
+                return {"value": None, "error": repr(e)[:300]}
+            for wname, per in got.items():
+                out.setdefault(wname, {}).update(per)
+        return out
     from oracle import csr_ref, krylov_ref
-    m = int(name.split("-")[1])
-    t0 = time.perf_counter()
-    A = csr_ref.poisson3d_varcoef_c(m, seed=VARCOEF_SEED) if name.endswith("-varcoef") else None
-    assert A is not None, "full-size CPU baseline: only the variable-coefficient workload has a C generator"
-    t_gen = time.perf_counter() - t0
-    n = A.shape[0]
-    rhs = A.matvec(np.ones(n))
-    krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=1)          # untimed: first touch of every page
-    t0 = time.perf_counter()
-    out = krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=passes)
-    dt = time.perf_counter() - t0
-    assert out["nMatvec"] == passes and np.isfinite(out["residHistory"][-1])
-    return {"value": passes / dt, "unit": "iterations/s", "cores": threads, "kind": "port", "extrapolated": False,
+    th = int(threads[0])
+    out = {}
+    for name in names:
+        m = int(name.split("-")[1])
+        t0 = time.perf_counter()
+        A = csr_ref.poisson3d_varcoef_c(m, seed=VARCOEF_SEED) if name.endswith("-varcoef") else csr_ref.poisson3d_c(m)
+        t_gen = time.perf_counter() - t0
+        n = A.shape[0]
+        rhs = A.matvec(np.ones(n))
+        krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=1)          # untimed: first touch of every page
+        t0 = time.perf_counter()
+        res = krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=passes)
+        dt = time.perf_counter() - t0
+        assert res["nMatvec"] == passes and np.isfinite(res["residHistory"][-1])
+        out[name] = {str(th): {
+            "value": passes / dt, "unit": "iterations/s", "cores": th, "kind": "port", "extrapolated": False,
             "sample_rows": int(n), "sample_nnz": int(A.nnz), "seconds_per_pass": dt / passes,
             "matrix_generation_seconds": t_gen,
             "sample": "%d CG passes of %s itself (%d rows, %d nnz) after 1 untimed pass; NumPy updates and np.dot on one "
-                      "thread, C CSR product on %d OpenMP thread(s)" % (passes, name, n, A.nnz, threads),
-            "host_cpus": os.cpu_count(), "residual_after": float(out["residHistory"][-1])}
+                      "thread, C CSR product on %d OpenMP thread(s)" % (passes, name, n, A.nnz, th),
+            "host_cpus": os.cpu_count(), "residual_after": float(res["residHistory"][-1])}}
+        del A, rhs, res
+    return out
 
 
 # ======================================================================================
@@ -308,7 +441,7 @@ def format_info(lib, op):
                                       ctypes.byref(nd), ctypes.byref(mbytes)))
     grid, tmap = ctypes.c_int32(), ctypes.c_int32()
     _lib.check(lib.mk_csr_launch_info(op.handle, ctypes.byref(grid), ctypes.byref(tmap)))
-    return {"format": fmt.value, "format_name": FMT_NAMES[fmt.value], "tiles_windowed": tiles.value,
+    return {"format": fmt.value, "format_name": FMT_NAMES.get(fmt.value, "format %d" % fmt.value), "tiles_windowed": tiles.value,
             "lds_window_chunks": chunks.value if fmt.value != 3 else 0,
             "column_phases": chunks.value if fmt.value == 3 else 0, "dictionary_size": nd.value,
             "matrix_bytes_per_product": mbytes.value, "grid": grid.value, "tile_order": tmap.value}
@@ -620,7 +753,7 @@ def main():
         return
     name = args.workload
     if name == "auto":
-        name = "poisson3d-512-varcoef"
+        name = "poisson3d-512"                               # BASELINE.json configs[4], literally
 
     def device_sync():
         _lib.check(lib.mk_sync())
@@ -778,7 +911,8 @@ def main():
                 traffic, tnote = ent, "measured with rocprofv3 PMC at this kernel build (%s)" % tj.get("measured", "?")
             elif ent:
                 tnote = "profiles/spmv_traffic.json was measured at another kernel build or format: not quoted"
-        roof = {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpi> (SpMV + fused <p,Ap>), " + fmt["format_name"],
+        roof = {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,%d> (SpMV + fused <p,Ap>)" % fmt["format"],
+                "kernel_format": fmt["format_name"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_bytes": (traffic or {}).get("bytes"), "traffic_note": tnote,
@@ -807,42 +941,35 @@ def main():
 
     multi = world_size > 1
     first_mode = "halo" if (not multi or args.exchange in ("both", "halo")) else "allgather"
-    info = run_cg(name, args.steps, args.warmup, args.event_stride, exchange=first_mode, comm_probe=multi,
-                  parity=(multi or args.parity or (name in ("poisson3d-512-varcoef", "poisson3d-512") and not args.no_parity)))
-    elapsed = info["elapsed"]
-    tm = info["timing"]
-    n_g = info["n_global"]
-    its, nnz_global, roof, it_roof = roofline_of(info, name)
+    full_512 = name in ("poisson3d-512-varcoef", "poisson3d-512")
+
+    def cg_workload(wname, steps, warmup, stride=0, headline=False):
+        """One CG workload measured end to end: the detail block both the compact line and bench_detail.json are cut from."""
+        info = run_cg(wname, steps, warmup, stride, exchange=first_mode, comm_probe=multi and headline,
+                      parity=(multi or args.parity or (wname in ("poisson3d-512-varcoef", "poisson3d-512")
+                                                        and not args.no_parity)))
+        w_its, w_nnz, w_roof, w_it = roofline_of(info, wname)
+        blk = {"workload": wname, "value": w_its, "unit": "iterations/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": 1e3 * info["elapsed"] / steps, "rows": info["n_global"], "nnz": w_nnz,
+               "roofline": w_roof, "iteration_roofline": w_it, "storage_format": info["fmt"],
+               "device_loop_ms": info["timing"]["iterate_ms"], "residual": info["residual"],
+               "parity_vs_n1": info["parity"], "placement_draws": info["placement"], "comm": info["comm"]}
+        return blk
+
+    head = cg_workload(name, args.steps, args.warmup, args.event_stride, headline=True)
     tkind, tranks, tsplit = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     _lib.check(lib.mk_comm_transport(ctypes.byref(tkind), ctypes.byref(tranks), ctypes.byref(tsplit)))
-
-    line = {
-        "metric": METRIC,
-        "value": its, "unit": "iterations/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "CG %s (%d rows, %d nnz), rhs=A*1, x0=0, tolerances 0" % (name, n_g, nnz_global),
-                   "baseline_config": ("configs[4]: CG on 3-D 7-point Poisson 512^3, the configuration the target is "
-                                       "quoted on (fits one GPU: same problem at every N, strong scaling)%s; the other "
-                                       "BASELINE configs are reported under extra"
-                                       % (", here with a variable coefficient field so that no constant-coefficient "
-                                          "compression applies and the product streams 8 B per nonzero"
-                                          if name.endswith("-varcoef") else "")) if name.startswith("poisson3d-512") else name,
-                   "solver": "cg", "rows": n_g, "nnz": nnz_global, "storage_format": info["fmt"],
-                   "parallelism": "1 GPU" if not multi else "row-partition x%d, %s exchange + allreduce(dots), %s"
-                                  % (world_size, first_mode, "RCCL (gloo bootstrap)" if transport_used == "rccl"
-                                     else "host-staged gloo (%s)" % (transport_note or "smoke test"))},
-        "roofline": roof,
-        "iteration_roofline": it_roof,
-        "device_loop_ms": tm["iterate_ms"],
-        "residual": info["residual"],
-        "placement_draws": info["placement"],
-    }
-    line["parity_vs_n1"] = info["parity"]
+    parallelism = "1 GPU" if not multi else ("row-partition x%d, %s exchange + allreduce(dots), %s"
+                                             % (world_size, first_mode, "RCCL (gloo bootstrap)" if transport_used == "rccl"
+                                                else "host-staged gloo (%s)" % (transport_note or "smoke test")))
+    detail = {"metric": METRIC, "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "scaling": "strong",
+              "dtype": "f64", "data": "synthetic", "headline": name, "parallelism": parallelism,
+              "baseline_config": BASELINE_CONFIG.get(name, name), "workloads": {name: head},
+              "kernel_source_sha": kernel_source_sha()}
     if multi:
         # what actually carried the collectives (a silent host-staged fallback must not pass for an RCCL number)
-        line["transport"] = {"kind": {0: "none", 1: "rccl", 2: "host-staged"}[tkind.value],
-                             "rccl_ranks_seen": tranks.value, "halo_communicator_split": bool(tsplit.value)}
+        detail["transport"] = {"kind": {0: "none", 1: "rccl", 2: "host-staged"}[tkind.value],
+                               "rccl_ranks_seen": tranks.value, "halo_communicator_split": bool(tsplit.value)}
         if transport_used == "rccl" and not (tkind.value == 1 and tranks.value == world_size):
             raise SystemExit("bench.py: asked for RCCL over %d ranks but the communicator reports kind %d with %d ranks"
                              % (world_size, tkind.value, tranks.value))
@@ -855,81 +982,66 @@ def main():
                       {"kernels_per_pass_us": 300, "spmv_interior_us": 108, "spmv_boundary_us": 18, "update_xp_us": 101,
                        "update_r_us": 68, "pack_us": 4.5})
             budget["source"] = "profiles/r03_slab_budget.txt (rank 3's slab alone on one GPU, rocprofv3 kernel trace)"
-        line["per_rank_budget"] = budget
-        ex = {first_mode: {"value": its, "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
-                           "comm": info["comm"]}}
+        detail["per_rank_budget"] = budget
+        ex = {first_mode: {"value": head["value"], "ms_per_step": head["ms_per_step"], "steps": args.steps,
+                           "comm": head["comm"]}}
         if args.exchange == "both":
             s2 = max(10, args.steps // 5)
             i2 = run_cg(name, s2, max(5, args.warmup // 5), 0, exchange="allgather", comm_probe=True)
             ex["allgather"] = {"value": s2 / i2["elapsed"], "ms_per_step": 1e3 * i2["elapsed"] / s2, "steps": s2,
                                "comm": i2["comm"],
                                "note": "full-iterate all-gather (%.0f MB per product): north_star's general path; "
-                                       "the halo exchange is the one `value` is quoted on" % (8e-6 * n_g)}
-        line["exchange"] = ex
-        # SpMV roofline of rank 0's share, timed without collectives is not possible per launch: quote the
-        # per-step budget instead
-        line["roofline"]["note_multi"] = ("N > 1: the SpMV kernel is not timed alone (each launch is preceded by an "
+                                       "the halo exchange is the one `value` is quoted on" % (8e-6 * head["rows"])}
+        detail["exchange"] = ex
+        head["roofline"]["note_multi"] = ("N > 1: the SpMV kernel is not timed alone (each launch is preceded by an "
                                           "exchange); see iteration_roofline and exchange.*.comm")
+    second = None
+    if not multi and name == "poisson3d-512" and not args.no_extra:
+        # the same grid with a VARIABLE coefficient field: no constant-coefficient compression applies, the product streams
+        # 8 B per nonzero -- the CSR-class product north_star names, measured beside the literal configs[4] matrix
+        second = "poisson3d-512-varcoef"
+        detail["workloads"][second] = cg_workload(second, args.steps, args.warmup)
     if rank == 0 and not multi and not args.no_cpu and not os.environ.get("BENCH_CHILD"):
-        small = cpu_baseline(name)
-        line["cpu_baseline"] = small
-        if name == "poisson3d-512-varcoef":
-            # MEASURED at the quoted size; the 128^3 sample scaled by the rows ratio stays beside it
-            full1 = cpu_baseline_full_size(name, passes=4, threads=1)
-            if full1.get("value"):
-                full1["extrapolated_from_128cubed"] = small
-                line["cpu_baseline"] = full1
-                ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-                line["cpu_baseline_all_cores"] = cpu_baseline_full_size(name, passes=4, threads=min(ncpu, 64))
-            else:
-                line["cpu_baseline"]["full_size_attempt"] = full1
-        line["cpu_baseline_all_cores_extrapolated"] = cpu_baseline_all_cores(name)
-    if not multi and name.startswith("poisson3d-512") and not args.no_extra:
-        # the other BASELINE configs on one GPU, same measurement, reported beside the headline
-        extra = {}
-        others = [("poisson2d-1000", 2000, 200)]
-        if name.endswith("-varcoef"):
-            others.insert(0, ("poisson3d-512", max(100, args.steps // 2), max(10, args.warmup // 2)))
-            # rows of 27 entries (HPCG's sparsity): the wide storage formats, constant and variable coefficients
-            others += [("stencil27-256", 400, 40), ("stencil27-256-varcoef", 200, 20)]
+        small = cpu_baseline(name, seconds_budget=8.0 if full_512 else 20.0)
+        head["cpu_baseline"] = small
+        if full_512:
+            # MEASURED at the quoted size, both matrices in one child process; the 128^3 sample scaled by the rows ratio
+            # stays beside it in the detail file
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            wl = [name] + ([second] if second else [])
+            full = cpu_baseline_full_size(wl, passes=3, threads=(1, min(ncpu, 64)))
+            for wname in wl:
+                got = full.get(wname) if isinstance(full, dict) else None
+                blk = detail["workloads"][wname]
+                if got and got.get("1") and got["1"].get("value"):
+                    one = got["1"]
+                    one["extrapolated_from_128cubed"] = small if wname == name else None
+                    blk["cpu_baseline"] = one
+                    blk["cpu_baseline_all_cores"] = got.get(str(min(ncpu, 64)))
+                else:
+                    blk.setdefault("cpu_baseline", small if wname == name else cpu_baseline(wname, seconds_budget=8.0))
+                    blk["cpu_baseline"]["full_size_attempt"] = full if not isinstance(full, dict) or "error" in full \
+                        or "skipped" in full else got
+    if not multi and full_512 and not args.no_extra:
+        # the other BASELINE configs and every other solver loop on one GPU, same measurement (bench_detail.json; the
+        # compact line carries iterations/s and the physical fraction of each)
+        others = [("poisson2d-1000", 2000, 200), ("stencil27-256", 400, 40), ("stencil27-256-varcoef", 200, 20)]
         for wname, st, wu in others:
-            exi = run_cg(wname, st, wu, 0)
-            e_its, e_nnz, e_roof, e_it = roofline_of(exi, wname)
-            extra[wname + "@1"] = {"value": e_its, "unit": "iterations/s", "steps": st, "warmup": wu,
-                                   "ms_per_step": 1e3 * exi["elapsed"] / st, "roofline": e_roof,
-                                   "iteration_roofline": e_it, "storage_format": exi["fmt"],
-                                   "residual": exi["residual"]}
-        if "poisson3d-512@1" in extra:
-            extra["poisson3d-512@1"]["note"] = ("constant-coefficient special case of the headline workload: rows AND "
-                                                "values compress to one byte per row (format 4), so the product moves "
-                                                "a fraction of the CSR bytes; its roofline is priced at those bytes")
-        for k27 in ("stencil27-256@1", "stencil27-256-varcoef@1"):
-            if k27 in extra:
-                extra[k27]["note"] = ("not a BASELINE config: the 27-point box stencil (4.5e8 nonzeros), the matrix class "
-                                      "of storage formats 6 / 7 / 8; CSR gathers take 1.25-1.36 ms per product here")
-        extra.update(other_configs(lib))
-        line["extra"] = extra
-        if "poisson3d-512@1" in extra:
-            # the LITERAL configs[4] matrix (constant coefficients) at top level, where the driver's parser keeps it
-            lit = extra["poisson3d-512@1"]
-            line["config_literal"] = {"workload": "CG poisson3d-512 (constant coefficients: diagonal 6, off-diagonals -1)",
-                                      "value": lit["value"], "unit": "iterations/s", "ms_per_step": lit["ms_per_step"],
-                                      "steps": lit["steps"], "roofline": {k: lit["roofline"][k] for k in
-                                                                          ("achieved", "peak", "unit", "frac", "bytes_per_launch",
-                                                                           "avg_launch_us", "traffic")},
-                                      "iteration_frac_of_hbm": lit["iteration_roofline"]["frac_of_aggregate_hbm"],
-                                      "residual_rel_gap": lit["residual"]["rel_gap"],
-                                      "storage_format": lit["storage_format"]["format"]}
-        # one flat summary of all ten solver loops (north_star's list): it/s and physical fraction of the HBM roofline
-        loops = {"cg": {"workload": name, "value": its, "iteration_frac": it_roof["frac_of_aggregate_hbm"]}}
-        for k, v in extra.items():
-            sk = k.split("-")[0]
-            if sk in LOOP_BYTES:
-                loops[sk] = {"workload": k, "value": v["value"], "iteration_frac": v["iteration_roofline"]["frac"],
-                             "product_us": {pk: pv["avg_product_us"] for pk, pv in v.get("products", {}).items()}}
-        line["solver_loops"] = loops
+            detail["workloads"][wname] = cg_workload(wname, st, wu)
+        detail["workloads"]["stencil27-256"]["note"] = detail["workloads"]["stencil27-256-varcoef"]["note"] = (
+            "not a BASELINE config: the 27-point box stencil (4.5e8 nonzeros), the matrix class of storage formats 6 / 7 / 8")
+        detail["solver_loops"] = other_configs(lib)
     if rank == 0:
-        json_out.write(json.dumps(line) + "\n")
+        line = compact_line(detail)
+        text = json.dumps(line, separators=(",", ":"))
+        dpath = os.environ.get("BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+        try:
+            with open(dpath, "w") as fh:
+                json.dump(dict(detail, line=line), fh, indent=1)
+        except OSError as e:                                  # (a read-only checkout must not cost the line)
+            sys.stderr.write("bench.py: could not write %s: %r\n" % (dpath, e))
+        assert len(text) <= LINE_LIMIT, "compact line is %d bytes" % len(text)
+        json_out.write(text + "\n")
         json_out.flush()
     if td is not None:
         barrier()

@@ -102,3 +102,22 @@ void ref_poisson3d_varcoef_fill(int64_t mx, int64_t my, int64_t mz, uint64_t see
             if (ok[d]) { indices[p] = (int32_t)(i + off[d]); data[p] = -term[d]; ++p; }
     }
 }
+
+/* The constant-coefficient 7-point Laplacian (diagonal 6, off-diagonals -1; BASELINE configs[4]) written the same way:
+ * twin of csr_ref.py poisson3d, pinned bit for bit by tests/test_oracle_golden.py.  Row pointers: ref_poisson3d_indptr. */
+void ref_poisson3d_const_fill(int64_t mx, int64_t my, int64_t mz, int64_t row_begin, int64_t row_end,
+                              const int32_t *indptr, int32_t *indices, double *data)
+{
+    const int64_t off[6] = {-mx * my, -mx, -1, 1, mx, mx * my};
+#pragma omp parallel for schedule(static)
+    for (int64_t i = row_begin; i < row_end; ++i) {
+        const int64_t gx = i % mx, gy = (i / mx) % my, gz = i / (mx * my);
+        const int ok[6] = {gz > 0, gy > 0, gx > 0, gx < mx - 1, gy < my - 1, gz < mz - 1};
+        int64_t p = indptr[i - row_begin];
+        for (int d = 0; d < 3; ++d)
+            if (ok[d]) { indices[p] = (int32_t)(i + off[d]); data[p] = -1.0; ++p; }
+        indices[p] = (int32_t)i; data[p] = 6.0; ++p;
+        for (int d = 3; d < 6; ++d)
+            if (ok[d]) { indices[p] = (int32_t)(i + off[d]); data[p] = -1.0; ++p; }
+    }
+}

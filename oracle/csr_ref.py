@@ -35,6 +35,8 @@ def _clib():
             lib.ref_poisson3d_varcoef_fill.argtypes = ([ctypes.c_int64] * 3 + [ctypes.c_uint64] + [ctypes.c_int64] * 2
                                                        + [ctypes.c_void_p] * 3)
             lib.ref_poisson3d_varcoef_fill.restype = None
+            lib.ref_poisson3d_const_fill.argtypes = [ctypes.c_int64] * 5 + [ctypes.c_void_p] * 3
+            lib.ref_poisson3d_const_fill.restype = None
             _LIB = lib
         else:
             _LIB = False
@@ -220,6 +222,27 @@ def poisson3d_varcoef_c(mx, my=None, mz=None, seed=7, rows=None):
     indices = np.empty(nnz, dtype=np.int32)
     data = np.empty(nnz, dtype=np.float64)
     lib.ref_poisson3d_varcoef_fill(mx, my, mz, seed, a, b, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data)
+    A = RefCsr.__new__(RefCsr)
+    A.indptr, A.indices, A.data, A.shape, A._T = indptr, indices, data, (b - a, n), None
+    return A
+
+
+def poisson3d_c(mx, my=None, mz=None, rows=None):
+    """:func:`poisson3d` (constant coefficients) written straight into CSR arrays by the C twin (csr_ref.c
+    ref_poisson3d_const_fill): what lets bench.py's CPU baseline hold the literal BASELINE configs[4] matrix at 512^3.
+    Bit-identical to :func:`poisson3d` (tests/test_oracle_golden.py)."""
+    lib = _clib()
+    assert lib, "oracle/libcsr_ref.so is not built (make -C oracle)"
+    my = mx if my is None else my
+    mz = mx if mz is None else mz
+    n = mx * my * mz
+    a, b = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    indptr = np.empty(b - a + 1, dtype=np.int32)
+    nnz = lib.ref_poisson3d_indptr(mx, my, mz, a, b, indptr.ctypes.data)
+    assert nnz < 2 ** 31
+    indices = np.empty(nnz, dtype=np.int32)
+    data = np.empty(nnz, dtype=np.float64)
+    lib.ref_poisson3d_const_fill(mx, my, mz, a, b, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data)
     A = RefCsr.__new__(RefCsr)
     A.indptr, A.indices, A.data, A.shape, A._T = indptr, indices, data, (b - a, n), None
     return A

@@ -16,6 +16,7 @@ OBJDIR = os.path.join(HERE, "build")
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "-fvisibility=hidden",        # only the MK_API entry points of include/mikrylov.h are exported
     "-ffp-contract=off",          # one rounding per multiply and per add, like the NumPy expressions replaced
     *os.environ.get("MK_EXTRA_HIPCC_FLAGS", "").split(),     # (experiments: a second build with other -D switches)
     "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",

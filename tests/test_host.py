@@ -35,6 +35,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.mk_version() == 100
 
 
+def test_library_exports_nothing_but_the_declared_entry_points():
+    """-fvisibility=hidden + MK_API: the functions `nm -D` lists are exactly the entry points include/mikrylov.h declares
+    (no mangled internals; what else is dynamic are HIP's kernel handles and module ids, data objects, not functions)."""
+    import subprocess
+    from pykrylov_amd import _lib
+    _lib.load()
+    so = os.path.join(ROOT, "pykrylov_amd", "libmikrylov.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    funcs = sorted(ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "Tt")
+    assert funcs == header_functions(), sorted(set(funcs) ^ set(header_functions()))
+
+
 def test_struct_layouts_match_header(tmp_path):
     """sizeof/offsetof as the C compiler sees include/mikrylov.h == the ctypes mirrors."""
     import ctypes
@@ -357,3 +369,102 @@ def test_bench_least_squares_matrix_is_canonical_csr():
     again = bench.random_tall_csr(4000, 1000, k=5, seed=11)
     assert all(np.array_equal(a, b) for a, b in zip((indptr, indices, data), again))
     assert set(bench.LOOP_BYTES) == {"bicgstab", "cgs", "tfqmr", "minres", "symmlq", "lsqr", "lsmr", "craig", "craigmr"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py's compact line (the driver keeps an 8 KB tail of stdout; a 32 KB line cost round 4 its record)
+# ---------------------------------------------------------------------------------------------------------------------
+def _canned_cg_block(bench, wname, fmt, n_ranks=1):
+    m = int(wname.split("-")[1])
+    n = m ** 3 if "3d" in wname or "stencil" in wname else m * m
+    blk = {"workload": wname, "value": 438.31234567891234, "unit": "iterations/s", "steps": 1000, "warmup": 50,
+           "ms_per_step": 2.2815123456789, "rows": n, "nnz": 7 * n - 6 * m * m,
+           "roofline": {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,%d> (SpMV + fused <p,Ap>)" % fmt,
+                        "kernel_format": bench.FMT_NAMES[fmt], "achieved": 3019.123456789, "peak": 8000.0, "unit": "GB/s",
+                        "frac": 0.37739043209876, "traffic": {"bytes": 4712632246, "read_bytes": 3638830073},
+                        "traffic_bytes": 4712632246, "traffic_note": "x" * 200, "bytes_per_launch": 2323644416,
+                        "avg_launch_us": 769.61234567, "launches_timed": 200, "method": "y" * 100, "note": "z" * 400,
+                        "csr_bytes_per_launch": 13939769348, "csr_equivalent_GBs": 18112.123},
+           "iteration_roofline": {"bytes_per_iter": 10913579008, "achieved_GBs": 4783.2, "frac_of_aggregate_hbm": 0.5979,
+                                  "note": "n" * 300},
+           "storage_format": {"format": fmt, "format_name": bench.FMT_NAMES[fmt], "tiles_windowed": 524288, "grid": 1792},
+           "device_loop_ms": 2281.5,
+           "residual": {"first": 1254.1, "last": 3.1e-5, "recurrence": 3.123456789e-5, "true": 3.123456788e-5,
+                        "rel_gap": 8.1234e-18, "passes": 1050, "note": "r" * 250, "ok": True},
+           "parity_vs_n1": {"passes": 60, "fixture": "tests/golden/dev_hist_512.npz", "fixture_has_workload": True,
+                            "rel_hist_err": 1.23456789e-15, "bit_equal": False, "tolerance": 1e-12, "ok": True},
+           "placement_draws": {"count": 1, "chosen": 0, "per_draw_ms_per_pass": [], "probe_seconds": 0.0},
+           "comm": None}
+    if n_ranks > 1:
+        blk["comm"] = {"per_rank": [{"last_overlapped_halo_group_us": 31.5 + r, "device_loop_ms_per_step": 0.412345678,
+                                     "product_alone_us": 251.123456 + r, "exchange_alone_us": 29.87654321,
+                                     "allreduce_2048_doubles_us": 17.123456789, "allreduces_per_step": 2}
+                                    for r in range(n_ranks)], "tiles_interior_boundary_rank0": [63488, 2048]}
+    return blk
+
+
+def _canned_detail(bench, n_ranks):
+    head = "poisson3d-512"
+    d = {"metric": bench.METRIC, "n_gpus": n_ranks, "steps": 1000, "warmup": 50, "scaling": "strong", "dtype": "f64",
+         "data": "synthetic", "headline": head, "baseline_config": bench.BASELINE_CONFIG[head],
+         "parallelism": "1 GPU" if n_ranks == 1 else "row-partition x%d, halo exchange + allreduce(dots), host-staged gloo "
+                        "(RCCL communicator unavailable (rank 0: RuntimeError('%s')): host-staged gloo fallback)" % (n_ranks, "e" * 300),
+         "workloads": {head: _canned_cg_block(bench, head, 4, n_ranks)}, "kernel_source_sha": "0" * 16}
+    cpu = {"value": 0.93123456, "unit": "iterations/s", "cores": 1, "kind": "port", "extrapolated": False,
+           "sample_rows": 134217728, "sample_nnz": 937951232, "seconds_per_pass": 1.07, "sample": "s" * 300, "host_cpus": 128}
+    if n_ranks == 1:
+        d["workloads"][head]["cpu_baseline"] = dict(cpu)
+        d["workloads"][head]["cpu_baseline_all_cores"] = dict(cpu, cores=64, value=1.49)
+        d["workloads"]["poisson3d-512-varcoef"] = dict(_canned_cg_block(bench, "poisson3d-512-varcoef", 5),
+                                                       cpu_baseline=dict(cpu), cpu_baseline_all_cores=dict(cpu, cores=64))
+        for w, f in (("poisson2d-1000", 4), ("stencil27-256", 8), ("stencil27-256-varcoef", 7)):
+            d["workloads"][w] = _canned_cg_block(bench, w, f)
+        d["solver_loops"] = {}
+        for key in bench.LOOP_BYTES:
+            lab = {"bicgstab": "bicgstab-rand1m@1", "cgs": "cgs-rand1m@1", "tfqmr": "tfqmr-rand1m@1",
+                   "minres": "minres-shifted2d-2000@1", "symmlq": "symmlq-shifted2d-2000@1"}.get(key, key + "-rand4m-x-1m@1")
+            d["solver_loops"][lab] = {"value": 9545.151661382939, "iteration_roofline": {"frac": 0.3627153145104236},
+                                      "products": {"first (A p / A y)": {"avg_product_us": 37.48055458068848}}}
+    else:
+        d["transport"] = {"kind": "host-staged", "rccl_ranks_seen": 0, "halo_communicator_split": False}
+        d["per_rank_budget"] = {"kernels_per_pass_us": 300, "source": "profiles/r03_slab_budget.txt"} if n_ranks == 8 else None
+        comm = d["workloads"][head]["comm"]
+        d["exchange"] = {"halo": {"value": 1234.5678, "ms_per_step": 0.81, "steps": 1000, "comm": comm},
+                         "allgather": {"value": 234.5678, "ms_per_step": 4.26, "steps": 200, "comm": comm, "note": "a" * 200}}
+    return d
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 8])
+def test_bench_compact_line_fits_the_drivers_tail(n_ranks):
+    """`bench.compact_line` on canned results with worst-case string lengths: one JSON object of <= 4096 bytes that
+    carries the contract keys, `roofline` and (N = 1) `cpu_baseline`, for the N = 1, 2 and 8 shapes of the detail dict."""
+    import json
+    import bench
+    line = bench.compact_line(_canned_detail(bench, n_ranks))
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= bench.LINE_LIMIT == 4096, len(text)
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "iteration_frac", "residual", "parity_vs_n1",
+              "placement_draws"):
+        assert k in back, k
+    assert back["n_gpus"] == n_ranks and back["config"]["workload"] == "CG poisson3d-512" and back["dtype"] == "f64"
+    assert back["metric"] == bench.METRIC and back["vs_baseline"] is None and back["higher_is_better"] is True
+    roof = back["roofline"]
+    assert set(roof) >= {"bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "avg_launch_us",
+                         "traffic", "traffic_bytes"}
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and len(roof["kernel"]) <= 80
+    assert roof["traffic"] == 4712632246 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert back["residual"]["ok"] is True and back["parity_vs_n1"]["ok"] is True
+    if n_ranks == 1:
+        cb = back["cpu_baseline"]
+        assert set(cb) >= {"value", "unit", "cores", "kind", "sample"} and cb["kind"] == "port" and cb["cores"] == 1
+        second = back["second_workload"]
+        assert second["workload"] == "CG poisson3d-512-varcoef" and "roofline" in second and "cpu_baseline" in second
+        assert set(back["solver_loops"]) == {"cg"} | {k + s for k, s in zip(
+            bench.LOOP_BYTES, ["-rand1m"] * 3 + ["-shifted2d-2000"] * 2 + ["-rand4m-x-1m"] * 4)}
+        assert set(back["cg_other_workloads"]) == {"poisson2d-1000", "stencil27-256", "stencil27-256-varcoef"}
+    else:
+        assert back["transport"]["kind"] == "host-staged"
+        assert set(back["exchange"]) == {"halo", "allgather"}
+        assert back["exchange"]["halo"]["max_over_ranks"]["product_alone_us"] == pytest.approx(251.123456 + n_ranks - 1, rel=1e-4)

@@ -495,3 +495,17 @@ def test_varcoef_row_blocks_and_c_generator_twin(dims, rows):
     assert c.shape == blk.shape
     assert np.array_equal(c.indptr, blk.indptr) and np.array_equal(c.indices, blk.indices)
     assert np.array_equal(c.data, blk.data)
+
+
+@pytest.mark.parametrize("dims,rows", [((8, 6, 5), None), ((8, 6, 5), (37, 141)), ((16, 16, 16), None), ((12, 9, 4), (108, 324))])
+def test_constant_coefficient_c_generator_twin(dims, rows):
+    """The C generator of the literal BASELINE configs[4] matrix (csr_ref.c ref_poisson3d_const_fill: what bench.py's
+    cpu_baseline holds the constant-coefficient 512^3 problem with) writes the arrays of `poisson3d` bit for bit."""
+    whole = csr_ref.poisson3d(*dims)
+    a, b = rows if rows else (0, whole.shape[0])
+    lo, hi = whole.indptr[a], whole.indptr[b]
+    c = csr_ref.poisson3d_c(*dims, rows=rows)
+    assert c.shape == (b - a, whole.shape[1])
+    assert np.array_equal(c.indptr, whole.indptr[a:b + 1] - lo)
+    assert np.array_equal(c.indices, whole.indices[lo:hi]) and np.array_equal(c.data, whole.data[lo:hi])
+    assert c.indptr.dtype == np.int32 and c.indices.dtype == np.int32 and c.data.dtype == np.float64
