@@ -195,10 +195,17 @@ MK_API int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn,
  *      tile-sliced ELL order (10 bytes per nonzero; needs neither patterns nor a dictionary).  6 or 7 asked for
  *      explicitly are also applied to matrices formats 1 .. 5 would have served;
  *   3  plain CSR for matrices without a window cover whose x is longer than an L2: the tile's stream is held in LDS
- *      and the gathers of all workgroups walk x slice by slice (same arrays as format 0).
- * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 8 = the most compact format the matrix qualifies for;
+ *      and the gathers of all workgroups walk x slice by slice (same arrays as format 0);
+ *   9  z-marching bricks for 7-point-class matrices (round 5): every column offset in {0, +-1, +-L, +-P} with
+ *      L % 128 == 0, P % 4L == 0, nrows % P == 0 (the 7-point stencil of an nx x ny x nz grid, L = nx, P = nx ny, any
+ *      boundary treatment) and <= 256 distinct values: ONE BYTE per row names its pattern {7 values, presence mask}; a
+ *      workgroup owns a brick of 4 lines x 128 rows and marches through the planes with the planes z-1, z, z+1 of its own
+ *      rows in registers, so that every x entry is loaded once per product (format 4 requests each five times).  Chosen
+ *      automatically for single-device matrices of at least 2^21 rows (MK_PENCIL_MIN_ROWS); asked for explicitly it is
+ *      applied to any matrix of the class.  Matrices outside the class degrade to 8 and below.
+ * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 9 = the most compact format the matrix qualifies for;
  * format 3 is chosen automatically for scattered matrices with more than 5 MiB of x).  A request is an upper bound and
- * degrades silently (8 -> 7 -> 6 -> 0, 5 -> 1, 4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the
+ * degrades silently (9 -> 8, 8 -> 7 -> 6 -> 0, 5 -> 1, 4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the
  * gather path of format 0.
  * mk_csr_format_info reports what is in use: the format, the number of windowed tiles, the LDS chunks (128
  * doubles each) a workgroup reserves (format 3: the number of column phases), the dictionary size and the bytes of
@@ -230,6 +237,14 @@ MK_API int mk_csr_colblocks(const mk_csr *A, int32_t *nblocks);
 /* Launch geometry of A's product kernels (what fixes the summation order of the dots fused into them): the grid,
  * and the tile order (0 round robin; 1 each XCD sweeps a contiguous eighth; 2 XCD-contiguous blocks per step). */
 MK_API int mk_csr_launch_info(const mk_csr *A, int32_t *grid, int32_t *tile_map);
+/* Geometry of format 9 (all zero when A is in another format): the line and plane strides L and P found in the matrix,
+ * the number of planes, the planes a workgroup marches through per (brick, chunk) item, the chunks per brick and the
+ * number of distinct row patterns.  Workgroup b of a launch of `grid` workgroups takes the items b, b + grid, ...;
+ * item i = brick (i % bricks_per_plane) of chunk (i / bricks_per_plane), bricks_per_plane = (L / 128) (P / 4L), brick j
+ * starting at row (j / (L / 128)) 4L + (j % (L / 128)) 128 of a plane -- what oracle/gpu_order.py restates for the
+ * fused dots (test infrastructure). */
+MK_API int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t *stride_plane, int32_t *planes,
+                              int32_t *planes_per_chunk, int32_t *chunks, int32_t *patterns);
 
 /* y = A x   (K1; `self.op * p`, pykrylov/cg/cg.py:115 and every other solver).
  * x_dev must be 16-byte aligned and readable up to an even number of entries (one entry of slack when ncols is odd;

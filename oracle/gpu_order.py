@@ -121,9 +121,38 @@ def spmv_tile_order(ntiles, grid=None, tile_map=1):
     return order
 
 
+def pencil_partials(w, y, grid, L, P, nz, zc, chunks):
+    """Storage format 9 (csrc/mk_spmv_fmt9.h): workgroup b takes the (brick, chunk) items b, b + grid, ...; item i is
+    brick i % bpp of chunk i // bpp (bpp = (L / 128) (P / 4L) bricks per plane, brick j starting at row
+    (j // (L / 128)) 4 L + (j % (L / 128)) 128 of a plane); lane (wave v, lane l) owns the rows z P + c and z P + c + 1,
+    c = brick start + v L + 2 l, and adds their terms plane by plane through the chunk, row c first."""
+    prod = (np.asarray(w, dtype=np.float64) * np.asarray(y, dtype=np.float64)).reshape(nz, P)
+    bx = L // 128
+    bpp = bx * (P // (4 * L))
+    items = bpp * chunks
+    lane_c = (np.arange(4)[:, None] * L + 2 * np.arange(64)[None, :]).reshape(-1)       # lane t = 64 v + l
+    acc = np.zeros((grid, BLOCK))
+    for first in range(0, items, grid):                      # round k of every workgroup (vectorised over workgroups)
+        it = np.arange(first, min(first + grid, items))
+        b0 = ((it % bpp) // bx) * 4 * L + ((it % bpp) % bx) * 128
+        ch = it // bpp
+        cols = b0[:, None] + lane_c[None, :]                 # (workgroups, 256): in-plane index of row c
+        for zi in range(zc):
+            z = ch * zc + zi
+            live = z < nz
+            if not live.any():
+                break
+            rows = np.nonzero(live)[0]
+            acc[rows] = acc[rows] + prod[z[live][:, None], cols[live]]
+            acc[rows] = acc[rows] + prod[z[live][:, None], cols[live] + 1]
+    return _block_sum(acc)
+
+
 def spmv_partials(w, y, ntiles, grid=None, tile_map=1):
     """Per-workgroup partial sums of sum(w*y) when the dot is fused into the SpMV kernel: lane t of a
     workgroup owns row 256*tile + t of each of its tiles and adds w[r]*y[r] in tile order."""
+    if isinstance(tile_map, tuple) and tile_map[0] == "pencil":
+        return pencil_partials(w, y, grid, *tile_map[1:])
     n = len(w)
     prod = np.zeros(ntiles * BLOCK)
     prod[:n] = np.asarray(w, dtype=np.float64) * np.asarray(y, dtype=np.float64)
@@ -145,6 +174,12 @@ def launch_geometry(op):
     from pykrylov_amd import _lib
     g, m = ctypes.c_int32(), ctypes.c_int32()
     _lib.check(_lib.init().mk_csr_launch_info(op.handle, ctypes.byref(g), ctypes.byref(m)))
+    sl, sp = ctypes.c_int64(), ctypes.c_int64()
+    nz, zc, ch, npat = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(_lib.init().mk_csr_pencil_info(op.handle, ctypes.byref(sl), ctypes.byref(sp), ctypes.byref(nz), ctypes.byref(zc),
+                                              ctypes.byref(ch), ctypes.byref(npat)))
+    if sl.value:                                              # storage format 9: brick march instead of 256-row tiles
+        return g.value, ("pencil", sl.value, sp.value, nz.value, zc.value, ch.value)
     if m.value in (3, 4):                                     # (these orders have parameters)
         o, s, p = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.init().mk_csr_tile_order(op.handle, ctypes.byref(o), ctypes.byref(s), ctypes.byref(p), None))

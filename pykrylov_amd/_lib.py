@@ -93,6 +93,7 @@ PROTOTYPES = {
     "mk_csr_set_format": (ctypes.c_int, [c_vp, ctypes.c_int]),
     "mk_csr_format_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i64), P(c_i32), P(c_i32), P(c_i64)]),
     "mk_csr_launch_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
+    "mk_csr_pencil_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
     "mk_csr_colblocks": (ctypes.c_int, [c_vp, P(c_i32)]),
     "mk_csr_set_tile_order": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32]),
     "mk_csr_tile_order": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),

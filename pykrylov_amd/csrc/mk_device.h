@@ -75,6 +75,10 @@ struct MkCsrView {
     const void *ptab;        // fmt 8: pattern entries {byte offset, value} (mk_spmv_fmtw.h) and per pattern {length | diagonal << 8}
     const int32_t *pinfo;
     int allwin;              // every tile of the matrix has windows (no tile ever takes the gather path)
+    // fmt 9 (mk_spmv_fmt9.h): strides of the 7-point-class matrix, planes, bricks per line / plane, planes per chunk, chunks
+    // (pid = pattern byte per row, ptab = 64 bytes per pattern)
+    int64_t pen_L, pen_P;
+    int pen_nz, pen_bx, pen_bpp, pen_zc, pen_chunks;
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
     int rt_c0;               // first column of the phases (0; a column block's first column: its phases cover ITS slice of x)
@@ -179,6 +183,10 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         if (g3 >= 8) g3 -= g3 % 8;
         return g3;
     }
+    if (P && P->fmt == 9) {                                  // one workgroup per (brick, chunk) item, at most MK_MAXP
+        const int64_t items = (int64_t)P->pen_bpp * P->pen_chunks;
+        return (int)(items > MK_MAXP ? MK_MAXP : items);
+    }
     if (P && P->fmt == 3) {                                  // as many as fit at once with one tile in LDS each
         int g3 = (int)(A->ntiles > MK_MAXP ? MK_MAXP : A->ntiles);
         if (g3 >= 8) g3 -= g3 % 8;
@@ -248,7 +256,18 @@ static inline MkCsrView mk_view(const mk_csr *A) {
     v.part = 0;
     const MkPlan *P = mk_csr_plan(A);
     v.fmt = P ? P->fmt : 0;
-    if (v.fmt == 3) {
+    if (v.fmt == 9) {
+        v.pid = P->d_pid;
+        v.ptab = P->d_ptab;
+        v.npat = P->npat;
+        v.pen_L = P->pen_L;
+        v.pen_P = P->pen_P;
+        v.pen_nz = P->pen_nz;
+        v.pen_bx = P->pen_bx;
+        v.pen_bpp = P->pen_bpp;
+        v.pen_zc = P->pen_zc;
+        v.pen_chunks = P->pen_chunks;
+    } else if (v.fmt == 3) {
         v.rt_cap = P->rt_cap;
         v.rt_k = P->rt_k;
         v.rt_w = P->rt_w;
@@ -538,11 +557,13 @@ __device__ __forceinline__ void mk_load_meta(const MkCsrView &A, int64_t p, int6
 #include "mk_spmv_fmt3r.h"
 #include "mk_spmv_fmt5.h"
 #include "mk_spmv_fmtw.h"
+#include "mk_spmv_fmt9.h"
 
 constexpr int MK_FMT_WIDE = 7;                       // template values of the wide kernels (6 = format 5, non-temporal):
 constexpr int MK_FMT_WIDE_DICT = 8;                  // 7 streams values (fmt 6, 7), 8 takes them from the dictionary (fmt 8),
 constexpr int MK_FMT_WIDE_NT = 9;                    // 9 = 7 with non-temporal loads of the streams
 constexpr int MK_FMT_PAIR = 10;                      // format 3 with a second tile per workgroup in registers (rows <= 5 entries)
+constexpr int MK_FMT_PENCIL = 11;                    // format 9: z-marching bricks (mk_spmv_fmt9.h)
 
 template <int FMT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
@@ -551,6 +572,7 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     else if constexpr (FMT == 1) mk_spmv_tiles_fmt1<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 3) mk_spmv_tiles_fmt3<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == MK_FMT_PAIR) mk_spmv_tiles_fmt3r<5, PROG>(A, x, epi, prod, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL) mk_spmv_tiles_fmt9<PROG>(A, x, epi, xw, acc);
     else if constexpr (FMT == MK_FMT_WIDE || FMT == MK_FMT_WIDE_DICT || FMT == MK_FMT_WIDE_NT)
         mk_spmv_tiles_wide<FMT == MK_FMT_WIDE_DICT, FMT == MK_FMT_WIDE_NT, PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT >= 5) mk_spmv_tiles_fmt5<PROG, FMT == 6>(A, x, epi, prod, xw, acc);
@@ -565,13 +587,13 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : (FMT == 11 ? 2 : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
     extern __shared__ __attribute__((aligned(16))) double mk_smem[];
     double *prod = mk_smem;
-    double *xw = (FMT == 2 || (FMT >= 4 && FMT < 10)) ? mk_smem : mk_smem + MK_PROD_LDS;
+    double *xw = (FMT == 2 || (FMT >= 4 && FMT != 10)) ? mk_smem : mk_smem + MK_PROD_LDS;
     __shared__ double s4[4];
     const bool halted = halt.in();
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -643,7 +665,11 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         const size_t w = sizeof(double) * (size_t)(128 * v.wchunks + 2) + sizeof(uint32_t) * (MK_SPMV_TILE + 16);
         lds = w > lds ? w : lds;
     }
-    if (v.fmt == 4) {                                        // windows + pattern table, or the gather path's products
+    if (v.fmt == 9) {                                        // two plane images of the brick + the dump row
+        lds = sizeof(double) * (size_t)MK_PEN_LDS + 64 * (size_t)v.npat;
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi,
+                           gate, halt, partials);
+    } else if (v.fmt == 4) {                                 // windows + pattern table, or the gather path's products
         size_t wtop = (size_t)(128 * v.wchunks + 2);
         if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
         lds = sizeof(double) * (wtop + MK_BLOCK) + 16 * (size_t)(v.npat * v.pmax + 1);   // windows, zeros, table

@@ -517,8 +517,8 @@ void plan_free(MkPlan &P) {
 int default_format() {
     static int f = [] {
         const char *e = getenv("MK_SPMV_FORMAT");
-        int v = e ? atoi(e) : 8;
-        return v < 0 ? 0 : (v > 8 ? 8 : v);
+        int v = e ? atoi(e) : 9;
+        return v < 0 ? 0 : (v > 9 ? 9 : v);
     }();
     return f;
 }
@@ -972,6 +972,227 @@ bool cover_build(const mk_csr *A, MkPlan &P, bool wide) {
     return ok;
 }
 
+// ------------------------------------------------------------------------------------------------ fmt 9
+// z-marching bricks (mk_spmv_fmt9.h): is the matrix 7-point class -- every column offset in {0, +-1, +-L, +-P} -- with
+// strides the brick geometry can tile (L % 128 == 0, P % 4L == 0, nrows % P == 0) and <= 256 distinct values?  Then a row
+// is described EXACTLY by a 63-bit key, 9 bits per offset in column order: 0 = no entry, 1 + the value's dictionary code
+// otherwise.  Distinct keys (<= 256) are collected in the open-addressing set the dictionary uses, numbered in ascending
+// order (deterministic), and every row gets the number of its key: no hashing, nothing to verify.
+// stats: [0] smallest |offset| above 1, [1] largest |offset|, [2] longest row
+__global__ __launch_bounds__(MK_BLOCK) void pen_scan(int64_t nrows, const int32_t *__restrict__ ip,
+                                                     const int32_t *__restrict__ ix, int *__restrict__ stats) {
+    int mn = 0x7fffffff, mx = 0, ml = 0;
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        const int lo = ip[r], hi = ip[r + 1];
+        ml = (hi - lo > ml) ? hi - lo : ml;
+        if (hi - lo > 7) continue;                           // (the caller gives up on ml > 7)
+        for (int j = lo; j < hi; ++j) {
+            const int64_t d = (int64_t)ix[j] - r;
+            const int64_t a = d < 0 ? -d : d;
+            if (a > 1) {
+                mn = a < mn ? (int)a : mn;
+                mx = a > mx ? (int)a : mx;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int omn = __shfl_down(mn, off), omx = __shfl_down(mx, off), oml = __shfl_down(ml, off);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+        ml = oml > ml ? oml : ml;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&stats[0], mn);
+        atomicMax(&stats[1], mx);
+        atomicMax(&stats[2], ml);
+    }
+}
+
+// the key of row r (0 = the row does not fit the class: an offset outside the set, or a value outside the dictionary)
+__device__ inline unsigned long long pen_row_key(const int32_t *__restrict__ ip, const int32_t *__restrict__ ix,
+                                                 const double *__restrict__ data, const unsigned long long *dk, int count,
+                                                 int64_t r, int64_t L, int64_t P) {
+    const int lo = ip[r], hi = ip[r + 1];
+    unsigned long long key = 0;
+    if (hi - lo > 7 || hi == lo) return 0;
+    for (int j = lo; j < hi; ++j) {
+        const int64_t d = (int64_t)ix[j] - r;
+        int k;
+        if (d == -P) k = 0;
+        else if (d == -L) k = 1;
+        else if (d == -1) k = 2;
+        else if (d == 0) k = 3;
+        else if (d == 1) k = 4;
+        else if (d == L) k = 5;
+        else if (d == P) k = 6;
+        else return 0;
+        const unsigned long long v = (unsigned long long)__double_as_longlong(data[j]);
+        int c = 0;                                           // largest index with dk[c] <= v
+#pragma unroll
+        for (int step = 128; step >= 1; step >>= 1)
+            if (c + step < count && dk[c + step] <= v) c += step;
+        if (dk[c] != v) return 0;
+        key |= (unsigned long long)(c + 1) << (9 * k);
+    }
+    return key;
+}
+
+// pass 1 (sorted == null): every row's key into the set; pass 2: the number of the row's key among the sorted keys -> pid
+__global__ __launch_bounds__(MK_BLOCK) void pen_rows(int64_t nrows, const int32_t *__restrict__ ip, const int32_t *__restrict__ ix,
+                                                     const double *__restrict__ data, const double *__restrict__ dict, int count,
+                                                     int64_t L, int64_t P, unsigned long long *table, int *state,
+                                                     const double *__restrict__ sorted, int nkeys, uint8_t *__restrict__ pid) {
+    __shared__ unsigned long long dk[256], sk[256];
+    dk[threadIdx.x] = (threadIdx.x < count) ? (unsigned long long)__double_as_longlong(dict[threadIdx.x]) : ~0ULL;
+    if (sorted) sk[threadIdx.x] = (threadIdx.x < nkeys) ? (unsigned long long)__double_as_longlong(sorted[threadIdx.x]) : ~0ULL;
+    __syncthreads();
+    unsigned long long seen = 0;
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        const unsigned long long key = pen_row_key(ip, ix, data, dk, count, r, L, P);
+        if (key == 0) {
+            state[1] = 1;
+            return;
+        }
+        if (!sorted) {
+            if (key == seen) continue;
+            if (__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            set_insert(table, state, key, 256);
+            seen = key;
+        } else {
+            int c = 0;
+#pragma unroll
+            for (int step = 128; step >= 1; step >>= 1)
+                if (c + step < nkeys && sk[c + step] <= key) c += step;
+            pid[r] = (uint8_t)c;
+        }
+    }
+}
+
+// 64 bytes per pattern: the seven values in column order (+0.0 where the row has no entry), the presence mask, 0
+__global__ __launch_bounds__(MK_BLOCK) void pen_table(int nkeys, const double *__restrict__ sorted, const double *__restrict__ dict,
+                                                      uint32_t *__restrict__ tab) {
+    const int j = threadIdx.x;
+    if (j >= nkeys) return;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(sorted[j]);
+    unsigned mask = 0;
+    for (int k = 0; k < 7; ++k) {
+        const unsigned f = (unsigned)(key >> (9 * k)) & 511u;
+        const unsigned long long v = f ? (unsigned long long)__double_as_longlong(dict[f - 1]) : 0ULL;
+        tab[16 * j + 2 * k] = (uint32_t)v;
+        tab[16 * j + 2 * k + 1] = (uint32_t)(v >> 32);
+        mask |= f ? (1u << k) : 0u;
+    }
+    tab[16 * j + 14] = mask;
+    tab[16 * j + 15] = 0;
+}
+
+// Below this many rows the windowed pattern format (fmt 4) keeps the matrix: a brick march needs a few thousand
+// (brick, chunk) items of >= 8 planes to fill the chip, and a cache-resident product is latency bound either way
+int64_t pencil_min_rows() {
+    static int64_t v = [] {
+        const char *e = getenv("MK_PENCIL_MIN_ROWS");
+        return e ? atoll(e) : (int64_t)1 << 21;
+    }();
+    return v;
+}
+
+// true: P holds format 9.  false: the matrix is not of the class (P untouched apart from freed scratch).
+bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced) {
+    if (A->nrows != A->ncols || A->nnz > 7 * A->nrows || A->nrows < 1024 || A->alias || A->ex.mode >= 0) return false;
+    if (!forced && A->nrows < pencil_min_rows()) return false;
+    hipStream_t st = mk_ctx().stream;
+    int *d_stats = nullptr;
+    unsigned long long *d_table = nullptr;
+    double *d_dict = nullptr, *d_keys = nullptr;
+    uint8_t *d_pid = nullptr;
+    uint32_t *d_tab = nullptr;
+    auto drop = [&]() {
+        hipFree(d_stats);
+        hipFree(d_table);
+        hipFree(d_dict);
+        hipFree(d_keys);
+        hipFree(d_pid);
+        hipFree(d_tab);
+        return false;
+    };
+    int h_stats[3] = {0x7fffffff, 0, 0};
+    if (hipMalloc((void **)&d_stats, sizeof(h_stats)) != hipSuccess) return drop();
+    if (hipMemcpyAsync(d_stats, h_stats, sizeof(h_stats), hipMemcpyHostToDevice, st) != hipSuccess) return drop();
+    int grid = (int)((A->nrows + MK_BLOCK - 1) / MK_BLOCK);
+    grid = grid > 2048 ? 2048 : grid;
+    hipLaunchKernelGGL(pen_scan, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, d_stats);
+    if (hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return drop();
+    const int64_t L = h_stats[0], PP = h_stats[1];
+    if (h_stats[2] > 7 || L >= PP || L <= 1 || L % 128 != 0 || PP % (4 * L) != 0 || A->nrows % PP != 0 || A->nrows / PP < 2 ||
+        L / 128 * (PP / (4 * L)) > (1 << 24))
+        return drop();
+    // the dictionary (values only: no per-nonzero words)
+    int h_state[2] = {0, 0};
+    if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS + 2 * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&d_dict, sizeof(double) * 256) != hipSuccess ||
+        hipMalloc((void **)&d_keys, sizeof(double) * 256) != hipSuccess)
+        return drop();
+    int *d_state = reinterpret_cast<int *>(d_table + DICT_SLOTS);
+    std::vector<unsigned long long> empty(DICT_SLOTS, DICT_EMPTY);
+    auto reset_set = [&]() {
+        return hipMemcpyAsync(d_table, empty.data(), sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyHostToDevice, st) == hipSuccess &&
+               hipMemsetAsync(d_state, 0, 2 * sizeof(int), st) == hipSuccess;
+    };
+    auto read_state = [&]() {
+        return hipMemcpyAsync(h_state, d_state, sizeof(h_state), hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess;
+    };
+    if (!reset_set()) return drop();
+    int gnz = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
+    hipLaunchKernelGGL(dict_collect, dim3(gnz > 512 ? 512 : gnz), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, d_table, d_state);
+    if (!read_state() || h_state[1] || h_state[0] > 256 || h_state[0] < 1) return drop();
+    const int ndict = h_state[0];
+    hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_dict);
+    // the rows' keys
+    if (!reset_set()) return drop();
+    hipLaunchKernelGGL(pen_rows, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, d_dict, ndict,
+                       L, PP, d_table, d_state, (const double *)nullptr, 0, (uint8_t *)nullptr);
+    if (!read_state() || h_state[1] || h_state[0] > 256 || h_state[0] < 1) return drop();
+    const int nkeys = h_state[0];
+    hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_keys);
+    if (hipMalloc((void **)&d_pid, (size_t)A->nrows + 64) != hipSuccess ||
+        hipMalloc((void **)&d_tab, 64 * 256) != hipSuccess)
+        return drop();
+    hipMemsetAsync(d_pid, 0, (size_t)A->nrows + 64, st);
+    hipMemsetAsync(d_tab, 0, 64 * 256, st);
+    hipLaunchKernelGGL(pen_rows, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, d_dict, ndict,
+                       L, PP, d_table, d_state, (const double *)d_keys, nkeys, d_pid);
+    hipLaunchKernelGGL(pen_table, dim3(1), dim3(MK_BLOCK), 0, st, nkeys, d_keys, d_dict, d_tab);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return drop();
+    hipFree(d_stats);
+    hipFree(d_table);
+    hipFree(d_keys);
+    P.fmt = 9;
+    P.d_pid = d_pid;
+    P.d_ptab = d_tab;
+    P.d_dict = d_dict;
+    P.ndict = ndict;
+    P.npat = nkeys;
+    P.pen_L = L;
+    P.pen_P = PP;
+    P.pen_nz = (int)(A->nrows / PP);
+    P.pen_bx = (int)(L / 128);
+    P.pen_bpp = (int)(L / 128 * (PP / (4 * L)));
+    // chunks: about MK_MAXP (brick, chunk) items -- eight resident workgroups per CU -- of at least 8 planes each, a
+    // multiple of the ring depth so that only the matrix's last chunk has planes left over
+    static const char *env_zc = getenv("MK_PENCIL_ZC");
+    int chunks = (MK_MAXP + P.pen_bpp - 1) / P.pen_bpp;
+    int zc = (P.pen_nz + chunks - 1) / chunks;
+    zc = zc < 8 ? 8 : zc;
+    if (env_zc && atoi(env_zc) > 0) zc = atoi(env_zc);
+    zc = (zc + MK_PEN_R - 1) / MK_PEN_R * MK_PEN_R;
+    P.pen_zc = zc;
+    P.pen_chunks = (P.pen_nz + zc - 1) / zc;
+    return true;
+}
+
 // Which format: `want` (mk_csr_set_format, MK_SPMV_FORMAT; default 8) is the highest one the builder may choose.
 //   0 / 3     plain CSR (3: resident tiles when x is longer than an L2)
 //   1 .. 5    the 16-chunk cover (tiles of <= 2048 nonzeros): 1 slots + values, 2 + dictionary, 4 + row patterns,
@@ -997,6 +1218,7 @@ int plan_build(const mk_csr *A) {
         return MK_OK;
     };
     if (want == 0 || want == 3) return plain();
+    if (want >= 9 && pencil_plan(A, P, A->want_fmt == 9)) return MK_OK;      // fmt 9: 7-point-class matrices beyond the caches
     auto fail = [&](const char *what) {
         plan_free(P);
         P.built = true;
@@ -1082,7 +1304,7 @@ void mk_csr_plan_reset(const mk_csr *A) {
 
 extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {
     MK_REQUIRE_INIT();
-    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 8);
+    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 9);
     if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_format: set the format on the matrix a composed operator was built from");
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
@@ -1096,6 +1318,13 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
     if (fmt) *fmt = P->fmt;
+    if (P->fmt == 9) {                                       // one byte per row + the pattern table; no windows, no tiles
+        if (tiles_windowed) *tiles_windowed = 0;
+        if (lds_chunks) *lds_chunks = 0;
+        if (dict_size) *dict_size = P->ndict;
+        if (matrix_bytes_per_product) *matrix_bytes_per_product = A->nrows + 64 * (int64_t)P->npat;
+        return MK_OK;
+    }
     const bool windowed = (P->fmt == 1 || P->fmt == 2 || P->fmt >= 4);
     if (tiles_windowed) *tiles_windowed = windowed ? P->covered : 0;
     if (lds_chunks) *lds_chunks = windowed ? P->wchunks : (P->fmt == 3 ? P->rt_k : 0);
@@ -1165,5 +1394,20 @@ extern "C" int mk_csr_set_colblocks(mk_csr *A, int32_t block_kb) {
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
     A->want_cb_kb = block_kb;
+    return MK_OK;
+}
+
+extern "C" int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t *stride_plane, int32_t *planes,
+                                  int32_t *planes_per_chunk, int32_t *chunks, int32_t *patterns) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr);
+    const MkPlan *P = mk_csr_plan(A);
+    const bool on = P->fmt == 9;
+    if (stride_line) *stride_line = on ? P->pen_L : 0;
+    if (stride_plane) *stride_plane = on ? P->pen_P : 0;
+    if (planes) *planes = on ? P->pen_nz : 0;
+    if (planes_per_chunk) *planes_per_chunk = on ? P->pen_zc : 0;
+    if (chunks) *chunks = on ? P->pen_chunks : 0;
+    if (patterns) *patterns = on ? P->npat : 0;
     return MK_OK;
 }

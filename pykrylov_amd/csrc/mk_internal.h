@@ -101,7 +101,8 @@ constexpr int MK_WCHUNKS_WIDE = 32; // ... of the wide cover (8 per wave, 32 KiB
 constexpr int MK_WIDE_TILE = 8192;
 struct MkPlan {
     bool built = false;
-    int fmt = 0;                   // 0 plain CSR, 1 windows + uint16 slots, 2 windows + slots + value dictionary,
+    int fmt = 0;                   // 9 z-marching bricks: pattern byte per row + dictionary, 7-point-class matrices (below);
+                                   // 0 plain CSR, 1 windows + uint16 slots, 2 windows + slots + value dictionary,
                                    // 3 plain CSR, tile resident in LDS, gathers ordered by column block,
                                    // 4 windows + dictionary + row patterns (one byte per row)
                                    // 5 windows + row patterns + raw values in tile-sliced ELL order
@@ -138,6 +139,10 @@ struct MkPlan {
     int rt_c0 = 0;                 // first column of phase 0 (a column block's first column; 0 otherwise)
     int rt_reg = 0;                // rows of <= 5 entries and more tiles than resident workgroups: pairs of tiles (mk_spmv_fmt3r.h)
     int max_row = 0;               // longest row (entries) of the matrix
+    // fmt 9 (z-marching bricks, mk_spmv_fmt9.h): the three strides, planes, bricks per line / per plane, planes per chunk
+    // and chunks; d_pid holds the pattern byte per row, d_ptab 64 bytes per pattern {7 values, mask}, npat their number
+    int64_t pen_L = 0, pen_P = 0;
+    int pen_nz = 0, pen_bx = 0, pen_bpp = 0, pen_zc = 0, pen_chunks = 0;
     double *d_carry = nullptr;     // per-lane accumulators of fused dots between the launches of a stepped product
     // column blocks (plain-CSR matrices whose x does not fit an XCD's L2): A = [A_0 | A_1 | ...] by column range,
     // each block a CSR matrix over all rows; a product runs block after block with the running row sums carried

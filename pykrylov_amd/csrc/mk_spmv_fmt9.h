@@ -1,0 +1,192 @@
+// mk_spmv_fmt9.h -- z-marching bricks for 7-point-class matrices (one pattern byte per row + a value dictionary)
+#pragma once
+// (included by mk_device.h: one SpMV loop per storage format behind the same Epi / Gate / row_x interface)
+//
+// fmt 9 (round 5).  A matrix whose column offsets all lie in {0, +-1, +-L, +-P} with L a multiple of 128, P a multiple of
+// 4 L and nrows a multiple of P -- the 7-point stencil of an nx x ny x nz grid (L = nx, P = nx ny), any boundary
+// treatment, any band matrix of that shape -- and whose values come from <= 256 distinct bit patterns is stored as ONE
+// BYTE PER ROW (the number of the row's pattern) plus a table of 64 bytes per pattern: {7 values in column order, +0.0
+// where the row has no entry, a 7-bit presence mask}.  Same data volume as fmt 4; what changes is how x is read.
+//
+// fmt 4 ingests, per 256-row tile, every x window the tile touches (own, +-line, +-plane): each x entry is requested five
+// times, crosses the fabric about twice (counter traffic 2.03 x the format's bytes at 512^3), and a tile's chain
+// copies -> barrier -> row walk exposes the copy latency (0.75 ms for 2.3 GB).  Here a workgroup owns a BRICK -- 4 lines
+// x 128 rows, two adjacent rows per lane -- and marches through `zc` planes:
+//   * the x entries at the lane's own two rows of the planes z-1, z, z+1 ride in a ring of R = 6 register slots: every
+//     entry is loaded ONCE per product, 16 bytes per lane, R - 3 planes ahead of its first use, always into the slot
+//     whose plane went out of use one step EARLIER (a slot reloaded while its old value is still needed makes the
+//     compiler rotate the ring through register copies at the loop's back edge, and a copy of a register with a load in
+//     flight waits for that load: the pipeline drained once per round);
+//   * the in-plane neighbours (+-1, +-L) come from a double-buffered LDS image of the brick's current plane with a one-row
+//     halo (2 x 128 halo rows + 8 edge rows per plane: one 8-byte load per lane, R planes ahead; they are L2 hits --
+//     the neighbouring bricks' own rows);
+//   * one barrier per plane, 16-byte stores of the product.
+// The loop is unrolled R times so that every ring index is static, every load is unconditional (addresses clamped into
+// the vector) and no branch in the loop diverges: only then does the compiler count the loads in flight instead of
+// draining them (vmcnt(0)) once per round -- tools/ubench/pencil2.hip, where this structure moves the compulsory 16 N
+// bytes of the 512^3 product at 5.0 TB/s (0.43 ms) against 3.6 TB/s for round 4's unpipelined walker.
+//
+// Row sums: LEFT TO RIGHT in column order (-P, -L, -1, 0, +1, +L, +P), every product and every add rounds separately: the
+// bits of the scalar CSR loop.  The loop body is ONE basic block -- a waterfall over the wave's distinct patterns (fmt 8's
+// way) puts inner loops into the body, the register allocator then splits the ring slots' live ranges around them and
+// rotates the ring through copies at the back edge, each of which waits for a load issued a step earlier (measured in the
+// ISA: vmcnt(4) once per round).  So a lane keeps its two rows' patterns in registers -- seven values and seven 32-bit
+// AND masks each, reloaded from an LDS copy of the table only when a pattern byte of the wave changes (a wave-uniform
+// `if` that a stencil takes at the first and the last plane) -- and an entry the row does not have costs one v_and: its
+// value is +0.0 and the HIGH word of the x candidate is masked to zero, which leaves a tiny non-negative finite number, so
+// the product is exactly +0.0 whatever the candidate held (Inf, NaN included) and adding it leaves the running sum --
+// which started at +0.0 and therefore is never -0.0 -- unchanged bit for bit.  Everything is index based (row r's
+// neighbours are the vector entries r +- 1, r +- L, r +- P): no grid geometry is assumed beyond the three strides.
+//
+// Fused dots: lane (w, l) of a workgroup owns the rows z P + c, z P + c + 1 (c = brick base + w L + 2 l) of its items
+// (item = brick + bricks_per_plane * chunk; items blockIdx, blockIdx + grid, ...), and adds their terms plane by plane,
+// row c before row c + 1 (the tests restate this order on the host to demand bit equality).
+
+// one term of a row sum: s + v * x, x with its high word ANDed by m (0xffffffff: the row has the entry; 0: it has not, v = +0.0)
+__device__ __forceinline__ double mk_pen_term(double s, double v, unsigned m, double xk) {
+    return s + v * __hiloint2double((int)((unsigned)__double2hiint(xk) & m), __double2loint(xk));
+}
+
+constexpr int MK_PEN_R = 6;                                  // ring slots = unroll factor (own rows: prefetch depth R - 3 planes)
+constexpr int MK_PEN_H = 3;                                  // slots of the halo / pattern-byte rings (depth H planes; R % H == 0)
+constexpr int MK_PEN_RS = 132;                               // LDS row: [0] pad, [1] west edge, [2..129] rows, [130] east edge, [131] pad
+constexpr int MK_PEN_LDS = 3 * 6 * MK_PEN_RS + MK_BLOCK;     // doubles: two plane images of 6 rows + the dump rows (lanes without an
+                                                             // edge row store there, at the same buffer offset as the others)
+
+template <bool PROG, class Epi, int NACC>
+__device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
+                                                   double *smem, double (&acc)[NACC]) {
+    constexpr int R = MK_PEN_R, RS = MK_PEN_RS, BUF = 6 * MK_PEN_RS;
+    static_assert(MK_PEN_R % 2 == 0 && MK_PEN_R % MK_PEN_H == 0, "ring geometry");
+    constexpr bool ROWX = !PROG && MkHasRowX<Epi>::value;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int64_t L = A.pen_L, P = A.pen_P;
+    const int nz = A.pen_nz, bx = A.pen_bx, bpp = A.pen_bpp, zc = A.pen_zc;
+    const int64_t items = (int64_t)bpp * A.pen_chunks;
+    const int64_t last = A.nrows - 1;
+    const uint8_t *pid = A.pid;
+    // the pattern table, 16 words per pattern, behind the plane images (read-only after this copy)
+    unsigned *ptl = reinterpret_cast<unsigned *>(smem + MK_PEN_LDS);
+    for (int e = tid; e < 16 * A.npat; e += MK_BLOCK) ptl[e] = reinterpret_cast<const unsigned *>(A.ptab)[e];
+    __syncthreads();
+    double va[7], vb[7];                                     // this lane's two rows: values and AND masks of the 7 candidates
+    unsigned ma[7], mb[7], pprev = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        va[k] = vb[k] = 0.0;
+        ma[k] = mb[k] = 0u;
+    }
+    double *cdst = smem + (1 + w) * RS + 2 + 2 * l;
+    double *hdst = smem + (tid < 128 ? 0 : 5) * RS + 2 + (tid & 127);
+    double *edst = tid < 8 ? smem + (1 + (tid & 3)) * RS + ((tid & 4) ? 130 : 1) : smem + 2 * BUF + tid;
+
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int bi = (int)(item % bpp), chunk = (int)(item / bpp);
+        const int z0 = chunk * zc, z1 = (z0 + zc < nz) ? z0 + zc : nz;
+        const int64_t b0 = (int64_t)(bi / bx) * 4 * L + (int64_t)(bi % bx) * 128;    // the brick's first row in plane 0
+        const int64_t c = b0 + (int64_t)w * L + 2 * l;                                // this lane's rows c, c + 1 (in-plane index)
+        // halo row of this lane: lanes 0..127 the line below the brick, 128..255 the line above; lanes 0..7 also the row
+        // west / east of brick line tid & 3 (lanes >= 8 load lane (tid & 7)'s edge row again and drop it into the dump row)
+        const int64_t hc = tid < 128 ? b0 - L + tid : b0 + 4 * L + (tid - 128);
+        const int64_t ec = b0 + (int64_t)(tid & 3) * L + ((tid & 4) ? 128 : -1);
+        auto plane = [&](int p) -> mk_d2 {                    // the own rows of plane p (clamped into the grid: values of a
+            p = p < 0 ? 0 : (p > nz - 1 ? nz - 1 : p);       // plane that does not exist are never multiplied)
+            return *reinterpret_cast<const mk_d2 *>(x + (int64_t)p * P + c);
+        };
+        auto clampr = [&](int64_t r) { return r < 0 ? (int64_t)0 : (r > last ? last : r); };
+        constexpr int H = MK_PEN_H;
+        double hreg[H], ereg[H];
+        mk_d2 ring[R];
+        unsigned pidr[H];
+        auto halo = [&](int p, int d) {                       // plane p at the halo rows + the pattern bytes of the own rows
+            p = p > nz - 1 ? nz - 1 : p;
+            hreg[d] = x[clampr((int64_t)p * P + hc)];
+            ereg[d] = x[clampr((int64_t)p * P + ec)];
+            pidr[d] = *reinterpret_cast<const uint16_t *>(pid + (int64_t)p * P + c);
+        };
+        // one plane: slots (xm, xc, xp) = planes zz-1, zz, zz+1 at the own rows; hv / ev / pp = halo rows and pattern bytes of plane zz
+        auto step = [&](int zz, int bo, const mk_d2 xm_, const mk_d2 xc_, const mk_d2 xp_, double hv, double ev, unsigned pp,
+                        auto &&reload) {
+            mk_d2 xm, xc, xp;
+            xm.x = epi.xin(xm_.x); xm.y = epi.xin(xm_.y);
+            xc.x = epi.xin(xc_.x); xc.y = epi.xin(xc_.y);
+            xp.x = epi.xin(xp_.x); xp.y = epi.xin(xp_.y);
+            if (__builtin_amdgcn_ballot_w64(pp != pprev) != 0) {  // (wave uniform) a row of this wave follows another pattern now
+                const mk_u4 *ta = reinterpret_cast<const mk_u4 *>(ptl + 16 * (pp & 0xffu));
+                const mk_u4 *tb = reinterpret_cast<const mk_u4 *>(ptl + 16 * (pp >> 8));
+                const mk_u4 a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3], b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3];
+                const unsigned wa[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+                const unsigned wb[16] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    va[k] = __hiloint2double((int)wa[2 * k + 1], (int)wa[2 * k]);
+                    vb[k] = __hiloint2double((int)wb[2 * k + 1], (int)wb[2 * k]);
+                    ma[k] = ((wa[14] >> k) & 1u) ? 0xffffffffu : 0u;
+                    mb[k] = ((wb[14] >> k) & 1u) ? 0xffffffffu : 0u;
+                }
+                pprev = pp;
+            }
+            *reinterpret_cast<mk_d2 *>(cdst + bo) = xc;
+            hdst[bo] = epi.xin(hv);
+            edst[bo] = epi.xin(ev);
+            reload();
+            __syncthreads();
+            const double *row = cdst + bo;
+            const mk_d2 lo = *reinterpret_cast<const mk_d2 *>(row - RS), up = *reinterpret_cast<const mk_d2 *>(row + RS);
+            const double we = row[-1], ea = row[2];
+            const int64_t r = (int64_t)zz * P + c;
+            const double na[7] = {xm.x, lo.x, we, xc.x, xc.y, up.x, xp.x}, nb[7] = {xm.y, lo.y, xc.x, xc.y, ea, up.y, xp.y};
+            double sa = 0.0, sb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                sa = mk_pen_term(sa, va[k], ma[k], na[k]);
+                sb = mk_pen_term(sb, vb[k], mb[k], nb[k]);
+            }
+            if constexpr (PROG) {
+                sa = mk_rowprog(A, sa, x, r, epi);
+                sb = mk_rowprog(A, sb, x, r + 1, epi);
+            }
+            if constexpr (ROWX) {
+                epi.row_x(r, sa, xc.x, acc);
+                epi.row_x(r + 1, sb, xc.y, acc);
+            } else {
+                if constexpr (MkHasPre<Epi>::value) epi.pre(r);
+                epi.row(r, sa, acc);
+                if constexpr (MkHasPre<Epi>::value) epi.pre(r + 1);
+                epi.row(r + 1, sb, acc);
+            }
+        };
+        const int zfull = z0 + ((z1 - z0) / R) * R;          // planes of the pipelined rounds; the rest one by one below
+        if (zfull > z0) {
+#pragma unroll
+            for (int d = 0; d < R - 1; ++d) {                 // (issue order = consumption order; slot R - 1 is loaded by step 0)
+                ring[d] = plane(z0 - 1 + d);
+                if (d < H) halo(z0 + d, d);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // one full wait at entry: the loop header's wait count is the stricter of the entry edge and the back edge,
+            // and the entry edge as the compiler models it would drain the pipeline on every round
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+            int z = z0;
+            do {
+#pragma unroll
+                for (int d = 0; d < R; ++d) {
+                    const int zz = z + d;
+                    step(zz, (d & 1) * BUF, ring[d], ring[(d + 1) % R], ring[(d + 2) % R], hreg[d % H], ereg[d % H], pidr[d % H],
+                         [&]() {
+                             __builtin_amdgcn_sched_barrier(0);   // (the slots' last uses stay ABOVE their reloads)
+                             ring[(d + R - 1) % R] = plane(zz + R - 2);   // the slot of plane zz - 2: dead since the last step
+                             halo(zz + H, d % H);
+                         });
+                }
+                z += R;
+            } while (z < zfull);
+        }
+        for (int zz = zfull; zz < z1; ++zz) {                 // (<= R - 1 planes of the last chunk when nz is not a multiple of R)
+            const mk_d2 xm = plane(zz - 1), xc = plane(zz), xp = plane(zz + 1);
+            halo(zz, 0);
+            step(zz, ((zz - zfull) & 1) * BUF, xm, xc, xp, hreg[0], ereg[0], pidr[0], [] {});
+        }
+        __syncthreads();                                     // the next item's first plane image overwrites this LDS
+    }
+}

@@ -1,0 +1,170 @@
+"""Storage format 9 (csrc/mk_spmv_fmt9.h): z-marching bricks for 7-point-class matrices -- every column offset in
+{0, +-1, +-L, +-P}, L % 128 == 0, P % 4L == 0, <= 256 distinct values.  The product must be BIT-identical to the oracle's
+scalar left-to-right CSR loop, the fused dots to the oracle run in the brick march's summation order (oracle/gpu_order.py
+`pencil`), for every loop that launches a product kernel; matrices outside the class must degrade to the windowed formats."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import csr_ref, gpu_order, krylov_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def fmt_of(op):
+    from pykrylov_amd import _lib
+    fmt = ctypes.c_int32()
+    _lib.check(_lib.init().mk_csr_format_info(op.handle, ctypes.byref(fmt), None, None, None, None))
+    return fmt.value
+
+
+def pencil_info(op):
+    from pykrylov_amd import _lib
+    sl, sp = ctypes.c_int64(), ctypes.c_int64()
+    nz, zc, ch, npat = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(_lib.init().mk_csr_pencil_info(op.handle, ctypes.byref(sl), ctypes.byref(sp), ctypes.byref(nz), ctypes.byref(zc),
+                                              ctypes.byref(ch), ctypes.byref(npat)))
+    return dict(L=sl.value, P=sp.value, planes=nz.value, zc=zc.value, chunks=ch.value, patterns=npat.value)
+
+
+def op9(A, symmetric=False):
+    from pykrylov_amd import CsrOperator, _lib
+    op = CsrOperator(A.indptr, A.indices, A.data, A.shape, symmetric=symmetric)
+    _lib.check(_lib.init().mk_csr_set_format(op.handle, 9))
+    return op
+
+
+def banded7(n, L, P, rng, values=(-1.0, 6.0, 0.5, -0.0, 2.0 ** -1060), combos=40, drop=0.0):
+    """Any band matrix of the class: offsets {0, +-1, +-L, +-P} wherever the column exists (no grid geometry: the +-1
+    entries cross line ends); a row follows one of `combos` random (presence mask, value per offset) combinations -- the
+    diagonal always present, the other offsets dropped with probability `drop` -- with values from a small set (zero,
+    negative zero and a denormal included)."""
+    offs = np.array([-P, -L, -1, 0, 1, L, P])
+    mask = rng.random((combos, 7)) >= drop
+    mask[:, 3] = True
+    vidx = rng.integers(0, len(values), size=(combos, 7))
+    which = rng.integers(0, combos, size=n)
+    r = np.repeat(np.arange(n), 7)
+    k = np.tile(np.arange(7), n)
+    c = r + offs[k]
+    keep = mask[which[r], k] & (c >= 0) & (c < n)
+    vals = np.asarray(values)[vidx[which[r], k]]
+    return csr_ref.from_coo(r[keep], c[keep], vals[keep], (n, n))
+
+
+GRIDS = [(128, 4, 2), (128, 8, 9), (256, 4, 13), (128, 12, 31), (384, 8, 6), (256, 16, 24)]
+
+
+@pytest.mark.parametrize("dims", GRIDS)
+def test_poisson3d_product_bit_exact(dims):
+    A = csr_ref.poisson3d(*dims)
+    op = op9(A)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(A.shape[1])
+    y = op * x
+    assert fmt_of(op) == 9
+    info = pencil_info(op)
+    assert (info["L"], info["P"], info["planes"]) == (dims[0], dims[0] * dims[1], dims[2]) and info["patterns"] <= 27
+    assert info["zc"] % 6 == 0 or info["zc"] % 2 == 0
+    assert np.array_equal(y, A.matvec(x))
+    x[::7] = 0.0
+    x[5::11] *= 1e300
+    assert np.array_equal(op * x, A.matvec(x))
+
+
+@pytest.mark.parametrize("n,L,P,drop", [(128 * 4 * 7, 128, 512, 0.0), (256 * 8 * 5, 256, 2048, 0.3), (128 * 8 * 20, 128, 1024, 0.6)])
+def test_generic_band_matrix_bit_exact(n, L, P, drop):
+    """No grid geometry: +-1 entries across line ends, rows with any subset of the seven offsets, zeros / negative zero /
+    denormals among the values, and x with an infinity next to entries a row does not have (a candidate the row has no
+    entry for must not reach the sum)."""
+    rng = np.random.default_rng(n)
+    A = banded7(n, L, P, rng, drop=drop)
+    op = op9(A)
+    x = rng.standard_normal(n)
+    y = op * x
+    assert fmt_of(op) == 9, pencil_info(op)
+    assert np.array_equal(y, A.matvec(x))
+    assert np.array_equal(np.signbit(y), np.signbit(A.matvec(x)))
+    if drop > 0:
+        # an infinity in x reaches exactly the rows that have an entry in its column
+        j = int(rng.integers(P, n - P))
+        x[j] = np.inf
+        with np.errstate(invalid="ignore"):
+            ref = A.matvec(x)
+        got = op * x
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+        fin = np.isfinite(ref)
+        assert np.array_equal(got[fin], ref[fin])
+
+
+def test_matrices_outside_the_class_degrade():
+    from pykrylov_amd import CsrOperator, _lib
+    rng = np.random.default_rng(1)
+    for A in (csr_ref.poisson3d(100, 8, 8),                   # L = 100: not a multiple of 128
+              csr_ref.poisson2d(256),                         # no plane stride
+              csr_ref.poisson3d_varcoef(128, 8, 8),           # > 256 distinct values
+              csr_ref.stencil27(128, 8, 4)):                  # 27 offsets
+        op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
+        _lib.check(_lib.init().mk_csr_set_format(op.handle, 9))
+        x = rng.standard_normal(A.shape[1])
+        assert np.array_equal(op * x, A.matvec(x))
+        assert fmt_of(op) != 9 and pencil_info(op)["L"] == 0
+
+
+@pytest.mark.parametrize("dims", [(128, 8, 9), (256, 8, 26)])
+def test_cg_bit_exact_in_brick_order(dims):
+    """CG with its <p, Ap> fused into the brick march: history, iterate and matvec count equal the oracle run with the
+    device's summation order (pencil order for the fused dot, stream order for the others), bit for bit."""
+    from pykrylov_amd import CG
+    A = csr_ref.poisson3d(*dims)
+    op = op9(A, symmetric=True)
+    rhs = A.matvec(np.ones(A.shape[0]))
+    s = CG(op)
+    s.solve(rhs)
+    assert fmt_of(op) == 9
+    geo = gpu_order.launch_geometry(op)
+    assert geo[1][0] == "pencil"
+    dots = gpu_order.GpuDots(A.shape[0], gpu_order.SPMV_SITES["cg"], geometry=geo)
+    ref = krylov_ref.cg(A, rhs, red=krylov_ref.Reductions(dots))
+    assert s.nMatvec == ref["nMatvec"]
+    assert np.array_equal(np.array(s.residHistory), ref["residHistory"])
+    assert np.array_equal(s.x, ref["x"])
+
+
+def test_minres_and_bicgstab_on_format_9():
+    """Epilogues with an on-the-fly input scaling (MINRES' v = y / beta through `xin`) and with several fused dots
+    (BiCGSTAB) run on the brick march: bit-exact against the oracle in the device's order."""
+    from pykrylov_amd import Minres, BiCGSTAB
+    A = csr_ref.poisson3d(128, 8, 12)
+    n = A.shape[0]
+    rhs = A.matvec(np.ones(n))
+    op = op9(A, symmetric=True)
+    geo = gpu_order.launch_geometry(op)
+    m = Minres(op)
+    m.solve(rhs, show=False, check=False, shift=1.5, etol=0.0, rtol=1e-10, itnlim=60)
+    ref = krylov_ref.minres(A, rhs, shift=1.5, etol=0.0, rtol=1e-10, itnlim=60, check=False,
+                            red=krylov_ref.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["minres"], geometry=geo)))
+    assert fmt_of(op) == 9
+    assert m.itn == ref["itn"] and np.array_equal(np.array(m.residHistory), np.array(ref["residHistory"]))
+    assert np.array_equal(m.x, ref["x"])
+    b = BiCGSTAB(op)
+    b.solve(rhs, matvec_max=40)
+    refb = krylov_ref.bicgstab(A, rhs, matvec_max=40,
+                               red=krylov_ref.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["bicgstab"], geometry=geo)))
+    assert b.nMatvec == refb["nMatvec"] and b.residNorm == refb["residNorm"] and np.array_equal(b.x, refb["x"])
+
+
+def test_composed_operator_on_format_9():
+    """Row programs (alpha A + D x) ride on the brick march through mk_rowprog."""
+    from pykrylov_amd.linop import DiagonalOperator
+    A = csr_ref.poisson3d(128, 4, 7)
+    n = A.shape[0]
+    op = op9(A)
+    rng = np.random.default_rng(2)
+    d = rng.standard_normal(n)
+    x = rng.standard_normal(n)
+    comp = 2.5 * op + DiagonalOperator(d)
+    y = comp * x
+    assert fmt_of(op) == 9
+    assert np.array_equal(y, 2.5 * A.matvec(x) + d * x)
