@@ -651,8 +651,8 @@ extern "C" int mk_csr_download(const mk_csr *A, int32_t *indptr, int32_t *indice
     MK_REQUIRE_INIT();
     MK_ARG(A != nullptr);
     if (A->comp_kind || A->host_fn) return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_download: the operand has no matrix of its own");
-    if (A->nnz > 0 && (!A->d_indices || !A->d_data))         // (MK_FREE_CSR experiment: the CSR arrays were given back)
-        return mk_fail(MK_ERR_STATE, "%s: the CSR arrays of this matrix were released (MK_FREE_CSR)", __func__);
+    if (A->nnz > 0 && (!A->d_indices || !A->d_data))         // (defensive: a matrix whose CSR arrays are gone cannot be read back)
+        return mk_fail(MK_ERR_STATE, "%s: the CSR arrays of this matrix were released", __func__);
     hipStream_t st = mk_ctx().stream;
     if (indptr)
         MK_HIP(hipMemcpyAsync(indptr, A->d_indptr, sizeof(int32_t) * (size_t)(A->nrows + 1), hipMemcpyDeviceToHost, st));
@@ -671,8 +671,8 @@ extern "C" int mk_csr_download_rows(const mk_csr *A, int64_t row_begin, int64_t 
     MK_ARG(row_begin >= 0 && row_begin <= row_end && row_end <= A->nrows);
     if (A->comp_kind || A->host_fn)
         return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_download_rows: the operand has no matrix of its own");
-    if (A->nnz > 0 && (!A->d_indices || !A->d_data))         // (MK_FREE_CSR experiment: the CSR arrays were given back)
-        return mk_fail(MK_ERR_STATE, "%s: the CSR arrays of this matrix were released (MK_FREE_CSR)", __func__);
+    if (A->nnz > 0 && (!A->d_indices || !A->d_data))         // (defensive: a matrix whose CSR arrays are gone cannot be read back)
+        return mk_fail(MK_ERR_STATE, "%s: the CSR arrays of this matrix were released", __func__);
     hipStream_t st = mk_ctx().stream;
     int32_t ends[2] = {0, 0};
     MK_HIP(hipMemcpyAsync(&ends[0], A->d_indptr + row_begin, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1090,8 +1090,8 @@ extern "C" int mk_csr_transpose(const mk_csr *A, mk_csr **out) {
     MK_ARG(A && out);
     if (A->comp_kind || A->host_fn)
         return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_transpose: the operand has no matrix of its own; transpose its parts");
-    if (A->nnz > 0 && (!A->d_indices || !A->d_data))         // (MK_FREE_CSR experiment: the CSR arrays were given back)
-        return mk_fail(MK_ERR_STATE, "%s: the CSR arrays of this matrix were released (MK_FREE_CSR)", __func__);
+    if (A->nnz > 0 && (!A->d_indices || !A->d_data))         // (defensive: a matrix whose CSR arrays are gone cannot be read back)
+        return mk_fail(MK_ERR_STATE, "%s: the CSR arrays of this matrix were released", __func__);
     mk_csr *B = nullptr;
     int32_t *cursor = nullptr;
     int rc = mk_csr_alloc(A->ncols, A->nrows, A->nnz, &B);

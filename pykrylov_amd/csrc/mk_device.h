@@ -587,7 +587,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : (FMT == 11 ? 2 : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : (FMT == 11 ? MK_PEN_OCC : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)

@@ -574,6 +574,15 @@ int cblocks_build(const mk_csr *A, int64_t blk_override = 0) {
     const int64_t xbytes = 8 * A->x_len();
     if (xbytes <= 2 * blk) return MK_OK;
     int K = (int)((xbytes + blk - 1) / blk);
+    if (automatic) {
+        //  the automatic choice was measured on x slices that fit an L2: beyond CB_MAX blocks of this size a clamped
+        // K would make the slices larger than that again, and the second copy of the matrix (12 B per nonzero + K row-pointer
+        // arrays) must fit comfortably beside everything else -- otherwise the matrix keeps its single launch
+        if (K > CB_MAX) return MK_OK;
+        size_t free_b = 0, total_b = 0;
+        const int64_t extra = 12 * A->nnz + (int64_t)K * 4 * (A->nrows + 1) + 8 * A->nrows;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || extra > (int64_t)(free_b / 4)) return MK_OK;
+    }
     if (K > CB_MAX) K = CB_MAX;
     int64_t bw = (A->x_len() + K - 1) / K;
     bw = (bw + 255) / 256 * 256;
@@ -619,9 +628,11 @@ int cblocks_build(const mk_csr *A, int64_t blk_override = 0) {
         bool all = true;
         for (size_t bi = 0; bi < P.cblocks.size(); ++bi) {
             mk_csr *B = P.cblocks[bi];
-            B->plan = MkPlan();
+            plan_free(B->plan);
             B->plan.built = true;
             if (resident_plan(B, B->plan, true) != MK_OK || B->plan.fmt != 3) all = false;
+            hipFree(B->plan.d_carry);                        // (a block never runs as a stepped pair product)
+            B->plan.d_carry = nullptr;
             // phases over the block's OWN slice of x (bw columns from b * bw), 1.5 MiB each: a slice larger than an L2's share
             // is walked in lockstep like a whole format-3 matrix
             const int64_t c0 = (int64_t)bi * bw;
@@ -634,13 +645,16 @@ int cblocks_build(const mk_csr *A, int64_t blk_override = 0) {
             B->plan.rt_c0 = (int)c0;
             B->plan.rt_reg = 0;
         }
-        if (!all && automatic && blk > ((int64_t)4 << 20)) {  // a tile of some block is too long for LDS: smaller blocks
+        if (!all && automatic) {
+            // a tile of some block is too long for LDS: smaller blocks once, if they still are at most CB_MAX; otherwise the
+            // matrix keeps its single launch (blocks on the gather path were measured slower than that: DESIGN.md 3.1-4)
             cblocks_drop(P);
-            return cblocks_build(A, -(blk / 2));
+            if (blk > ((int64_t)4 << 20) && (xbytes + blk / 2 - 1) / (blk / 2) <= CB_MAX) return cblocks_build(A, -(blk / 2));
+            return MK_OK;
         }
         if (!all)
             for (mk_csr *B : P.cblocks) {
-                B->plan = MkPlan();
+                plan_free(B->plan);                          // (no leak of what resident_plan allocated)
                 B->plan.built = true;
             }
     }
@@ -1180,12 +1194,14 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced) {
     P.pen_nz = (int)(A->nrows / PP);
     P.pen_bx = (int)(L / 128);
     P.pen_bpp = (int)(L / 128 * (PP / (4 * L)));
-    // chunks: about MK_MAXP (brick, chunk) items -- eight resident workgroups per CU -- of at least 8 planes each, a
-    // multiple of the ring depth so that only the matrix's last chunk has planes left over
+    // chunks: the kernel keeps two workgroups per CU resident (its register ring), so 512 (brick, chunk) items fill the
+    // chip in one round; more chunks only add pipeline fills and re-read two planes per chunk start (512^3, tools/
+    // r05_pencil_variants.sh: 4 chunks of 132 planes 441 us, 8 of 66 436, one of 516 421).  At least 6 planes per chunk, a
+    // multiple of the ring depth so that only the matrix's last chunk has planes left over.
     static const char *env_zc = getenv("MK_PENCIL_ZC");
-    int chunks = (MK_MAXP + P.pen_bpp - 1) / P.pen_bpp;
+    int chunks = (512 + P.pen_bpp - 1) / P.pen_bpp;
     int zc = (P.pen_nz + chunks - 1) / chunks;
-    zc = zc < 8 ? 8 : zc;
+    zc = zc < MK_PEN_R ? MK_PEN_R : zc;
     if (env_zc && atoi(env_zc) > 0) zc = atoi(env_zc);
     zc = (zc + MK_PEN_R - 1) / MK_PEN_R * MK_PEN_R;
     P.pen_zc = zc;
@@ -1234,18 +1250,6 @@ int plan_build(const mk_csr *A) {
         if (rc < 0) return fail("value dictionary");
         if (rc == 0) {                                       // too many distinct values: windows with raw values
             if (want >= 5) pattern_plan(A, P, true);         // ... in pattern order when the rows follow patterns (fmt 5)
-            if (P.fmt == 5 && P.covered == A->ntiles && getenv("MK_FREE_CSR") && atoi(getenv("MK_FREE_CSR")) > 0 &&
-                !A->alias && A->ex.mode < 0) {
-                // EXPERIMENT (placement): no product of a fully covered format-5 matrix reads the CSR
-                // values or columns again -- give their 12 bytes per nonzero back before the solver allocates its vectors.
-                // (download / transpose / partitioning of such a matrix fail afterwards: measurement only.)
-                mk_csr *M = const_cast<mk_csr *>(A);
-                hipStreamSynchronize(mk_ctx().stream);
-                hipFree(M->d_indices);
-                hipFree(M->d_data);
-                M->d_indices = nullptr;
-                M->d_data = nullptr;
-            }
             return MK_OK;
         }
         P.fmt = 2;

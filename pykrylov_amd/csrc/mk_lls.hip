@@ -1248,6 +1248,7 @@ struct LlsSolver : mk_solver {
         res->aux[0] = o[O_R1NORM];
         res->aux[1] = o[O_NORMR];
         res->aux[2] = o[O_NORMAR];
+        res->aux[3] = h_scal[S_BLK + (int)(it & 1) * BLK + B_XNRG2];      // xNrgNorm2 of the last pass (lsqr.py:311, the `show` summary)
         const int is = res->istop;
         res->converged = (is == 1 || is == 2 || is == 4 || is == 5 || is == 8) ? 1 : 0;     // `optimal`, lsqr.py:442
         // the gates leave itn one ahead when they admit a pass that the host never enqueued; report completed passes

@@ -17,6 +17,7 @@ namespace {
 constexpr int MAXWIN = 16;
 // fixed scalars
 enum { S_BETA1 = 0, S_ALFA = 1, S_RNORM = 2, S_ARNORM = 3, S_ANORM = 4, S_ACOND = 5, S_YNORM = 6, S_ISTOP = 7,
+       S_TEST2 = 8, S_GBAR = 9,               // (what the reference's `show` table prints besides: minres.py:372-376)
        S_BLK = 16, BLK = 48 };
 // ping-pong block: read from scal[S_BLK + par*BLK + k], written to the other parity by K3's lead lane
 enum { B_OLDB = 0, B_BETA, B_DBAR, B_EPSLN, B_PHIBAR, B_RHS1, B_RHS2, B_TNORM2, B_YNORM2, B_CS, B_SN, B_GMAX, B_GMIN,
@@ -250,6 +251,8 @@ struct OpK3 {
             scal[S_ACOND] = Acond;
             scal[S_YNORM] = ynorm;
             scal[S_ISTOP] = (double)istop;
+            scal[S_TEST2] = test2;
+            scal[S_GBAR] = gbar;
             const int64_t h = st->hist_len % MK_HIST_RING;
             hist[h] = rnorm;                                                  // minres.py:336
             hist[MK_HIST_RING + h] = derr_ratio;                              // minres.py:308
@@ -396,6 +399,8 @@ struct MinresSolver : mk_solver {
         res->Anorm = h_scal[S_ANORM];
         res->Acond = h_scal[S_ACOND];
         res->ynorm = h_scal[S_YNORM];
+        res->aux[0] = h_scal[S_TEST2];                    // test2 = root / Anorm and gbar of the last pass (minres.py:374-375)
+        res->aux[1] = h_scal[S_GBAR];
         const int is = res->istop;
         res->converged = (is == 1 || is == 2 || is == 3 || is == 4 || is == 10) ? 1 : 0;   // minres.py:395
         return MK_OK;

@@ -293,8 +293,9 @@ extern "C" int mk_solver_create(const mk_csr *A, const mk_params *params, mk_sol
 extern "C" int mk_solver_set_transpose(mk_solver *s, const mk_csr *At) {
     MK_ARG(s && At);
     MK_ARG(At->nrows == s->A->ncols && At->ncols == s->A->nrows && At->nnz == s->A->nnz);
+    if (s->At == At) return MK_OK;                           // (re-setting the same operator must not release it)
+    At->dependents += 1;                                     // take the new reference first, then drop the old one
     if (s->At) mk_release_operand(s->At);
-    At->dependents += 1;
     s->At = At;
     return MK_OK;
 }

@@ -47,8 +47,17 @@ __device__ __forceinline__ double mk_pen_term(double s, double v, unsigned m, do
     return s + v * __hiloint2double((int)((unsigned)__double2hiint(xk) & m), __double2loint(xk));
 }
 
-constexpr int MK_PEN_R = 6;                                  // ring slots = unroll factor (own rows: prefetch depth R - 3 planes)
-constexpr int MK_PEN_H = 3;                                  // slots of the halo / pattern-byte rings (depth H planes; R % H == 0)
+#ifndef MK_PEN_R_DEF
+#define MK_PEN_R_DEF 6
+#endif
+#ifndef MK_PEN_H_DEF
+#define MK_PEN_H_DEF 3
+#endif
+#ifndef MK_PEN_OCC
+#define MK_PEN_OCC 2                                         // workgroups per CU the register budget is cut for (tools/variants)
+#endif
+constexpr int MK_PEN_R = MK_PEN_R_DEF;                                  // ring slots = unroll factor (own rows: prefetch depth R - 3 planes)
+constexpr int MK_PEN_H = MK_PEN_H_DEF;                                  // slots of the halo / pattern-byte rings (depth H planes; R % H == 0)
 constexpr int MK_PEN_RS = 132;                               // LDS row: [0] pad, [1] west edge, [2..129] rows, [130] east edge, [131] pad
 constexpr int MK_PEN_LDS = 3 * 6 * MK_PEN_RS + MK_BLOCK;     // doubles: two plane images of 6 rows + the dump rows (lanes without an
                                                              // edge row store there, at the same buffer offset as the others)

@@ -162,7 +162,9 @@ class DeviceRun(object):
         if draws is not None:
             self.placement_draws = int(draws)
         n = getattr(op, 'local_size', None) or (op.shape[0] if transpose is not None else op.shape[1])
-        self.n = n
+        self.n = n                                           # entries of rhs / guess
+        #  entries of the solution: ncols(A) for the least-squares kinds (CRAIG-MR's lives in m-space)
+        self.n_x = n if (transpose is None or kind == _lib.MK_CRAIGMR) else op.shape[1]
         # rhs / guess: host arrays (copied to HBM) or DeviceArray objects already resident there
         self._borrowed = [b for b in (rhs, guess) if isinstance(b, _lib.DeviceArray)]
         self.d_rhs = rhs if isinstance(rhs, _lib.DeviceArray) else \
@@ -347,12 +349,20 @@ class DeviceRun(object):
     def x(self):
         p = ctypes.c_void_p()
         _lib.check(self.lib.mk_solver_x(self.handle, ctypes.byref(p)))
-        return _lib.download(p.value, self.n)
+        return _lib.download(p.value, self.n_x)
 
     def vector(self, index):
         p, ln = ctypes.c_void_p(), ctypes.c_int64()
         _lib.check(self.lib.mk_solver_vector(self.handle, index, ctypes.byref(p), ctypes.byref(ln)))
         return _lib.download(p.value, ln.value)
+
+    def x_first(self):
+        """x[0] of the current iterate (eight bytes from the device: what the reference's `show` tables print)."""
+        px = ctypes.c_void_p()
+        _lib.check(self.lib.mk_solver_x(self.handle, ctypes.byref(px)))
+        v = ctypes.c_double()
+        _lib.check(self.lib.mk_memcpy_d2h(ctypes.byref(v), px.value, 8))
+        return v.value
 
     def history(self):
         n = int(self.result.hist_len)

@@ -39,6 +39,12 @@ class _LlsBase(KrylovMethod):
                     'The iteration limit has been reached                      ',
                     'The truncated direct error is small enough, given etol    ']
 
+    def _trnc_dir_err(self, res):
+        """trncDirErr of the last pass for the `show` summaries: the window's ratio trnc / sqrt(xNrgNorm2) the device
+        records (lsqr.py:310-318), times sqrt(xNrgNorm2); 0 while the window is not full (the reference's initial value)."""
+        d = self.dir_errors_window
+        return float(d[-1]) * float(np.sqrt(res.aux[3])) if len(d) and np.isfinite(d[-1]) else 0.0
+
     def _lls_diag(self, P, size, which):
         """M / N for the device loop: the fp64 diagonal of an operator that exposes one (DiagonalOperator,
         linop.py:473-516; applied inside the kernels), else the callable itself -- the reference applies them as
@@ -124,13 +130,26 @@ class _LlsBase(KrylovMethod):
                 return _lib.download(px.value, nx)
             if store_iterates:
                 self.iterates.append(get_x())
+            table = kwargs.get('_table')                     # `show=True`: the reference's iteration log (see _ShowTable)
+
+            def x_first():
+                px = ctypes.c_void_p()
+                _lib.check(lib.mk_solver_x(handle, ctypes.byref(px)))
+                v0 = ctypes.c_double()
+                _lib.check(lib.mk_memcpy_d2h(ctypes.byref(v0), px.value, 8))
+                return v0.value
+            if table is not None:
+                table.start(res, x_first())
             while not res.halted:
                 done = ctypes.c_int64()
-                chk(lib.mk_solver_iterate(handle, 1 if store_iterates else (1 << 20), ctypes.byref(done)))
+                chk(lib.mk_solver_iterate(handle, 1 if (store_iterates or table is not None) else (1 << 20),
+                                          ctypes.byref(done)))
                 last_itn = int(res.itn)
                 _lib.check(lib.mk_solver_finish(handle, ctypes.byref(res)))
                 if store_iterates and int(res.itn) > last_itn:
                     self.iterates.append(get_x())
+                if table is not None:
+                    table.after_pass(res, x_first() if int(res.itn) > last_itn else None, int(res.itn) > last_itn)
             x = get_x()
             hist = np.empty(int(res.hist_len))
             derr = np.empty(int(res.hist_len))
@@ -155,6 +174,83 @@ class _LlsBase(KrylovMethod):
         return res, x, r, itn
 
 
+class _ShowTable(object):
+    """The iteration log the reference prints with ``show=True`` (lsqr.py:222-234,394-411; lsmr.py:288-296,450-473), from
+    the device loop stepped one pass at a time.  One quantity of a row is only settled by the NEXT pass's gate kernel
+    (LSQR: cond(A), lsqr.py:338; LSMR: norm(x) for the print rule, lsmr.py:415), so row k is printed after pass k + 1 --
+    or after the halting gate -- from the snapshot taken after pass k.  Same print rule, same formats; costs a device
+    round trip per iteration, like every `show` mode: a debugging aid."""
+
+    def __init__(self, kind, n, itnlim, atol, btol, ctol=0.0, pfreq=20):
+        self.kind, self.n, self.itnlim, self.atol, self.btol, self.ctol = kind, n, itnlim, atol, btol, ctol
+        self.pending = None
+        self.pfreq, self.pcount = pfreq, 0
+        self.lsqr = kind == _lib.MK_LSQR
+        self.head = ('   Itn      x(1)       r1norm     r2norm ' + ' Compatible   LS      Norm A   Cond A') if self.lsqr else \
+            ('   itn      x(1)       norm r    norm Ar ' + ' compatible   LS      norm A   cond A')
+
+    @staticmethod
+    def _snap(res, x0):
+        return dict(itn=int(res.itn), x0=x0, r1=res.aux[0], r2=res.residNorm, normr=res.aux[1], normar=res.aux[2],
+                    Anorm=res.Anorm, Acond=res.Acond, Arnorm=res.Arnorm, xnorm=res.xnorm, bnorm=res.residNorm0,
+                    istop=int(res.istop))
+
+    def start(self, res, x0):
+        s = self._snap(res, x0)
+        if res.halted:                                       # x = 0 is the solution: the reference prints msg[0] and returns
+            return
+        print(' ')
+        print(self.head)
+        beta = s['bnorm']
+        if self.lsqr:                                        # lsqr.py:229-234 (test2 = alpha / beta; Arnorm = alpha beta)
+            print('%6g %12.5e' % (0, x0) + ' %10.3e %10.3e' % (s['r1'], s['r2']) + '  %8.1e %8.1e' % (1.0, s['Arnorm'] / beta / beta))
+        else:                                                # lsmr.py:291-296 (normA = alpha at this point)
+            print(''.join(['%6g %12.5e' % (0, x0), ' %10.3e %10.3e' % (s['normr'], s['normar']),
+                           '  %8.1e %8.1e' % (1, s['Anorm'] / beta)]))
+
+    def _row(self, s, late):
+        itn, bnorm = s['itn'], s['bnorm']
+        if self.lsqr:
+            Acond = late['Acond']                            # settled by the gate that followed
+            test1 = s['r2'] / bnorm
+            test2 = np.inf if (s['Anorm'] == 0. or s['r2'] == 0.) else s['Arnorm'] / (s['Anorm'] * s['r2'])
+            test3 = np.inf if Acond == 0.0 else 1.0 / Acond
+            rtol = self.btol + self.atol * s['Anorm'] * s['xnorm'] / bnorm
+            prnt = (self.n <= 40 or itn <= 10 or itn >= self.itnlim - 10 or itn % 10 == 0 or test3 <= 2 * 0.0
+                    or test2 <= 10 * self.atol or test1 <= 10 * rtol or late['istop'] != 0)     # (ctol stays 0: lsqr.py:161-163)
+            if prnt:
+                print('%6g %12.5e' % (itn, s['x0']) + ' %10.3e %10.3e' % (s['r1'], s['r2']) + '  %8.1e %8.1e' % (test1, test2)
+                      + ' %8.1e %8.1e' % (s['Anorm'], Acond))
+        else:
+            normx = late['xnorm']
+            test1 = s['normr'] / bnorm
+            test2 = s['normar'] / (s['Anorm'] * s['normr'])
+            test3 = 1 / s['Acond']
+            rtol = self.btol + self.atol * s['Anorm'] * normx / bnorm
+            prnt = (self.n <= 40 or itn <= 10 or itn >= self.itnlim - 10 or itn % 10 == 0 or test3 <= 1.1 * self.ctol
+                    or test2 <= 1.1 * self.atol or test1 <= 1.1 * rtol or late['istop'] != 0)
+            if prnt:
+                if self.pcount >= self.pfreq:
+                    self.pcount = 0
+                    print(' ')
+                    print(self.head)
+                self.pcount += 1
+                print(''.join(['%6g %12.5e' % (itn, s['x0']), ' %10.3e %10.3e' % (s['normr'], s['normar']),
+                               '  %8.1e %8.1e' % (test1, test2), ' %8.1e %8.1e' % (s['Anorm'], s['Acond'])]))
+
+    def after_pass(self, res, x0, advanced):
+        now = self._snap(res, x0)
+        if self.pending is not None and (advanced or res.halted):
+            late = dict(now, istop=now['istop'] if res.halted and not advanced else 0)
+            self._row(self.pending, late)
+            self.pending = None
+        if advanced:
+            self.pending = now
+            if res.halted:                                   # (a pass and its halting gate in one call)
+                self._row(now, now)
+                self.pending = None
+
+
 class LSQRFramework(_LlsBase):
     """LSQR for ``A x = b`` / ``min |b - A x|`` / damped least squares (lsqr.py:26-453).
 
@@ -169,16 +265,30 @@ class LSQRFramework(_LlsBase):
         if itnlim == 0:
             itnlim = 3 * n
         kwargs['wantvar'] = wantvar
+        if show:                                             # lsqr.py:168-175
+            print(' ')
+            print('LSQR            Least-squares solution of  Ax = b')
+            print('The matrix A has %8d rows and %8d cols' % (m, n))
+            print('damp = %20.14e     wantvar = %-5s' % (damp, repr(wantvar)))
+            print('atol = %8.2e                 conlim = %8.2e' % (atol, conlim))
+            print('btol = %8.2e                 itnlim = %8g' % (btol, itnlim))
+            kwargs['_table'] = _ShowTable(self.kind, n, itnlim, atol, btol)
         res, x, _, itn = self._run(rhs, itnlim, damp, atol, btol, conlim, M, N, kwargs)
         if kwargs.get('store_resids', False):
             self.resids = [np.float64(res.residNorm0)] + [np.float64(h) for h in self._hist]
         istop = int(res.istop)
-        if show:
+        if show and istop == 0:
+            print(self.msg[0])                               # lsqr.py:215
+        elif show:                                           # lsqr.py:418-434
             print(' ')
             print('LSQR finished')
             print(self.msg[istop])
-            print('istop =%8g   r1norm =%8.1e   Anorm =%8.1e   Arnorm =%8.1e' % (istop, res.aux[0], res.Anorm, res.Arnorm))
-            print('itn   =%8g   r2norm =%8.1e   Acond =%8.1e   xnorm  =%8.1e' % (itn, res.residNorm, res.Acond, res.xnorm))
+            print(' ')
+            print('istop =%8g   r1norm =%8.1e' % (istop, res.aux[0]) + '   ' + 'Anorm =%8.1e   Arnorm =%8.1e' % (res.Anorm, res.Arnorm))
+            print('itn   =%8g   r2norm =%8.1e' % (itn, res.residNorm) + '   ' + 'Acond =%8.1e   xnorm  =%8.1e' % (res.Acond, res.xnorm))
+            print('                  bnorm  =%8.1e' % res.residNorm0)
+            print('xNrgNorm2 = %7.1e   trnDirErr = %7.1e' % (res.aux[3], self._trnc_dir_err(res)))
+            print(' ')
         self.status = _STATUS[istop]
         self.optimal = istop in [1, 2, 4, 5, 8]
         self.x = self.bestSolution = x
@@ -206,16 +316,27 @@ class LSMRFramework(_LlsBase):
         m, n = getattr(self.A, 'global_shape', self.A.shape)    # (row blocks on several GPUs: the same limit everywhere)
         if itnlim is None:
             itnlim = min([m, n])
+        if show:                                             # lsmr.py:196-206
+            print(' ')
+            print('LSMR            Least-squares solution of  Ax = b')
+            print('The matrix A has %8g rows  and %8g cols' % (m, n))
+            print('damp = %20.14e' % (damp))
+            print('atol = %8.2e                 conlim = %8.2e' % (atol, conlim))
+            print('btol = %8.2e               itnlim = %8g' % (btol, itnlim))
+            kwargs['_table'] = _ShowTable(self.kind, n, itnlim, atol, btol, ctol=(1.0 / conlim if conlim > 0 else 0.0))
         res, x, _, itn = self._run(b, itnlim, damp, atol, btol, conlim, M, N, kwargs)
         istop = int(res.istop)
         if kwargs.get('store_resids', False):
             self.resids = [np.float64(res.residNorm0)] + [np.float64(h) for h in self._hist]
-        if show:
+        if show and istop == 0 and itn == 0:
+            print(self.msg[0])                               # lsmr.py:286
+        elif show:                                           # lsmr.py:479-489
             print(' ')
             print('LSMR finished')
             print(self.msg[istop])
-            print('istop =%8g    normr =%8.1e    normA =%8.1e    normAr =%8.1e' % (istop, res.aux[1], res.Anorm, res.aux[2]))
-            print('itn   =%8g    condA =%8.1e    normx =%8.1e' % (itn, res.Acond, res.xnorm))
+            print('istop =%8g    normr =%8.1e' % (istop, res.aux[1]), '    normA =%8.1e    normAr =%8.1e' % (res.Anorm, res.aux[2]))
+            print('itn   =%8g    condA =%8.1e' % (itn, res.Acond), '    normx =%8.1e' % (res.xnorm))
+            print('Estimated energy norm of x: %7.1e' % np.sqrt(res.aux[3]))
         self.x = x
         return (x, istop, itn, np.float64(res.aux[1]), np.float64(res.aux[2]), np.float64(res.Anorm),
                 np.float64(res.Acond), np.float64(res.xnorm))
@@ -232,8 +353,27 @@ class CRAIGFramework(_LlsBase):
         if itnlim == 0:
             itnlim = 3 * n
         kwargs['wantvar'] = wantvar
+        if show:                                             # craig.py:193-200 (its iteration log is commented out there)
+            print(' ')
+            print('CRAIG           Least-squares solution of  Ax = b')
+            print('The matrix A has %8d rows and %8d cols' % (m, n))
+            print('damp = %20.14e     wantvar = %-5s' % (damp, repr(wantvar)))
+            print('atol = %8.2e                 conlim = %8.2e' % (atol, conlim))
+            print('btol = %8.2e                 itnlim = %8g' % (btol, itnlim))
         res, x, r, itn = self._run(rhs, itnlim, damp, atol, btol, conlim, M, N, kwargs)
         istop = int(res.istop)
+        if show and istop == 0:
+            print(self.msg[0])                               # craig.py:239
+        elif show:                                           # craig.py:483-499
+            print(' ')
+            print('CRAIG finished')
+            print(self.msg[istop])
+            print(' ')
+            print('istop =%8g   r1norm =%8.1e' % (istop, res.aux[0]))
+            print('itn   =%8g   r2norm =%8.1e' % (itn, res.residNorm))
+            print('                  bnorm  =%8.1e' % res.residNorm0)
+            print('xNrgNorm2 = %7.1e   trnDirErr = %7.1e' % (res.aux[3], self._trnc_dir_err(res)))
+            print(' ')
         self.dir_errors_d_window = self.dir_errors_window
         self.status = _STATUS[istop]
         self.optimal = istop in [1, 2, 4, 5, 8]

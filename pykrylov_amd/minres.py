@@ -36,8 +36,8 @@ class Minres(KrylovMethod):
         self.dir_errors_window = []
         self.iterates = []
         self.eps = machine_epsilon()
-        self.first = 'Enter MINRES.   '
-        self.last = 'Exit  MINRES.   '
+        self.first = 'Enter minres.   '
+        self.last = 'Exit  minres.   '
         self.msg = [' beta2 = 0.  If M = I, b and x are eigenvectors    ',
                     ' beta1 = 0.  The exact solution is  x = 0          ',
                     ' A solution to Ax = b was found, given rtol        ',
@@ -60,7 +60,10 @@ class Minres(KrylovMethod):
         :keywords:
             :precon:  preconditioner M^-1 given as a diagonal operator (`precon.diag`); must be positive definite
             :shift:   solve (A - shift I) x = b (default 0)
-            :show:    print a summary (default True, as in the reference)
+            :show:    print the reference's iteration log -- header, one row per printed iteration (minres.py:362-379:
+                      itn, x[0], test1, test2, Anorm, Acond, gbar / Anorm) and the exit summary (default True, as in
+                      the reference).  The rows are printed pass by pass, which costs one device round trip per
+                      iteration: a debugging aid, like the reference's.
             :check:   verify symmetry of A first (default True; 20 extra products on the operator)
             :itnlim:  iteration limit (default 5n)
             :rtol:    relative residual tolerance (default 1e-12)
@@ -81,8 +84,7 @@ class Minres(KrylovMethod):
         etol = kwargs.get('etol', 1.0e-6)
         store_iterates = kwargs.get('store_iterates', False)
         window = kwargs.get('window', 5)
-        if kwargs.get('store_resids', False):
-            raise NotImplementedError('Minres: store_resids keeps no vectors in the reference either (minres.py:128)')
+        kwargs.get('store_resids', False)      # read and ignored, exactly like the reference (minres.py:128)
 
         self.residHistory = []                 # MINRES resets its histories on every solve (minres.py:132-133)
         self.dir_errors_window = []
@@ -101,12 +103,33 @@ class Minres(KrylovMethod):
             res = run.finish()
             if check and not check_symmetric(A):                              # minres.py:186-190
                 symmetric_ok = False
-            elif store_iterates:
-                self.iterates.append(run.x())
+            elif store_iterates or show:
+                if store_iterates:
+                    self.iterates.append(run.x())
+                if show:                                                      # minres.py:210-214
+                    print(' ' * 2)
+                    print('   Itn     x[0]     Compatible    LS' + '       norm(A)  cond(A) gbar/|A|')
+                eps = np.finfo(np.double).eps
                 while not res.halted:
+                    last_itn = int(res.itn)
                     run.iterate(1)
                     res = run.finish()
-                    self.iterates.append(run.x())
+                    itn = int(res.itn)
+                    if itn == last_itn:
+                        continue
+                    if store_iterates:
+                        self.iterates.append(run.x())
+                    if show:                                                  # minres.py:362-383, same rule, same formats
+                        Anorm, Acond, ynorm, rnorm = res.Anorm, res.Acond, res.ynorm, res.residNorm
+                        epsx, epsr = Anorm * ynorm * eps, Anorm * ynorm * rtol
+                        test1, test2, gbar = rnorm / (Anorm * ynorm), res.aux[0], res.aux[1]
+                        prnt = (n <= 40 or itn <= 10 or itn >= itnlim - 10 or itn % 10 == 0 or rnorm <= 10 * epsx
+                                or rnorm <= 10 * epsr or Acond <= 1e-2 / eps or int(res.istop) != 0)
+                        if prnt:
+                            print('%6g %12.5e %10.3e' % (itn, run.x_first(), test1) + ' %10.3e' % test2
+                                  + ' %8.1e %8.1e %8.1e' % (Anorm, Acond, gbar / Anorm))
+                        if int(res.istop) <= 0 and itn % 10 == 0:
+                            print(' ')
             else:
                 while not res.halted:
                     run.iterate(1 << 20)

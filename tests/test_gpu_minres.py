@@ -86,7 +86,7 @@ def test_minres_defaults_stop_on_direct_error(golden, m, capsys):
     s = Minres(op_from(A, symmetric=True))
     s.solve(A.matvec(np.ones(m * m)), check=False)             # show defaults to True
     out = capsys.readouterr().out
-    assert "Enter MINRES" in out and "istop   =   10" in out
+    assert "Enter minres" in out and "istop   =   10" in out
     assert s.istop == int(d[k + "istop"]) == 10 and s.itn == int(d[k + "itn"]) and s.status == "direct error small"
     assert rel_hist_err(s.residHistory, d[k + "residHistory"]) <= TOL
     assert np.allclose(s.dir_errors_window, d[k + "dir_errors_window"], rtol=1e-9, atol=0)
