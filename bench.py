@@ -106,6 +106,8 @@ def _compact_roofline(r):
            "traffic": tb, "traffic_bytes": tb}
     if tb and r.get("bytes_per_launch"):
         out["traffic_ratio"] = sig(tb / float(r["bytes_per_launch"]), 4)
+    if r.get("fused_pass"):
+        out["fused_pass"] = True
     return out
 
 
@@ -864,6 +866,8 @@ def main():
             avg = ctypes.c_double()
             _lib.check(lib.mk_solver_time_spmv(run.handle, nl, ctypes.byref(avg)))
             timing["spmv_b2b_us"] = avg.value
+        fz = ctypes.c_int32()
+        _lib.check(lib.mk_solver_fused(run.handle, ctypes.byref(fz)))
         assert done == steps and done_w == warmup, (done, steps, done_w, warmup)
         assert np.isfinite(res.residNorm), "CG diverged"
         hist = run.history()
@@ -871,6 +875,7 @@ def main():
         info = dict(op_shape=op.shape, nnz=op.nnz, n_local=n_local, n_global=n_global, meta=meta, elapsed=elapsed,
                     timing=timing, resid_first=float(hist[0]), resid_last=float(hist[-1]), comm=comm,
                     fmt=format_info(lib, op), steps=steps, launches=nl, placement=dict(run.placement), parity=parity_info,
+                    fused=bool(fz.value),
                     residual={"first": float(hist[0]), "last": float(hist[-1]), "recurrence": float(hist[-1]), "true": true_resid,
                               "rel_gap": rel_gap, "passes": int(res.nMatvec),
                               "note": "true = ||b - A x_k|| recomputed from the iterate after the timed region with the "
@@ -900,7 +905,10 @@ def main():
         fmt = info["fmt"]
         # bytes this kernel has to stream: the matrix in its storage format + x once + y once (nothing for the fused
         # dot: p[r] comes from the LDS window) -- what an HBM counter would show with perfect reuse of x
-        b_fmt = fmt["matrix_bytes_per_product"] + 8 * info["op_shape"][1] + 8 * n_l
+        fused = bool(info.get("fused"))
+        # fused CG passes (storage format 9): the product kernel also carries the previous pass's x / p update -- p_old, r, x
+        # in; p, x, A p out: 48 bytes per row instead of 16 -- and the pass has no third kernel
+        b_fmt = fmt["matrix_bytes_per_product"] + ((48 * n_l) if fused else (8 * info["op_shape"][1] + 8 * n_l))
         achieved = b_fmt / (spmv_us * 1e-6) / 1e9 if spmv_us else None
         traffic, tnote = None, "no PMC profile for this kernel build under profiles/spmv_traffic.json"
         tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
@@ -911,7 +919,9 @@ def main():
                 traffic, tnote = ent, "measured with rocprofv3 PMC at this kernel build (%s)" % tj.get("measured", "?")
             elif ent:
                 tnote = "profiles/spmv_traffic.json was measured at another kernel build or format: not quoted"
-        roof = {"bound": "hbm", "kernel": "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,%d> (SpMV + fused <p,Ap>)" % fmt["format"],
+        kname = ("mk_spmv_kernel<CgFusedEpiT,MkNoGate,false,11> (x,p update + SpMV + <p,Ap>)" if fused else
+                 "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,%d> (SpMV + fused <p,Ap>)" % (11 if fmt["format"] == 9 else fmt["format"]))
+        roof = {"bound": "hbm", "kernel": kname, "fused_pass": fused,
                 "kernel_format": fmt["format_name"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
@@ -928,11 +938,14 @@ def main():
         # 16 n read, 8 n written; x, p update: 24 n read, 16 n written); beside it the reference's op count in CSR units
         scale = n_g / float(n_l)
         it_fmt = (fmt["matrix_bytes_per_product"] * scale + 16 * n_g) + 64 * n_g
+        if fused:                                             # K1f 48 n + K2 24 n (the scalar kernel moves nothing)
+            it_fmt = (fmt["matrix_bytes_per_product"] * scale + 48 * n_g) + 24 * n_g
         it_ref = spmv_bytes(n_g, n_g, nnz_global) + 104 * n_g
         agg = HBM_PEAK_GBS * world_size
         it_roof = {"bytes_per_iter": int(it_fmt), "achieved_GBs": it_fmt * its / 1e9,
                    "frac_of_aggregate_hbm": it_fmt * its / 1e9 / agg,
-                   "note": "physical: product in the storage format in use + 64 n bytes of the fused update kernels",
+                   "note": ("physical: fused pass -- product kernel with the x / p update (matrix + 48 n) + 24 n of the r update"
+                            if fused else "physical: product in the storage format in use + 64 n bytes of the fused update kernels"),
                    "reference_op_count_bytes_per_iter": it_ref, "reference_op_count_GBs": it_ref * its / 1e9,
                    "reference_op_count_note": "SURVEY.md 8d: B_spmv(CSR) + 104 n per pass; a throughput in the "
                                               "reference's units (for the 60 %% target: %.0f GB/s), not a fraction"

@@ -431,6 +431,13 @@ MK_API int mk_solver_iterate(mk_solver *s, int64_t max_iters, int64_t *iters_don
 MK_API int mk_solver_finish(mk_solver *s, mk_result *res);
 MK_API int mk_solver_x(const mk_solver *s, const double **x_dev);
 MK_API int mk_solver_history(const mk_solver *s, double *hist_host, int64_t cap);
+/* 1 when the solver runs FUSED passes: CG (cg.py:113-158) on a single-device matrix in storage format 9 applies a pass's
+ * `x += alpha p ; p = beta p - r` (cg.py:130,150-151) inside the NEXT pass's product kernel, which loads the rows of p, r
+ * and x once for both (one sweep over p less per iteration; every bit of x, p, r and of the history unchanged).  The
+ * product kernel then moves 48 bytes per row besides the matrix data (p, r, x in; p, x, A p out) instead of 16.
+ * mk_solver_x / mk_solver_vector always hand out the up-to-date iterate (formed into scratch vectors between passes).
+ * Environment MK_CG_FUSE=0 turns it off.  Valid after mk_solver_setup. */
+MK_API int mk_solver_fused(const mk_solver *s, int32_t *fused);
 /* Second per-iteration channel, same length as the history (MINRES: truncated direct-error
  * estimate / energy norm, `dir_errors_window` of minres.py:307-308; NaN while itn <= window). */
 MK_API int mk_solver_history2(const mk_solver *s, double *hist_host, int64_t cap);

@@ -133,6 +133,7 @@ PROTOTYPES = {
     "mk_solver_finish": (ctypes.c_int, [c_vp, P(MkResult)]),
     "mk_solver_x": (ctypes.c_int, [c_vp, P(c_vp)]),
     "mk_solver_history": (ctypes.c_int, [c_vp, c_vp, c_i64]),
+    "mk_solver_fused": (ctypes.c_int, [c_vp, P(c_i32)]),
     "mk_solver_history2": (ctypes.c_int, [c_vp, c_vp, c_i64]),
     "mk_solver_vector": (ctypes.c_int, [c_vp, ctypes.c_int, P(c_vp), P(c_i64)]),
     "mk_solver_timing": (ctypes.c_int, [c_vp, P(c_f64), P(c_f64), P(c_i64)]),

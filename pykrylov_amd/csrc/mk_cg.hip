@@ -9,11 +9,22 @@
 // runs when K2 did), which saves one pass over p.  Same operations on the same values: results are unchanged.
 // Algorithmic traffic per pass: B_spmv + (16n read + 8n write) + (24n read + 16n write)
 //   = B_spmv + 64n bytes (the reference's op count gives B_spmv + 104n).
+//
+// FUSED passes (round 5; storage format 9, one GPU): K3's vector work moves into the NEXT pass's product kernel --
+//   K1f  x += alpha p_old ; p = beta p_old - r ; Ap = A p ; partial sums of <p, Ap>   (cg.py:130,150-151 of the pass before,
+//        then cg.py:115-117): the brick march of mk_spmv_fmt9.h loads the own rows of p_old, r and x once, forms p and x,
+//        writes p to the OTHER p buffer (neighbouring bricks still read p_old for their halo rows) and x in place
+//   K2   unchanged
+//   K3s  one workgroup: beta, residNorm, history, loop test (the prologue of K3, nothing else); marks the update pending
+// -- same operations on the same values in the same order per element, so every bit of x, p, r and of the history is
+// the bit of the three-kernel pass.  Traffic per pass: (48n read/write in K1f) + 24n instead of 16n + 24n + 40n: one
+// sweep over p less.  The update of the LAST pass is applied when the loop has halted (mk_solver_x / _vector / finish:
+// `materialize`); a caller that looks at x between passes gets x + alpha p formed into a scratch vector.
 #include "mk_solver.h"
 
 namespace {
 
-enum { S_RY0 = 0, S_RY1 = 1, S_THRESH = 2, S_RESID = 3, S_RESID0 = 4, S_PAP = 5, S_ALPHA = 6 };
+enum { S_RY0 = 0, S_RY1 = 1, S_THRESH = 2, S_RESID = 3, S_RESID0 = 4, S_PAP = 5, S_ALPHA = 6, S_BETA = 7, S_PENDING = 8 };
 
 template <bool NTY>
 struct CgSpmvEpiT {
@@ -39,6 +50,70 @@ struct CgSpmvEpiT {
     }
 };
 using CgSpmvEpi = CgSpmvEpiT<false>;
+
+// K1f: the brick march's "fuse" hooks (mk_spmv_fmt9.h).  Only ever launched on a format-9 matrix; the other formats'
+// instantiations exist because the launcher is generic and are never run.
+template <bool NTY>
+struct CgFusedEpiT {
+    static constexpr int NACC = 1, SLOT0 = 0;
+    double *Ap;
+    const double *fuse_r;
+    double *fuse_x, *fuse_p, *fuse_dump;
+    double *scal;
+    double fa, fb;
+    __device__ void prologue(double *) {
+        fa = scal[S_ALPHA];                                // alpha and beta of the pass before (K2 / K3s)
+        fb = scal[S_BETA];
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[S_PENDING] = 0.0;     // this kernel applies the pending update
+    }
+    __device__ double xin(double v) const { return v; }
+    __device__ double fuse_pnew(double po, double rv) const { return fb * po - rv; }       // cg.py:150-151
+    __device__ double fuse_xnew(double xv, double po) const { return xv + fa * po; }       // cg.py:130
+    __device__ void row(int64_t r, double s, double *) { Ap[r] = s; }                      // (never run: see above)
+    __device__ void row_x(int64_t r, double s, double xr, double *acc) {
+        if constexpr (NTY) __builtin_nontemporal_store(s, Ap + r);
+        else Ap[r] = s;
+        acc[0] += xr * s;
+    }
+};
+
+// K3s: the scalar part of K3 (CgUpdateXP::prologue), one workgroup
+__global__ __launch_bounds__(MK_BLOCK) void cg_beta_kernel(const double *part, int np, double *scal, MkStatus *st, double *hist,
+                                                           int par, int64_t matvec_max, MkHalt halt) {
+    __shared__ double s4[4];
+    if (halt.in()) {
+        if (threadIdx.x == 0) halt.out(true);
+        return;
+    }
+    const double ry_next = mk_total(part + MK_MAXP, np, s4);
+    if (threadIdx.x == 0) {
+        const double ry = scal[S_RY0 + par];
+        const double beta = ry_next / ry;                 // cg.py:149
+        const double resid = fabs(__dsqrt_rn(ry_next));   // cg.py:154
+        const bool go = (resid > scal[S_THRESH]) && (st->nMatvec < matvec_max);   // cg.py:113
+        scal[S_RY0 + (par ^ 1)] = ry_next;                // cg.py:153
+        scal[S_RESID] = resid;
+        scal[S_BETA] = beta;
+        scal[S_PENDING] = 1.0;                            // x += alpha p ; p = beta p - r of this pass are still to be applied
+        hist[st->hist_len % MK_HIST_RING] = resid;        // cg.py:155
+        st->hist_len += 1;
+        st->itn += 1;
+        halt.out(!go);
+    }
+}
+
+// the pending update of the last pass, outside the halt protocol: in place once the loop has halted, into scratch
+// vectors for a caller that looks at the iterate between passes
+__global__ __launch_bounds__(MK_BLOCK) void cg_flush_kernel(int64_t n, const double *scal, const double *r, const double *p,
+                                                            const double *x, double *p_out, double *x_out) {
+    const bool pend = scal[S_PENDING] != 0.0;
+    const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
+    for (int64_t i = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * MK_BLOCK) {
+        const double pv = p[i], xv = x[i];
+        x_out[i] = pend ? xv + alpha * pv : xv;           // cg.py:130
+        p_out[i] = pend ? beta * pv - r[i] : pv;          // cg.py:150-151
+    }
+}
 
 struct CgUpdateR {
     static constexpr int NACC = 1, SLOT0 = 1;
@@ -181,12 +256,57 @@ __global__ __launch_bounds__(MK_BLOCK) void cg_init_kernel(const double *part, i
         st->nMatvec = nmv0;
         st->itn = 0;
         st->definite = 1;
+        scal[S_PENDING] = 0.0;
         halt.out(!((resid0 > thresh) && (nmv0 < matvec_max)));
     }
 }
 
 struct CgSolver : mk_solver {
     double *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_Ap = nullptr;
+    // fused passes (see the top of the file)
+    bool fused = false;
+    double *d_p2 = nullptr, *d_dump = nullptr;            // the second p buffer; the dump rows of the brick march
+    mutable double *d_xv = nullptr, *d_pv = nullptr;      // the iterate / direction as a caller sees them between passes
+    mutable bool flushed = false;
+    int64_t nmv0 = 0;                                     // products before the loop (the initial guess's)
+    double *pbuf(int64_t k) const { return (!fused || (k & 1) == 0) ? d_p : d_p2; }     // p of pass k
+    // the buffer of the direction in use: product k WROTE pbuf(k), and the passes the host enqueued behind a halt never ran,
+    // so the products the DEVICE counted decide (K2 counts one per product, cg.py:116), not the host's pass counter
+    double *pcur() const {
+        CgSolver *me = const_cast<CgSolver *>(this);
+        if (!fused || !is_setup) return d_p;
+        if (hipMemcpyAsync(me->h_status, d_status, sizeof(MkStatus), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess)
+            return d_p;
+        const int64_t done = h_status->nMatvec - nmv0;
+        return done > 0 ? pbuf(done - 1) : d_p;
+    }
+
+    static bool want_fuse() {
+        const char *e = getenv("MK_CG_FUSE");              // (read at every setup: tests switch it between solves)
+        return !e || atoi(e) != 0;
+    }
+    // apply (halted) or form (running) the pending x / p update; returns the vectors a caller may read
+    void materialize(const double **xo, const double **po) const {
+        CgSolver *me = const_cast<CgSolver *>(this);
+        *xo = d_x;
+        double *pc = pcur();
+        *po = pc;
+        if (!fused || it == 0 || !is_setup) return;
+        const int grid = (int)((n + MK_BLOCK - 1) / MK_BLOCK > 2048 ? 2048 : (n + MK_BLOCK - 1) / MK_BLOCK);
+        if (halted) {
+            if (!flushed) {
+                hipLaunchKernelGGL(cg_flush_kernel, dim3(grid), dim3(MK_BLOCK), 0, stream, n, d_scal, d_r, pc, d_x, pc, d_x);
+                hipMemsetAsync(d_scal + S_PENDING, 0, sizeof(double), stream);
+                me->flushed = true;
+            }
+            return;
+        }
+        if (!d_xv && (me->alloc_vec(&me->d_xv, n) != MK_OK || me->alloc_vec(&me->d_pv, n) != MK_OK)) return;
+        hipLaunchKernelGGL(cg_flush_kernel, dim3(grid), dim3(MK_BLOCK), 0, stream, n, d_scal, d_r, pc, d_x, d_pv, d_xv);
+        *xo = d_xv;
+        *po = d_pv;
+    }
 
     int setup(const double *rhs, const double *guess) override {
         if (!d_x) {
@@ -195,7 +315,15 @@ struct CgSolver : mk_solver {
                 (rc = alloc_vec(&d_Ap, n)))
                 return rc;
         }
-        int64_t nmv0 = 0;
+        const MkPlan *plan = A ? mk_csr_plan(A) : nullptr;
+        fused = want_fuse() && plan && plan->fmt == 9 && !precon_fn && !mk_comm_active() && A->ex.mode < 0 && A->nops == 0 &&
+                !A->comp_kind && nx == n;
+        flushed = false;
+        if (fused && !d_p2) {
+            int rc;
+            if ((rc = alloc_vec(&d_p2, nx)) || (rc = alloc_vec(&d_dump, (int64_t)MK_MAXP * 1024))) return rc;
+        }
+        nmv0 = 0;
         mk_launch_stream(this, MkOpNegCopy{rhs, d_r}, n);                   // r = -rhs          cg.py:85
         if (guess) {
             MK_HIP(hipMemcpyAsync(d_x, guess, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
@@ -224,6 +352,14 @@ struct CgSolver : mk_solver {
 
     int enqueue_spmv_only(int which) override {
         if (which != 0) return mk_fail(MK_ERR_ARG, "CG has one product per pass");
+        if (fused && it > 0) {
+            // the fused kernel exactly as a pass launches it (same streams: p_old, r, x in; p, x, Ap out), except that p goes
+            // to the buffer it came from's twin and x is updated again with the same alpha -- timing only, after the run
+            double *pc = pcur(), *po = (pc == d_p) ? d_p2 : d_p;
+            if (mk_store_nt(A)) mk_launch_spmv(this, pc, CgFusedEpiT<true>{d_Ap, d_r, d_x, po, d_dump, d_scal, 0.0, 0.0}, false);
+            else mk_launch_spmv(this, pc, CgFusedEpiT<false>{d_Ap, d_r, d_x, po, d_dump, d_scal, 0.0, 0.0}, false);
+            return MK_OK;
+        }
         if (A && mk_store_nt(A)) mk_launch_spmv(this, d_p, CgSpmvEpiT<true>{d_p, d_Ap, 0.0}, false);
         else mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0}, false);
         return MK_OK;
@@ -231,7 +367,23 @@ struct CgSolver : mk_solver {
 
     int enqueue_pass() override {
         const int par = (int)(it & 1);
-        int rc = exchange(d_p);
+        int rc;
+        if (fused) {
+            const bool nt = mk_store_nt(A);
+            if (it == 0) {                                  // nothing pending yet: the plain product on p = -r
+                if (nt) mk_launch_spmv(this, d_p, CgSpmvEpiT<true>{d_p, d_Ap, 0.0});
+                else mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0});
+            } else {                                        // K1f: p_old = the other buffer
+                if (nt) mk_launch_spmv(this, pbuf(it - 1), CgFusedEpiT<true>{d_Ap, d_r, d_x, pbuf(it), d_dump, d_scal, 0.0, 0.0});
+                else mk_launch_spmv(this, pbuf(it - 1), CgFusedEpiT<false>{d_Ap, d_r, d_x, pbuf(it), d_dump, d_scal, 0.0, 0.0});
+            }
+            mk_launch_stream(this, CgUpdateR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_Ap, d_r,
+                                             d_prec, 0.0, false}, n);
+            hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_stream, d_scal, d_status, d_hist,
+                               par, prm.matvec_max, next_halt());
+            return MK_OK;
+        }
+        rc = exchange(d_p);
         if (rc != MK_OK) return rc;
         if (A && mk_store_nt(A)) mk_launch_spmv(this, d_p, CgSpmvEpiT<true>{d_p, d_Ap, 0.0});
         else mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0});
@@ -260,8 +412,19 @@ struct CgSolver : mk_solver {
         return MK_OK;
     }
 
-    const double *x() const override { return d_x; }
-    const double *vector(int i) const override { return i == 0 ? d_r : (i == 1 ? d_p : nullptr); }
+    const double *x() const override {
+        const double *xo, *po;
+        materialize(&xo, &po);
+        return xo;
+    }
+    const double *vector(int i) const override {
+        if (i == 0) return d_r;
+        if (i != 1) return nullptr;
+        const double *xo, *po;
+        materialize(&xo, &po);
+        return po;
+    }
+    bool is_fused() const override { return fused; }
     // The search direction is built from r, not from y = precon*r, exactly as cg.py:104,150-151 do.
     bool takes_precon() const override { return true; }
 };

@@ -85,6 +85,7 @@ struct mk_solver {
     virtual const double *x() const = 0;
     virtual const double *vector(int) const { return nullptr; }
     virtual bool takes_precon() const { return false; }
+    virtual bool is_fused() const { return false; }   // CG on a format-9 matrix: the x / p update rides in the next product kernel
     // enqueue only the solver's (fused) SpMV kernel, exactly as a loop pass launches it; used to time
     // that kernel back to back.  Overwrites the product vector and its partial sums.
     // `which`: 0 = the first product of a pass, 1 = the second (BiCGSTAB / CGS / TFQMR: the product on z; least squares:

@@ -453,6 +453,12 @@ extern "C" int mk_solver_x(const mk_solver *s, const double **x_dev) {
     return MK_OK;
 }
 
+extern "C" int mk_solver_fused(const mk_solver *s, int32_t *fused) {
+    MK_ARG(s && fused);
+    *fused = s->is_fused() ? 1 : 0;
+    return MK_OK;
+}
+
 extern "C" int mk_solver_history(const mk_solver *s, double *hist_host, int64_t cap) {
     MK_ARG(s && (cap == 0 || hist_host));
     int64_t cnt = (int64_t)s->hist.size();

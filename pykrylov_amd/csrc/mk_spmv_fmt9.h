@@ -42,6 +42,16 @@
 // (item = brick + bricks_per_plane * chunk; items blockIdx, blockIdx + grid, ...), and adds their terms plane by plane,
 // row c before row c + 1 (the tests restate this order on the host to demand bit equality).
 
+// Optional epilogue hook set "fuse" (CG, mk_cg.hip): the product's input vector is FORMED on the fly from the previous
+// pass -- p = beta p_old - r (cg.py:150-151) -- and the deferred x += alpha p_old (cg.py:130) rides along: the own rows
+// of every plane are loaded from p_old, r and x, transformed once when the plane enters the ring's front, and written
+// out (p to a second buffer: the neighbouring bricks still read p_old for their halo rows and form the same p
+// redundantly); the halo rows are formed from p_old and r on the fly.  One pass over x, p, r less per CG iteration.
+template <class Epi, class = void>
+struct MkHasFuse : std::false_type {};
+template <class Epi>
+struct MkHasFuse<Epi, std::void_t<decltype(std::declval<Epi &>().fuse_r)>> : std::true_type {};
+
 // one term of a row sum: s + v * x, x with its high word ANDed by m (0xffffffff: the row has the entry; 0: it has not, v = +0.0)
 __device__ __forceinline__ double mk_pen_term(double s, double v, unsigned m, double xk) {
     return s + v * __hiloint2double((int)((unsigned)__double2hiint(xk) & m), __double2loint(xk));
@@ -68,6 +78,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     constexpr int R = MK_PEN_R, RS = MK_PEN_RS, BUF = 6 * MK_PEN_RS;
     static_assert(MK_PEN_R % 2 == 0 && MK_PEN_R % MK_PEN_H == 0, "ring geometry");
     constexpr bool ROWX = !PROG && MkHasRowX<Epi>::value;
+    constexpr bool FUSE = MkHasFuse<Epi>::value;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int64_t L = A.pen_L, P = A.pen_P;
     const int nz = A.pen_nz, bx = A.pen_bx, bpp = A.pen_bpp, zc = A.pen_zc;
@@ -107,11 +118,43 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         double hreg[H], ereg[H];
         mk_d2 ring[R];
         unsigned pidr[H];
+        [[maybe_unused]] double hr[FUSE ? H : 1], er[FUSE ? H : 1];      // fuse: r at the halo rows
+        [[maybe_unused]] mk_d2 rr[FUSE ? H : 1], xx[FUSE ? H : 1];      // fuse: r and x at the own rows of the plane to transform next
         auto halo = [&](int p, int d) {                       // plane p at the halo rows + the pattern bytes of the own rows
             p = p > nz - 1 ? nz - 1 : p;
             hreg[d] = x[clampr((int64_t)p * P + hc)];
             ereg[d] = x[clampr((int64_t)p * P + ec)];
+            if constexpr (FUSE) {
+                hr[d] = epi.fuse_r[clampr((int64_t)p * P + hc)];
+                er[d] = epi.fuse_r[clampr((int64_t)p * P + ec)];
+            }
             pidr[d] = *reinterpret_cast<const uint16_t *>(pid + (int64_t)p * P + c);
+        };
+        [[maybe_unused]] auto plane_of = [&](const double *v, int p) -> mk_d2 {
+            p = p < 0 ? 0 : (p > nz - 1 ? nz - 1 : p);
+            return *reinterpret_cast<const mk_d2 *>(v + (int64_t)p * P + c);
+        };
+        // fuse: raw p_old of plane `pl` in pv with its r (and x) -> p (in pv) and x; both written out when the plane is one of
+        // this chunk's own (anything else lands in the workgroup's dump rows: every store of the loop is unconditional)
+        [[maybe_unused]] auto transform = [&](mk_d2 &pv, const mk_d2 rv, const mk_d2 xv, int pl, bool store) {
+            if constexpr (FUSE) {
+                const mk_d2 po = pv;
+                pv.x = epi.fuse_pnew(po.x, rv.x);
+                pv.y = epi.fuse_pnew(po.y, rv.y);
+                if (store) {                                 // (compile-time constant at every call site)
+                    const bool own = pl >= z0 && pl < z1;    // (workgroup uniform: a scalar select of the address)
+                    double *dump = epi.fuse_dump + (int64_t)blockIdx.x * 1024 + 2 * tid;
+                    mk_d2 xn;
+                    xn.x = epi.fuse_xnew(xv.x, po.x);
+                    xn.y = epi.fuse_xnew(xv.y, po.y);
+                    *reinterpret_cast<mk_d2 *>(own ? epi.fuse_p + (int64_t)pl * P + c : dump) = pv;
+                    *reinterpret_cast<mk_d2 *>(own ? epi.fuse_x + (int64_t)pl * P + c : dump + 512) = xn;
+                }
+            }
+        };
+        [[maybe_unused]] auto halo_val = [&](double pv, double rv) -> double {
+            if constexpr (FUSE) return epi.fuse_pnew(pv, rv);
+            else return pv;
         };
         // one plane: slots (xm, xc, xp) = planes zz-1, zz, zz+1 at the own rows; hv / ev / pp = halo rows and pattern bytes of plane zz
         auto step = [&](int zz, int bo, const mk_d2 xm_, const mk_d2 xc_, const mk_d2 xp_, double hv, double ev, unsigned pp,
@@ -167,34 +210,65 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         };
         const int zfull = z0 + ((z1 - z0) / R) * R;          // planes of the pipelined rounds; the rest one by one below
         if (zfull > z0) {
+            [[maybe_unused]] mk_d2 rm1{0.0, 0.0}, r00{0.0, 0.0}, x00{0.0, 0.0};
+            if constexpr (FUSE) {                             // r (and x) of the two planes the ring starts with
+                rm1 = plane_of(epi.fuse_r, z0 - 1);
+                r00 = plane_of(epi.fuse_r, z0);
+                x00 = plane_of(epi.fuse_x, z0);
+            }
 #pragma unroll
             for (int d = 0; d < R - 1; ++d) {                 // (issue order = consumption order; slot R - 1 is loaded by step 0)
                 ring[d] = plane(z0 - 1 + d);
                 if (d < H) halo(z0 + d, d);
+                if constexpr (FUSE) {
+                    if (d < H) {                              // plane z0 + 1 + d -> slot (1 + d) % H
+                        rr[(1 + d) % H] = plane_of(epi.fuse_r, z0 + 1 + d);
+                        xx[(1 + d) % H] = plane_of(epi.fuse_x, z0 + 1 + d);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // one full wait at entry: the loop header's wait count is the stricter of the entry edge and the back edge,
             // and the entry edge as the compiler models it would drain the pipeline on every round
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+            if constexpr (FUSE) {
+                transform(ring[0], rm1, rm1, z0 - 1, false);  // (the chunk below owns plane z0 - 1: formed, not written)
+                transform(ring[1], r00, x00, z0, true);
+            }
             int z = z0;
             do {
 #pragma unroll
                 for (int d = 0; d < R; ++d) {
                     const int zz = z + d;
-                    step(zz, (d & 1) * BUF, ring[d], ring[(d + 1) % R], ring[(d + 2) % R], hreg[d % H], ereg[d % H], pidr[d % H],
-                         [&]() {
+                    if constexpr (FUSE) transform(ring[(d + 2) % R], rr[(d + 1) % H], xx[(d + 1) % H], zz + 1, true);
+                    step(zz, (d & 1) * BUF, ring[d], ring[(d + 1) % R], ring[(d + 2) % R], halo_val(hreg[d % H], hr[FUSE ? d % H : 0]),
+                         halo_val(ereg[d % H], er[FUSE ? d % H : 0]), pidr[d % H], [&]() {
                              __builtin_amdgcn_sched_barrier(0);   // (the slots' last uses stay ABOVE their reloads)
                              ring[(d + R - 1) % R] = plane(zz + R - 2);   // the slot of plane zz - 2: dead since the last step
                              halo(zz + H, d % H);
+                             if constexpr (FUSE) {            // plane zz + 1 + H into the slot plane zz + 1 just left
+                                 rr[(d + 1) % H] = plane_of(epi.fuse_r, zz + 1 + H);
+                                 xx[(d + 1) % H] = plane_of(epi.fuse_x, zz + 1 + H);
+                             }
                          });
                 }
                 z += R;
             } while (z < zfull);
         }
         for (int zz = zfull; zz < z1; ++zz) {                 // (<= R - 1 planes of the last chunk when nz is not a multiple of R)
-            const mk_d2 xm = plane(zz - 1), xc = plane(zz), xp = plane(zz + 1);
+            mk_d2 xm = plane(zz - 1), xc = plane(zz), xp = plane(zz + 1);
             halo(zz, 0);
-            step(zz, ((zz - zfull) & 1) * BUF, xm, xc, xp, hreg[0], ereg[0], pidr[0], [] {});
+            if constexpr (FUSE) {
+                // planes zz - 1 and zz are formed again from p_old and r (x was updated when they were written: not touched);
+                // a chunk without pipelined rounds writes its first plane here; plane zz + 1 is formed and written now
+                const mk_d2 ra = plane_of(epi.fuse_r, zz - 1), rb = plane_of(epi.fuse_r, zz), rc = plane_of(epi.fuse_r, zz + 1);
+                const mk_d2 xb = plane_of(epi.fuse_x, zz), xcn = plane_of(epi.fuse_x, zz + 1);
+                transform(xm, ra, ra, zz - 1, false);
+                if (zz == z0) transform(xc, rb, xb, zz, true);
+                else transform(xc, rb, rb, zz, false);
+                transform(xp, rc, xcn, zz + 1, true);
+            }
+            step(zz, ((zz - zfull) & 1) * BUF, xm, xc, xp, halo_val(hreg[0], hr[0]), halo_val(ereg[0], er[0]), pidr[0], [] {});
         }
         __syncthreads();                                     // the next item's first plane image overwrites this LDS
     }

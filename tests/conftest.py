@@ -15,6 +15,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: the heavier twins of full-size GPU cases; skipped unless the -m expression "
+                                       "names them (-m \"gpu and slow\"), so that the default -m gpu run keeps one full-size "
+                                       "case per BASELINE config and stays well inside the driver's time limit")
+
+
+def pytest_collection_modifyitems(config, items):
+    if "slow" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="slow twin of a full-size case: run with -m \"gpu and slow\"")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 def pytest_sessionstart(session):

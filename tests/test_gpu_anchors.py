@@ -22,6 +22,7 @@ def relerr(a, b):
     return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))
 
 
+@pytest.mark.slow
 def test_minres_config4_head_against_exact_dots():
     """BASELINE configs[3]: MINRES on the shifted 2-D Laplacian, n = 4e6, shift 1.5 (indefinite).  The Lanczos recurrence
     with the shift inside the spectrum is chaotic in the long run (any two summation orders part ways after a few

@@ -35,7 +35,7 @@ def device_rhs_ones(op, shift=0.0):
     return rhs
 
 
-@pytest.mark.parametrize("fmt", [2, 0])
+@pytest.mark.parametrize("fmt", [2, pytest.param(0, marks=pytest.mark.slow)])
 def test_cg_config2_n1e6_bit_exact_full_run(fmt):
     """configs[1]: CG, 2-D Poisson n = 1e6, defaults: all 1474 iterations, history and iterate bit for bit, in the
     windowed+dictionary format (1 280 workgroups, XCD-chunked) and in plain CSR (2 048 workgroups, XCD-chunked)."""

@@ -131,6 +131,7 @@ def test_cg_recurrence_residual_is_true_residual(op512):
         b.free()
 
 
+@pytest.mark.slow
 def test_cg_256cubed_head_matches_oracle():
     """Same problem class one size down (16.7 M rows): the first 25 iterations against the CPU oracle."""
     from pykrylov_amd import CG, gallery
@@ -160,6 +161,7 @@ def test_cg_256cubed_head_matches_oracle():
     op.free()
 
 
+@pytest.mark.slow
 def test_full_runs_against_the_order_independent_anchor():
     """BASELINE configs[1] (CG, 2-D Poisson n = 1e6, all 1474 iterations) and a variable-coefficient 3-D problem
     (128^3, full run): the device's residual history and iterate within 1e-12 of the oracle run with exactly rounded

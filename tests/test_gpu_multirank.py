@@ -21,7 +21,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("nranks", [2, pytest.param(3, marks=pytest.mark.slow)])
 def test_partitioned_solvers_on_one_gpu(nranks):
     env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),

@@ -168,3 +168,54 @@ def test_composed_operator_on_format_9():
     y = comp * x
     assert fmt_of(op) == 9
     assert np.array_equal(y, 2.5 * A.matvec(x) + d * x)
+
+
+def _solver_is_fused(op, rhs):
+    from pykrylov_amd import _lib
+    from pykrylov_amd.generic import DeviceRun
+    with DeviceRun(op, _lib.MK_CG, rhs, None, abstol=1e-8, reltol=1e-6, matvec_max=10, check_curvature=1) as run:
+        run.setup()
+        f = ctypes.c_int32()
+        _lib.check(run.lib.mk_solver_fused(run.handle, ctypes.byref(f)))
+    return bool(f.value)
+
+
+@pytest.mark.parametrize("dims", [(128, 8, 9), (128, 4, 14), (256, 8, 26)])
+def test_fused_cg_passes_change_no_bit(dims, monkeypatch):
+    """CG on a format-9 matrix runs FUSED passes (the x / p update of a pass inside the next pass's product kernel,
+    csrc/mk_cg.hip).  Same operations on the same values: history, iterate, matvec count, residual norm and the search
+    direction equal the three-kernel pass bit for bit -- with default stopping, with matvec_max cutting the run short
+    (the pending update of the last pass must still land), with an initial guess, with a diagonal preconditioner and
+    with store_iterates (the iterate as a caller sees it BETWEEN passes)."""
+    from pykrylov_amd import CG
+    from pykrylov_amd.linop import DiagonalOperator
+    A = csr_ref.poisson3d(*dims)
+    n = A.shape[0]
+    rng = np.random.default_rng(4)
+    rhs = A.matvec(np.ones(n)) + 0.1 * rng.standard_normal(n)
+    guess = rng.standard_normal(n)
+    prec = DiagonalOperator(1.0 / (6.0 + rng.random(n)))
+    cases = [dict(), dict(matvec_max=7), dict(guess=guess, matvec_max=23), dict(store_iterates=True, matvec_max=12),
+             dict(store_resids=True, matvec_max=9)]
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MK_CG_FUSE", fuse)
+        op = op9(A, symmetric=True)
+        assert _solver_is_fused(op, rhs) == (fuse == "1")
+        res = []
+        for kw in cases:
+            s = CG(op)
+            s.solve(rhs, **kw)
+            res.append((s.nMatvec, np.array(s.residHistory), s.x.copy(), float(s.residNorm), bool(s.converged),
+                        [np.array(v) for v in getattr(s, "iterates", [])], [np.array(v) for v in getattr(s, "resids", [])]))
+        s = CG(op, precon=prec)
+        s.solve(rhs, matvec_max=40)
+        res.append((s.nMatvec, np.array(s.residHistory), s.x.copy(), float(s.residNorm), bool(s.converged), [], []))
+        assert fmt_of(op) == 9
+        out[fuse] = res
+    for a, b in zip(out["1"], out["0"]):
+        assert a[0] == b[0] and a[3] == b[3] and a[4] == b[4]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert len(a[5]) == len(b[5]) and all(np.array_equal(u, v) for u, v in zip(a[5], b[5]))
+        assert len(a[6]) == len(b[6]) and all(np.array_equal(u, v) for u, v in zip(a[6], b[6]))
+    assert len(out["1"][3][5]) >= 12                                    # (the store_iterates case really kept iterates)
