@@ -115,7 +115,7 @@ def _compact_cpu(c):
     if not c:
         return None
     out = {k: sig(c.get(k)) for k in ("value", "unit", "cores", "kind", "extrapolated", "sample_rows")}
-    out["sample"] = str(c.get("sample", ""))[:96]
+    out["sample"] = str(c.get("sample_short") or c.get("sample", ""))[:96]
     return out
 
 
@@ -279,6 +279,7 @@ def cpu_baseline(name, seconds_budget=20.0):
     out = krylov_ref.cg(A, rhs, abstol=0.0, reltol=0.0, matvec_max=iters)
     dt = time.perf_counter() - t0
     return {"value": out["nMatvec"] / dt * scale, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample_short": "%d CG passes on %d rows%s" % (out["nMatvec"], n, ", scaled by the rows ratio" if scale != 1.0 else ""),
             "extrapolated": scale != 1.0, "measured_on_sample": out["nMatvec"] / dt, "sample_rows": int(n),
             "sample": sample % out["nMatvec"], "host_cpus": os.cpu_count(),
             "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS", "default"),
@@ -370,6 +371,7 @@ def cpu_baseline_full_size(names, passes=3, threads=(1,)):
             "value": passes / dt, "unit": "iterations/s", "cores": th, "kind": "port", "extrapolated": False,
             "sample_rows": int(n), "sample_nnz": int(A.nnz), "seconds_per_pass": dt / passes,
             "matrix_generation_seconds": t_gen,
+            "sample_short": "%d CG passes of the workload itself after 1 untimed; CSR product on %d thread(s)" % (passes, th),
             "sample": "%d CG passes of %s itself (%d rows, %d nnz) after 1 untimed pass; NumPy updates and np.dot on one "
                       "thread, C CSR product on %d OpenMP thread(s)" % (passes, name, n, A.nnz, th),
             "host_cpus": os.cpu_count(), "residual_after": float(res["residHistory"][-1])}}

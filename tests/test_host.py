@@ -468,3 +468,21 @@ def test_bench_compact_line_fits_the_drivers_tail(n_ranks):
         assert back["transport"]["kind"] == "host-staged"
         assert set(back["exchange"]) == {"halo", "allgather"}
         assert back["exchange"]["halo"]["max_over_ranks"]["product_alone_us"] == pytest.approx(251.123456 + n_ranks - 1, rel=1e-4)
+
+
+def test_bench_compact_line_on_a_real_detail_file():
+    """The same on what a real MI355X run wrote (tests/golden/bench_detail_n1.json = bench_detail.json of the default
+    command, round 5): the line rebuilt from the detail equals the line the run printed, fits, and carries the figures."""
+    import json
+    import bench
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_detail_n1.json")))
+    printed = d.pop("line")
+    line = bench.compact_line(d)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= bench.LINE_LIMIT
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "config", "iteration_frac", "residual",
+              "parity_vs_n1", "solver_loops", "cg_other_workloads"):
+        assert line[k] == printed[k], k
+    assert line["config"]["workload"] == "CG poisson3d-512" and line["roofline"]["frac"] == printed["roofline"]["frac"]
+    assert line["second_workload"]["workload"] == "CG poisson3d-512-varcoef"
+    assert line["cpu_baseline"]["sample_rows"] == 134217728 and line["cpu_baseline"]["extrapolated"] is False
