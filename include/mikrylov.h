@@ -203,9 +203,13 @@ MK_API int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn,
  *      rows in registers, so that every x entry is loaded once per product (format 4 requests each five times).  Chosen
  *      automatically for single-device matrices of at least 2^21 rows (MK_PENCIL_MIN_ROWS); asked for explicitly it is
  *      applied to any matrix of the class.  Matrices outside the class degrade to 8 and below.
- * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 9 = the most compact format the matrix qualifies for;
+ *  10  format 9's march for matrices of the class WITHOUT a value dictionary (variable-coefficient stencils): the byte per
+ *      row is its 7-bit presence mask and the values are streamed from seven position-major arrays (56 bytes per row,
+ *      +0.0 where a row has no entry) -- what format 5 streams, with every x entry loaded once.  Chosen automatically
+ *      (same size rule) when format 9 finds more than 256 values or patterns; asked for explicitly on any matrix of the class.
+ * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 10 = the most compact format the matrix qualifies for;
  * format 3 is chosen automatically for scattered matrices with more than 5 MiB of x).  A request is an upper bound and
- * degrades silently (9 -> 8, 8 -> 7 -> 6 -> 0, 5 -> 1, 4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the
+ * degrades silently (10 -> 9 -> 8, 8 -> 7 -> 6 -> 0, 5 -> 1, 4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the
  * gather path of format 0.
  * mk_csr_format_info reports what is in use: the format, the number of windowed tiles, the LDS chunks (128
  * doubles each) a workgroup reserves (format 3: the number of column phases), the dictionary size and the bytes of
@@ -237,10 +241,12 @@ MK_API int mk_csr_colblocks(const mk_csr *A, int32_t *nblocks);
 /* Launch geometry of A's product kernels (what fixes the summation order of the dots fused into them): the grid,
  * and the tile order (0 round robin; 1 each XCD sweeps a contiguous eighth; 2 XCD-contiguous blocks per step). */
 MK_API int mk_csr_launch_info(const mk_csr *A, int32_t *grid, int32_t *tile_map);
-/* Geometry of format 9 (all zero when A is in another format): the line and plane strides L and P found in the matrix,
+/* Geometry of formats 9 / 10 (all zero when A is in another format): the line and plane strides L and P found in the matrix,
  * the number of planes, the planes a workgroup marches through per (brick, chunk) item, the chunks per brick and the
  * number of distinct row patterns.  Workgroup b of a launch of `grid` workgroups takes the items b, b + grid, ...;
- * item i = brick (i % bricks_per_plane) of chunk (i / bricks_per_plane), bricks_per_plane = (L / 128) (P / 4L), brick j
+ * item i = brick (i % bricks_per_plane) of chunk (i / bricks_per_plane) -- dealt XCD-contiguously when bricks_per_plane and
+ * the grid are multiples of 8: brick (i % 8) bpp / 8 + (i / 8) % (bpp / 8) of chunk (i / 8) / (bpp / 8) --,
+ * bricks_per_plane = bpp = (L / 128) (P / 4L), brick j
  * starting at row (j / (L / 128)) 4L + (j % (L / 128)) 128 of a plane -- what oracle/gpu_order.py restates for the
  * fused dots (test infrastructure). */
 MK_API int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t *stride_plane, int32_t *planes,

@@ -123,7 +123,9 @@ def spmv_tile_order(ntiles, grid=None, tile_map=1):
 
 def pencil_partials(w, y, grid, L, P, nz, zc, chunks):
     """Storage format 9 (csrc/mk_spmv_fmt9.h): workgroup b takes the (brick, chunk) items b, b + grid, ...; item i is
-    brick i % bpp of chunk i // bpp (bpp = (L / 128) (P / 4L) bricks per plane, brick j starting at row
+    brick i % bpp of chunk i // bpp -- or, when bpp and the grid are multiples of 8, brick (i % 8) bpp / 8 + (i // 8) % (bpp / 8)
+    of chunk (i // 8) // (bpp / 8): XCD i % 8 works on one contiguous eighth of every plane --
+    (bpp = (L / 128) (P / 4L) bricks per plane, brick j starting at row
     (j // (L / 128)) 4 L + (j % (L / 128)) 128 of a plane); lane (wave v, lane l) owns the rows z P + c and z P + c + 1,
     c = brick start + v L + 2 l, and adds their terms plane by plane through the chunk, row c first."""
     prod = (np.asarray(w, dtype=np.float64) * np.asarray(y, dtype=np.float64)).reshape(nz, P)
@@ -134,8 +136,12 @@ def pencil_partials(w, y, grid, L, P, nz, zc, chunks):
     acc = np.zeros((grid, BLOCK))
     for first in range(0, items, grid):                      # round k of every workgroup (vectorised over workgroups)
         it = np.arange(first, min(first + grid, items))
-        b0 = ((it % bpp) // bx) * 4 * L + ((it % bpp) % bx) * 128
-        ch = it // bpp
+        if bpp % 8 == 0 and grid % 8 == 0:                   # XCD-contiguous deal (workgroup b runs on XCD b % 8)
+            per = bpp // 8
+            bi, ch = (it % 8) * per + (it // 8) % per, (it // 8) // per
+        else:
+            bi, ch = it % bpp, it // bpp
+        b0 = (bi // bx) * 4 * L + (bi % bx) * 128
         cols = b0[:, None] + lane_c[None, :]                 # (workgroups, 256): in-plane index of row c
         for zi in range(zc):
             z = ch * zc + zi

@@ -316,7 +316,7 @@ struct CgSolver : mk_solver {
                 return rc;
         }
         const MkPlan *plan = A ? mk_csr_plan(A) : nullptr;
-        fused = want_fuse() && plan && plan->fmt == 9 && !precon_fn && !mk_comm_active() && A->ex.mode < 0 && A->nops == 0 &&
+        fused = want_fuse() && plan && (plan->fmt == 9 || plan->fmt == 10) && !precon_fn && !mk_comm_active() && A->ex.mode < 0 && A->nops == 0 &&
                 !A->comp_kind && nx == n;
         flushed = false;
         if (fused && !d_p2) {

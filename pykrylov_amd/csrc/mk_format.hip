@@ -517,8 +517,8 @@ void plan_free(MkPlan &P) {
 int default_format() {
     static int f = [] {
         const char *e = getenv("MK_SPMV_FORMAT");
-        int v = e ? atoi(e) : 9;
-        return v < 0 ? 0 : (v > 9 ? 9 : v);
+        int v = e ? atoi(e) : 10;
+        return v < 0 ? 0 : (v > 10 ? 10 : v);
     }();
     return f;
 }
@@ -1100,6 +1100,43 @@ __global__ __launch_bounds__(MK_BLOCK) void pen_table(int nkeys, const double *_
     tab[16 * j + 15] = 0;
 }
 
+// format 10: per row the 7-bit presence mask, and the values in position-major order sval[k * nrows + r] (+0.0 where the row
+// has no entry at offset k); state[1] is raised by a row with an offset outside the class
+__global__ __launch_bounds__(MK_BLOCK) void pen_stream_fill(int64_t nrows, const int32_t *__restrict__ ip, const int32_t *__restrict__ ix,
+                                                            const double *__restrict__ data, int64_t L, int64_t P,
+                                                            uint8_t *__restrict__ pid, double *__restrict__ sval, int *state) {
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        const int lo = ip[r], hi = ip[r + 1];
+        double v[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        unsigned mask = 0;
+        bool bad = hi - lo > 7;
+        for (int j = lo; j < hi && !bad; ++j) {
+            const int64_t d = (int64_t)ix[j] - r;
+            int k;
+            if (d == -P) k = 0;
+            else if (d == -L) k = 1;
+            else if (d == -1) k = 2;
+            else if (d == 0) k = 3;
+            else if (d == 1) k = 4;
+            else if (d == L) k = 5;
+            else if (d == P) k = 6;
+            else {
+                bad = true;
+                break;
+            }
+            v[k] = data[j];
+            mask |= 1u << k;
+        }
+        if (bad) {
+            state[1] = 1;
+            return;
+        }
+        pid[r] = (uint8_t)mask;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) sval[(int64_t)k * nrows + r] = v[k];
+    }
+}
+
 // Below this many rows the windowed pattern format (fmt 4) keeps the matrix: a brick march needs a few thousand
 // (brick, chunk) items of >= 8 planes to fill the chip, and a cache-resident product is latency bound either way
 int64_t pencil_min_rows() {
@@ -1111,7 +1148,29 @@ int64_t pencil_min_rows() {
 }
 
 // true: P holds format 9.  false: the matrix is not of the class (P untouched apart from freed scratch).
-bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced) {
+void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP) {
+    P.pen_L = L;
+    P.pen_P = PP;
+    P.pen_nz = (int)(A->nrows / PP);
+    P.pen_bx = (int)(L / 128);
+    P.pen_bpp = (int)(L / 128 * (PP / (4 * L)));
+    // chunks: the kernel keeps two workgroups per CU resident (its register ring), so 512 (brick, chunk) items fill the
+    // chip in one round; more chunks only add pipeline fills and re-read two planes per chunk start (512^3, tools/
+    // r05_pencil_variants.sh: 4 chunks of 132 planes 441 us, 8 of 66 436, one of 516 421).  At least 6 planes per chunk, a
+    // multiple of the ring depth so that only the matrix's last chunk has planes left over.
+    static const char *env_zc = getenv("MK_PENCIL_ZC");
+    int chunks = (512 + P.pen_bpp - 1) / P.pen_bpp;
+    int zc = (P.pen_nz + chunks - 1) / chunks;
+    zc = zc < MK_PEN_R ? MK_PEN_R : zc;
+    if (env_zc && atoi(env_zc) > 0) zc = atoi(env_zc);
+    zc = (zc + MK_PEN_R - 1) / MK_PEN_R * MK_PEN_R;
+    P.pen_zc = zc;
+    P.pen_chunks = (P.pen_nz + zc - 1) / zc;
+}
+
+// want: 9 = dictionary + patterns only; 10 = also the streamed-value twin (format 10) when the matrix has too many values or
+// patterns for format 9
+bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     if (A->nrows != A->ncols || A->nnz > 7 * A->nrows || A->nrows < 1024 || A->alias || A->ex.mode >= 0) return false;
     if (!forced && A->nrows < pencil_min_rows()) return false;
     hipStream_t st = mk_ctx().stream;
@@ -1161,14 +1220,44 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced) {
     if (!reset_set()) return drop();
     int gnz = (int)((A->nnz + MK_BLOCK - 1) / MK_BLOCK);
     hipLaunchKernelGGL(dict_collect, dim3(gnz > 512 ? 512 : gnz), dim3(MK_BLOCK), 0, st, A->nnz, A->d_data, d_table, d_state);
-    if (!read_state() || h_state[1] || h_state[0] > 256 || h_state[0] < 1) return drop();
+    auto stream_twin = [&]() -> bool {                      // format 10: mask byte + seven value arrays
+        if (want < 10) return drop();
+        double *d_sval = nullptr;
+        if (hipMalloc((void **)&d_pid, (size_t)A->nrows + 64) != hipSuccess ||
+            hipMalloc((void **)&d_sval, sizeof(double) * 7 * (size_t)A->nrows + 64) != hipSuccess) {
+            hipFree(d_sval);
+            return drop();
+        }
+        hipMemsetAsync(d_pid, 0, (size_t)A->nrows + 64, st);
+        hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
+        hipLaunchKernelGGL(pen_stream_fill, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, L, PP,
+                           d_pid, d_sval, d_state);
+        if (!read_state() || h_state[1] || hipGetLastError() != hipSuccess) {
+            hipFree(d_sval);
+            return drop();
+        }
+        hipFree(d_stats);
+        hipFree(d_table);
+        hipFree(d_dict);
+        hipFree(d_keys);
+        P.fmt = 10;
+        P.d_pid = d_pid;
+        P.d_sval = d_sval;
+        P.sell_entries = 7 * A->nrows;
+        P.npat = 0;
+        pencil_geometry(A, P, L, PP);
+        return true;
+    };
+    if (!read_state()) return drop();
+    if (h_state[1] || h_state[0] > 256 || h_state[0] < 1) return stream_twin();
     const int ndict = h_state[0];
     hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_dict);
     // the rows' keys
     if (!reset_set()) return drop();
     hipLaunchKernelGGL(pen_rows, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, d_dict, ndict,
                        L, PP, d_table, d_state, (const double *)nullptr, 0, (uint8_t *)nullptr);
-    if (!read_state() || h_state[1] || h_state[0] > 256 || h_state[0] < 1) return drop();
+    if (!read_state()) return drop();
+    if (h_state[1] || h_state[0] > 256 || h_state[0] < 1) return stream_twin();
     const int nkeys = h_state[0];
     hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_keys);
     if (hipMalloc((void **)&d_pid, (size_t)A->nrows + 64) != hipSuccess ||
@@ -1189,23 +1278,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced) {
     P.d_dict = d_dict;
     P.ndict = ndict;
     P.npat = nkeys;
-    P.pen_L = L;
-    P.pen_P = PP;
-    P.pen_nz = (int)(A->nrows / PP);
-    P.pen_bx = (int)(L / 128);
-    P.pen_bpp = (int)(L / 128 * (PP / (4 * L)));
-    // chunks: the kernel keeps two workgroups per CU resident (its register ring), so 512 (brick, chunk) items fill the
-    // chip in one round; more chunks only add pipeline fills and re-read two planes per chunk start (512^3, tools/
-    // r05_pencil_variants.sh: 4 chunks of 132 planes 441 us, 8 of 66 436, one of 516 421).  At least 6 planes per chunk, a
-    // multiple of the ring depth so that only the matrix's last chunk has planes left over.
-    static const char *env_zc = getenv("MK_PENCIL_ZC");
-    int chunks = (512 + P.pen_bpp - 1) / P.pen_bpp;
-    int zc = (P.pen_nz + chunks - 1) / chunks;
-    zc = zc < MK_PEN_R ? MK_PEN_R : zc;
-    if (env_zc && atoi(env_zc) > 0) zc = atoi(env_zc);
-    zc = (zc + MK_PEN_R - 1) / MK_PEN_R * MK_PEN_R;
-    P.pen_zc = zc;
-    P.pen_chunks = (P.pen_nz + zc - 1) / zc;
+    pencil_geometry(A, P, L, PP);
     return true;
 }
 
@@ -1234,7 +1307,7 @@ int plan_build(const mk_csr *A) {
         return MK_OK;
     };
     if (want == 0 || want == 3) return plain();
-    if (want >= 9 && pencil_plan(A, P, A->want_fmt == 9)) return MK_OK;      // fmt 9: 7-point-class matrices beyond the caches
+    if (want >= 9 && pencil_plan(A, P, A->want_fmt >= 9, want)) return MK_OK;   // fmt 9 / 10: 7-point-class matrices
     auto fail = [&](const char *what) {
         plan_free(P);
         P.built = true;
@@ -1308,7 +1381,7 @@ void mk_csr_plan_reset(const mk_csr *A) {
 
 extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {
     MK_REQUIRE_INIT();
-    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 9);
+    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 10);
     if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_format: set the format on the matrix a composed operator was built from");
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
@@ -1322,11 +1395,12 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
     if (fmt) *fmt = P->fmt;
-    if (P->fmt == 9) {                                       // one byte per row + the pattern table; no windows, no tiles
+    if (P->fmt == 9 || P->fmt == 10) {                      // one byte per row + the pattern table (9) / seven values per row (10)
         if (tiles_windowed) *tiles_windowed = 0;
         if (lds_chunks) *lds_chunks = 0;
         if (dict_size) *dict_size = P->ndict;
-        if (matrix_bytes_per_product) *matrix_bytes_per_product = A->nrows + 64 * (int64_t)P->npat;
+        if (matrix_bytes_per_product)
+            *matrix_bytes_per_product = A->nrows + (P->fmt == 9 ? 64 * (int64_t)P->npat : 56 * A->nrows);
         return MK_OK;
     }
     const bool windowed = (P->fmt == 1 || P->fmt == 2 || P->fmt >= 4);
@@ -1406,7 +1480,7 @@ extern "C" int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t
     MK_REQUIRE_INIT();
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
-    const bool on = P->fmt == 9;
+    const bool on = P->fmt == 9 || P->fmt == 10;
     if (stride_line) *stride_line = on ? P->pen_L : 0;
     if (stride_plane) *stride_plane = on ? P->pen_P : 0;
     if (planes) *planes = on ? P->pen_nz : 0;

@@ -39,7 +39,9 @@
 // neighbours are the vector entries r +- 1, r +- L, r +- P): no grid geometry is assumed beyond the three strides.
 //
 // Fused dots: lane (w, l) of a workgroup owns the rows z P + c, z P + c + 1 (c = brick base + w L + 2 l) of its items
-// (item = brick + bricks_per_plane * chunk; items blockIdx, blockIdx + grid, ...), and adds their terms plane by plane,
+// (items blockIdx, blockIdx + grid, ...; item i = brick (i % 8) bpp / 8 + (i / 8) % (bpp / 8) of chunk (i / 8) / (bpp / 8)
+// when the bricks per plane bpp and the grid are multiples of 8 -- an XCD-contiguous deal --, else brick i % bpp of chunk
+// i / bpp), and adds their terms plane by plane,
 // row c before row c + 1 (the tests restate this order on the host to demand bit equality).
 
 // Optional epilogue hook set "fuse" (CG, mk_cg.hip): the product's input vector is FORMED on the fly from the previous
@@ -72,7 +74,11 @@ constexpr int MK_PEN_RS = 132;                               // LDS row: [0] pad
 constexpr int MK_PEN_LDS = 3 * 6 * MK_PEN_RS + MK_BLOCK;     // doubles: two plane images of 6 rows + the dump rows (lanes without an
                                                              // edge row store there, at the same buffer offset as the others)
 
-template <bool PROG, class Epi, int NACC>
+// STREAM (storage format 10): the same march for matrices of the class WITHOUT a value dictionary (variable coefficients):
+// the byte per row is the row's 7-bit presence mask itself and the values are streamed from seven arrays in column-position-
+// major order, sval[k * nrows + r] = the value at offset k of row r or +0.0 (one 16-byte non-temporal load per position and
+// lane and plane, two planes ahead): 56 B per row of values -- what fmt 5 streams -- with every x entry loaded once.
+template <bool PROG, bool STREAM, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
                                                    double *smem, double (&acc)[NACC]) {
     constexpr int R = MK_PEN_R, RS = MK_PEN_RS, BUF = 6 * MK_PEN_RS;
@@ -86,22 +92,39 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     const int64_t last = A.nrows - 1;
     const uint8_t *pid = A.pid;
     // the pattern table, 16 words per pattern, behind the plane images (read-only after this copy)
-    unsigned *ptl = reinterpret_cast<unsigned *>(smem + MK_PEN_LDS);
-    for (int e = tid; e < 16 * A.npat; e += MK_BLOCK) ptl[e] = reinterpret_cast<const unsigned *>(A.ptab)[e];
-    __syncthreads();
-    double va[7], vb[7];                                     // this lane's two rows: values and AND masks of the 7 candidates
-    unsigned ma[7], mb[7], pprev = 0xffffffffu;
+    [[maybe_unused]] unsigned *ptl = reinterpret_cast<unsigned *>(smem + MK_PEN_LDS);
+    if constexpr (!STREAM) {
+        for (int e = tid; e < 16 * A.npat; e += MK_BLOCK) ptl[e] = reinterpret_cast<const unsigned *>(A.ptab)[e];
+        __syncthreads();
+    }
+    [[maybe_unused]] double va[7], vb[7];                    // this lane's two rows: values and AND masks of the 7 candidates
+    [[maybe_unused]] unsigned ma[7], mb[7], pprev = 0xffffffffu;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         va[k] = vb[k] = 0.0;
         ma[k] = mb[k] = 0u;
     }
+    constexpr int VD = 2;                                    // STREAM: planes of values in flight (slot = plane parity)
+    [[maybe_unused]] mk_d2 vr[STREAM ? VD : 1][7];
     double *cdst = smem + (1 + w) * RS + 2 + 2 * l;
     double *hdst = smem + (tid < 128 ? 0 : 5) * RS + 2 + (tid & 127);
     double *edst = tid < 8 ? smem + (1 + (tid & 3)) * RS + ((tid & 4) ? 130 : 1) : smem + 2 * BUF + tid;
 
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const int bi = (int)(item % bpp), chunk = (int)(item / bpp);
+        // item -> (brick, chunk).  Workgroup b runs on XCD b % 8 and every XCD has its own L2: with bricks dealt round robin the
+        // halo rows of a brick -- the own rows of its neighbours in y -- always belong to another XCD and cross the fabric a
+        // second time (fused CG kernel at 512^3: 4.98 GB read for 3.35 GB of operands, profiles/r05_*).  So XCD k takes the
+        // k-th contiguous eighth of a plane's bricks (whole brick rows when the plane has a multiple of 8 of them).
+        int bi, chunk;
+        if ((bpp & 7) == 0 && (gridDim.x & 7) == 0) {
+            const int per = bpp >> 3;
+            const int64_t q = item >> 3;
+            chunk = (int)(q / per);
+            bi = (int)(item & 7) * per + (int)(q % per);
+        } else {
+            bi = (int)(item % bpp);
+            chunk = (int)(item / bpp);
+        }
         const int z0 = chunk * zc, z1 = (z0 + zc < nz) ? z0 + zc : nz;
         const int64_t b0 = (int64_t)(bi / bx) * 4 * L + (int64_t)(bi % bx) * 128;    // the brick's first row in plane 0
         const int64_t c = b0 + (int64_t)w * L + 2 * l;                                // this lane's rows c, c + 1 (in-plane index)
@@ -157,13 +180,29 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             else return pv;
         };
         // one plane: slots (xm, xc, xp) = planes zz-1, zz, zz+1 at the own rows; hv / ev / pp = halo rows and pattern bytes of plane zz
+        [[maybe_unused]] auto vals = [&](int p, int sl) {     // STREAM: the 14 values of the own rows of plane p
+            if constexpr (STREAM) {
+                p = p > nz - 1 ? nz - 1 : p;
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                    vr[sl][k] = __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(A.sval + (int64_t)k * A.nrows + (int64_t)p * P + c));
+            }
+        };
         auto step = [&](int zz, int bo, const mk_d2 xm_, const mk_d2 xc_, const mk_d2 xp_, double hv, double ev, unsigned pp,
-                        auto &&reload) {
+                        const mk_d2 (&vv)[7], auto &&reload, auto &&after) {
             mk_d2 xm, xc, xp;
             xm.x = epi.xin(xm_.x); xm.y = epi.xin(xm_.y);
             xc.x = epi.xin(xc_.x); xc.y = epi.xin(xc_.y);
             xp.x = epi.xin(xp_.x); xp.y = epi.xin(xp_.y);
-            if (__builtin_amdgcn_ballot_w64(pp != pprev) != 0) {  // (wave uniform) a row of this wave follows another pattern now
+            if constexpr (STREAM) {                          // the byte IS the mask; the values arrived with the plane
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    va[k] = vv[k].x;
+                    vb[k] = vv[k].y;
+                    ma[k] = (unsigned)__builtin_amdgcn_sbfe((int)pp, k, 1);
+                    mb[k] = (unsigned)__builtin_amdgcn_sbfe((int)pp, 8 + k, 1);
+                }
+            } else if (__builtin_amdgcn_ballot_w64(pp != pprev) != 0) {  // (wave uniform) a row of this wave follows another pattern now
                 const mk_u4 *ta = reinterpret_cast<const mk_u4 *>(ptl + 16 * (pp & 0xffu));
                 const mk_u4 *tb = reinterpret_cast<const mk_u4 *>(ptl + 16 * (pp >> 8));
                 const mk_u4 a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3], b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3];
@@ -207,6 +246,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 if constexpr (MkHasPre<Epi>::value) epi.pre(r + 1);
                 epi.row(r + 1, sb, acc);
             }
+            after();
         };
         const int zfull = z0 + ((z1 - z0) / R) * R;          // planes of the pipelined rounds; the rest one by one below
         if (zfull > z0) {
@@ -220,6 +260,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             for (int d = 0; d < R - 1; ++d) {                 // (issue order = consumption order; slot R - 1 is loaded by step 0)
                 ring[d] = plane(z0 - 1 + d);
                 if (d < H) halo(z0 + d, d);
+                if (d < VD) vals(z0 + d, d);
                 if constexpr (FUSE) {
                     if (d < H) {                              // plane z0 + 1 + d -> slot (1 + d) % H
                         rr[(1 + d) % H] = plane_of(epi.fuse_r, z0 + 1 + d);
@@ -242,7 +283,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                     const int zz = z + d;
                     if constexpr (FUSE) transform(ring[(d + 2) % R], rr[(d + 1) % H], xx[(d + 1) % H], zz + 1, true);
                     step(zz, (d & 1) * BUF, ring[d], ring[(d + 1) % R], ring[(d + 2) % R], halo_val(hreg[d % H], hr[FUSE ? d % H : 0]),
-                         halo_val(ereg[d % H], er[FUSE ? d % H : 0]), pidr[d % H], [&]() {
+                         halo_val(ereg[d % H], er[FUSE ? d % H : 0]), pidr[d % H], vr[STREAM ? d % VD : 0], [&]() {
                              __builtin_amdgcn_sched_barrier(0);   // (the slots' last uses stay ABOVE their reloads)
                              ring[(d + R - 1) % R] = plane(zz + R - 2);   // the slot of plane zz - 2: dead since the last step
                              halo(zz + H, d % H);
@@ -250,7 +291,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                                  rr[(d + 1) % H] = plane_of(epi.fuse_r, zz + 1 + H);
                                  xx[(d + 1) % H] = plane_of(epi.fuse_x, zz + 1 + H);
                              }
-                         });
+                         }, [&]() { vals(zz + VD, d % VD); });   // (values: their slot is free once the row sums are formed)
                 }
                 z += R;
             } while (z < zfull);
@@ -268,7 +309,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 else transform(xc, rb, rb, zz, false);
                 transform(xp, rc, xcn, zz + 1, true);
             }
-            step(zz, ((zz - zfull) & 1) * BUF, xm, xc, xp, halo_val(hreg[0], hr[0]), halo_val(ereg[0], er[0]), pidr[0], [] {});
+            vals(zz, 0);
+            step(zz, ((zz - zfull) & 1) * BUF, xm, xc, xp, halo_val(hreg[0], hr[0]), halo_val(ereg[0], er[0]), pidr[0], vr[0], [] {}, [] {});
         }
         __syncthreads();                                     // the next item's first plane image overwrites this LDS
     }

@@ -228,7 +228,7 @@ def test_non_temporal_accesses_are_the_default_beyond_the_infinity_cache(op512):
 
 # ------------------------------------------------------------------------------------------------------------
 # The workload bench.py's default line is quoted on: poisson3d-512-varcoef with the production defaults
-# (storage format 5, non-temporal accesses, tile order 2).  VERDICT r3 item 1.
+# (round 5: storage format 10, the brick march with streamed values; rounds 3-4: format 5).  VERDICT r3 item 1.
 # ------------------------------------------------------------------------------------------------------------
 VSEED = 7                                                                   # bench.VARCOEF_SEED
 PLANE = M * M
@@ -253,11 +253,12 @@ def test_varcoef_512_runs_with_the_production_defaults(op512v):
     tiles, mbytes = ctypes.c_int64(), ctypes.c_int64()
     _lib.check(lib.mk_csr_format_info(op512v.handle, ctypes.byref(fmt), ctypes.byref(tiles), ctypes.byref(chunks),
                                       ctypes.byref(nd), ctypes.byref(mbytes)))
-    assert fmt.value == 5 and tiles.value == N // 256
-    assert mbytes.value < 8.3 * NNZ                                         # 8 B / nonzero + 1 B / row + descriptors
+    # round 5: the brick march with streamed values (format 10: 7 values + 1 mask byte per row) is the production default
+    assert fmt.value == 10 and tiles.value == 0
+    assert mbytes.value == 57 * N                                           # 56 B / row of values + 1 B / row
     o, s, p, nt = (ctypes.c_int32() for _ in range(4))
     _lib.check(lib.mk_csr_tile_order(op512v.handle, ctypes.byref(o), ctypes.byref(s), ctypes.byref(p), ctypes.byref(nt)))
-    assert (o.value, nt.value) == (2, 1)
+    assert nt.value == 1
     assert op512v.shape == (N, N) and op512v.nnz == NNZ
     x.free()
     y.free()
@@ -265,7 +266,7 @@ def test_varcoef_512_runs_with_the_production_defaults(op512v):
 
 def test_varcoef_512_slabs_bit_exact_against_the_oracle(op512v):
     """Four 4-plane slabs (first, last, two interior) of the 512^3 variable-coefficient matrix: the generated CSR
-    arrays and the product of the PRODUCTION kernel (format 5, non-temporal, tile order 2) on a seeded x, both bit for
+    arrays and the product of the PRODUCTION kernel (format 10 since round 5) on a seeded x, both bit for
     bit against the NumPy twin's rows and the oracle's scalar left-to-right loop."""
     from pykrylov_amd import _lib
     rng = np.random.default_rng(2024)

@@ -28,10 +28,10 @@ def pencil_info(op):
     return dict(L=sl.value, P=sp.value, planes=nz.value, zc=zc.value, chunks=ch.value, patterns=npat.value)
 
 
-def op9(A, symmetric=False):
+def op9(A, symmetric=False, fmt=9):
     from pykrylov_amd import CsrOperator, _lib
     op = CsrOperator(A.indptr, A.indices, A.data, A.shape, symmetric=symmetric)
-    _lib.check(_lib.init().mk_csr_set_format(op.handle, 9))
+    _lib.check(_lib.init().mk_csr_set_format(op.handle, fmt))
     return op
 
 
@@ -103,13 +103,17 @@ def test_matrices_outside_the_class_degrade():
     rng = np.random.default_rng(1)
     for A in (csr_ref.poisson3d(100, 8, 8),                   # L = 100: not a multiple of 128
               csr_ref.poisson2d(256),                         # no plane stride
-              csr_ref.poisson3d_varcoef(128, 8, 8),           # > 256 distinct values
+              csr_ref.poisson3d_varcoef(128, 8, 8),           # > 256 distinct values (format 10's class: asked for 9 only)
               csr_ref.stencil27(128, 8, 4)):                  # 27 offsets
-        op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
-        _lib.check(_lib.init().mk_csr_set_format(op.handle, 9))
-        x = rng.standard_normal(A.shape[1])
-        assert np.array_equal(op * x, A.matvec(x))
-        assert fmt_of(op) != 9 and pencil_info(op)["L"] == 0
+        for want in (9, 10):
+            op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
+            _lib.check(_lib.init().mk_csr_set_format(op.handle, want))
+            x = rng.standard_normal(A.shape[1])
+            assert np.array_equal(op * x, A.matvec(x))
+            if want == 10 and A.nnz > 6 * A.shape[0] and A.nnz <= 7 * A.shape[0] and A.shape[0] == 128 * 8 * 8:
+                assert fmt_of(op) == 10                        # (the variable-coefficient matrix IS of format 10's class)
+            else:
+                assert fmt_of(op) not in (9, 10) and pencil_info(op)["L"] == 0
 
 
 @pytest.mark.parametrize("dims", [(128, 8, 9), (256, 8, 26)])
@@ -219,3 +223,63 @@ def test_fused_cg_passes_change_no_bit(dims, monkeypatch):
         assert len(a[5]) == len(b[5]) and all(np.array_equal(u, v) for u, v in zip(a[5], b[5]))
         assert len(a[6]) == len(b[6]) and all(np.array_equal(u, v) for u, v in zip(a[6], b[6]))
     assert len(out["1"][3][5]) >= 12                                    # (the store_iterates case really kept iterates)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# storage format 10: the brick march with streamed values (matrices of the class without a value dictionary)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dims", [(128, 4, 2), (128, 8, 9), (256, 4, 13), (128, 12, 31), (256, 16, 24)])
+def test_format10_variable_coefficients_product_bit_exact(dims):
+    A = csr_ref.poisson3d_varcoef(*dims, seed=7)
+    op = op9(A, fmt=10)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(A.shape[1])
+    y = op * x
+    assert fmt_of(op) == 10
+    info = pencil_info(op)
+    assert (info["L"], info["P"], info["planes"]) == (dims[0], dims[0] * dims[1], dims[2])
+    assert np.array_equal(y, A.matvec(x))
+    x[::5] = 0.0
+    x[3::7] *= -1e200
+    assert np.array_equal(op * x, A.matvec(x))
+
+
+def test_format10_generic_band_with_many_values():
+    """Any subset of the seven offsets per row, every value different (no dictionary), an infinity in x next to entries a
+    row does not have."""
+    n, L, P = 128 * 8 * 12, 128, 1024
+    rng = np.random.default_rng(11)
+    A = banded7(n, L, P, rng, combos=60, drop=0.4)
+    A.data[:] = rng.standard_normal(A.nnz)                   # (all different: format 9 cannot take it)
+    op = op9(A, fmt=10)
+    x = rng.standard_normal(n)
+    assert np.array_equal(op * x, A.matvec(x)) and fmt_of(op) == 10
+    j = int(rng.integers(P, n - P))
+    x[j] = np.inf
+    with np.errstate(invalid="ignore"):
+        ref = A.matvec(x)
+    got = op * x
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert np.array_equal(got[fin], ref[fin])
+
+
+@pytest.mark.parametrize("dims", [(128, 8, 9), (256, 8, 26)])
+def test_format10_cg_fused_bit_exact_and_equal_to_the_three_kernel_pass(dims, monkeypatch):
+    from pykrylov_amd import CG
+    A = csr_ref.poisson3d_varcoef(*dims, seed=7)
+    n = A.shape[0]
+    rhs = A.matvec(np.ones(n))
+    runs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MK_CG_FUSE", fuse)
+        op = op9(A, symmetric=True, fmt=10)
+        assert _solver_is_fused(op, rhs) == (fuse == "1")
+        s = CG(op)
+        s.solve(rhs, matvec_max=150)
+        assert fmt_of(op) == 10
+        runs[fuse] = (s.nMatvec, np.array(s.residHistory), s.x.copy())
+        geo = gpu_order.launch_geometry(op)
+    assert runs["1"][0] == runs["0"][0] and np.array_equal(runs["1"][1], runs["0"][1]) and np.array_equal(runs["1"][2], runs["0"][2])
+    ref = krylov_ref.cg(A, rhs, matvec_max=150, red=krylov_ref.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geometry=geo)))
+    assert runs["1"][0] == ref["nMatvec"] and np.array_equal(runs["1"][1], ref["residHistory"]) and np.array_equal(runs["1"][2], ref["x"])
