@@ -1307,7 +1307,8 @@ int plan_build(const mk_csr *A) {
         return MK_OK;
     };
     if (want == 0 || want == 3) return plain();
-    if (want >= 9 && pencil_plan(A, P, A->want_fmt >= 9, want)) return MK_OK;   // fmt 9 / 10: 7-point-class matrices
+    if (want >= 9 && (A->march_pref != 0 || A->want_fmt >= 9) && pencil_plan(A, P, A->want_fmt >= 9, want))
+        return MK_OK;                                        // fmt 9 / 10: 7-point-class matrices (mk_csr_march_pref)
     auto fail = [&](const char *what) {
         plan_free(P);
         P.built = true;
@@ -1377,6 +1378,25 @@ const MkPlan *mk_csr_plan(const mk_csr *A) {
 
 void mk_csr_plan_reset(const mk_csr *A) {
     plan_free(A->plan);
+}
+
+// The brick march is a per-MATRIX format, but whether it pays depends on the LOOP: CG's product epilogue (and a plain
+// product's) loads nothing, so the march's software pipeline runs undisturbed (512^3: CG 442 -> 582 passes per second);
+// the other loops' epilogues load their vectors inside the pipelined loop and every such load waits for everything issued
+// before it (512^3: MINRES 369 -> 292, SYMMLQ 357 -> 270, BiCGSTAB 254 -> 229; tools/r05_solvers_on_bricks.py).  So the
+// solver being created says what it is, and an automatically chosen format follows the last one -- unless other solvers
+// are alive on the matrix (their partial-sum counts were sized for the format in use) or the caller fixed the format.
+void mk_csr_march_pref(const mk_csr *A, int pref) {
+    const mk_csr *o = A->base ? A->base : A;
+    if (o->want_fmt >= 9 || o->comp_kind || o->host_fn) return;
+    if (o->solver_users > 0 && o->plan.built) return;
+    o->march_pref = pref;
+    if (!o->plan.built) return;
+    const bool march = o->plan.fmt == 9 || o->plan.fmt == 10;
+    if ((pref == 0 && march) || (pref == 1 && !march && o->nrows >= pencil_min_rows() && o->nnz <= 7 * o->nrows && o->ex.mode < 0)) {
+        hipStreamSynchronize(mk_ctx().stream);
+        plan_free(o->plan);
+    }
 }
 
 extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {

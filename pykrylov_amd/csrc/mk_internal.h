@@ -187,6 +187,11 @@ struct mk_csr {
     // operands of composites are borrowed: they count their dependents, and a matrix destroyed while composites still
     // use it lives on until the last of them goes (mk_csr_destroy)
     mutable int dependents = 0;
+    // brick-march formats (9 / 10) are chosen per matrix but pay only for loops whose product epilogue loads nothing inside
+    // the march's pipelined loop (CG, plain products): -1 no solver has asked yet (march allowed), 1 the last solver created
+    // on this matrix was CG, 0 another loop (its products keep the windowed formats 4 / 5); mk_csr_march_pref, mk_format.hip
+    mutable int march_pref = -1;
+    mutable int solver_users = 0;  // live solvers on this matrix (the preference only changes while there is none)
     mutable bool doomed = false;
     double *d_comp_tmp = nullptr;  // first product's row sums (sum / difference) or B x (product)
     // matrix-free operator (mk_csr_create_callback): no arrays; products come from a host callback
@@ -209,6 +214,7 @@ struct mk_csr {
 int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out);
 void mk_release_operand(const mk_csr *B);   // a borrower lets go: the matrix is destroyed now if its owner already asked for it
 void mk_csr_plan_reset(const mk_csr *A);    // drop the windowed format (it is rebuilt on the next product)
+void mk_csr_march_pref(const mk_csr *A, int pref);   // a solver is being created on A: 1 = CG, 0 = any other loop
 
 // grid sizes -------------------------------------------------------------------------
 // Persistent-style grids: at most `cap` workgroups which stride over the work.  The caps are tuning

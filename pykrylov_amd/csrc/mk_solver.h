@@ -68,6 +68,7 @@ struct mk_solver {
     int64_t q = 0;                  // kernels launched so far (halt parity)
     int64_t it = 0;                 // loop passes enqueued so far
     bool is_setup = false, halted = false;
+    bool counted_user = false;      // this solver is in its matrix's solver_users count (mk_csr_march_pref)
     int np_spmv = 1, np_stream = 1; // partial counts consumers must add up
 
     // timing

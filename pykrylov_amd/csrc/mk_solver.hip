@@ -72,6 +72,7 @@ mk_solver::~mk_solver() {
     if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
     if (precon_op) mk_release_operand(precon_op);
     if (At) mk_release_operand(At);
+    if (A && counted_user) (A->base ? A->base : A)->solver_users -= 1;
     if (A) mk_release_operand(A);
     hipFree(d_ones);
     hipFree(d_ptmp);
@@ -281,11 +282,14 @@ extern "C" int mk_solver_create(const mk_csr *A, const mk_params *params, mk_sol
         default: break;
     }
     if (!s) return mk_fail(MK_ERR_UNSUPPORTED, "mk_solver_create: solver kind %d is not available", params->kind);
+    mk_csr_march_pref(A, params->kind == MK_CG ? 1 : 0);     // (before the partial-sum counts are sized for the format in use)
     int rc = s->init_common(A, params);
     if (rc != MK_OK) {
         delete s;
         return rc;
     }
+    (A->base ? A->base : A)->solver_users += 1;
+    s->counted_user = true;
     *out = s;
     return MK_OK;
 }

@@ -11,6 +11,8 @@ from oracle import csr_ref, gpu_order, krylov_ref
 
 pytestmark = pytest.mark.gpu
 
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
 
 def fmt_of(op):
     from pykrylov_amd import _lib
@@ -283,3 +285,44 @@ def test_format10_cg_fused_bit_exact_and_equal_to_the_three_kernel_pass(dims, mo
     assert runs["1"][0] == runs["0"][0] and np.array_equal(runs["1"][1], runs["0"][1]) and np.array_equal(runs["1"][2], runs["0"][2])
     ref = krylov_ref.cg(A, rhs, matvec_max=150, red=krylov_ref.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geometry=geo)))
     assert runs["1"][0] == ref["nMatvec"] and np.array_equal(runs["1"][1], ref["residHistory"]) and np.array_equal(runs["1"][2], ref["x"])
+
+
+def test_automatic_march_follows_the_loop(monkeypatch):
+    """The brick march is chosen per matrix but pays only for loops whose product epilogue loads nothing (CG, plain
+    products): an automatically formatted matrix of the class is in format 9 for a plain product and for CG, goes back to
+    the windowed pattern format when a MINRES solver is created on it, and returns to format 9 for the next CG -- with the
+    same bits as the forced formats every time.  (MK_PENCIL_MIN_ROWS lowered so that a small grid qualifies.)"""
+    from pykrylov_amd import CG, Minres, CsrOperator
+    monkeypatch.setenv("MK_PENCIL_MIN_ROWS", "1024")
+    # (the threshold is read once per process: run in a child so that the variable is seen)
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import csr_ref
+from pykrylov_amd import CG, Minres, CsrOperator, _lib
+def fmt_of(op):
+    f = ctypes.c_int32()
+    _lib.check(_lib.init().mk_csr_format_info(op.handle, ctypes.byref(f), None, None, None, None))
+    return f.value
+A = csr_ref.poisson3d(128, 8, 12)
+n = A.shape[0]
+rhs = A.matvec(np.ones(n))
+op = CsrOperator(A.indptr, A.indices, A.data, A.shape, symmetric=True)
+x = np.random.default_rng(0).standard_normal(n)
+assert np.array_equal(op * x, A.matvec(x)) and fmt_of(op) == 9
+c = CG(op); c.solve(rhs); assert fmt_of(op) == 9
+m = Minres(op); m.solve(rhs, show=False, check=False, etol=0.0, rtol=1e-10); assert fmt_of(op) == 4, fmt_of(op)
+c2 = CG(op); c2.solve(rhs); assert fmt_of(op) == 9
+assert c.nMatvec == c2.nMatvec and np.array_equal(np.array(c.residHistory), np.array(c2.residHistory)) and np.array_equal(c.x, c2.x)
+forced = CsrOperator(A.indptr, A.indices, A.data, A.shape, symmetric=True)
+_lib.check(_lib.init().mk_csr_set_format(forced.handle, 4))
+m4 = Minres(forced); m4.solve(rhs, show=False, check=False, etol=0.0, rtol=1e-10)
+assert m.itn == m4.itn and np.array_equal(np.array(m.residHistory), np.array(m4.residHistory)) and np.array_equal(m.x, m4.x)
+print("OK")
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(__import__("os").environ, MK_PENCIL_MIN_ROWS="1024"))
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout[-2000:] + p.stderr[-3000:]
