@@ -326,3 +326,29 @@ print("OK")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(__import__("os").environ, MK_PENCIL_MIN_ROWS="1024"))
     assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_fused_cg_negative_curvature_leaves_nothing_pending(monkeypatch):
+    """An indefinite matrix of the class: CG meets p'Ap <= 0 after a few passes (cg.py:119-124), the pass is abandoned BEFORE
+    its x update -- the fused loop must not apply a pending update then.  Fused, three-kernel and oracle agree bit for bit."""
+    from pykrylov_amd import CG
+    A = csr_ref.poisson3d(128, 8, 10)
+    n = A.shape[0]
+    diag = A.indices == np.repeat(np.arange(n), np.diff(A.indptr))
+    data = A.data.copy()
+    data[diag] = 2.5                                         # (inside the spectrum of the off-diagonal part: indefinite)
+    B = csr_ref.RefCsr(A.indptr, A.indices, data, A.shape)
+    rhs = B.matvec(np.cos(np.arange(n)))
+    got = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MK_CG_FUSE", fuse)
+        op = op9(B, symmetric=True)
+        s = CG(op)
+        s.solve(rhs, matvec_max=60)
+        assert fmt_of(op) == 9
+        got[fuse] = (s.nMatvec, np.array(s.residHistory), s.x.copy(), s.definite, getattr(s, "infiniteDescent", None))
+        geo = gpu_order.launch_geometry(op)
+    assert got["1"][3] is False or got["1"][3] == 0          # negative curvature was met
+    assert got["1"][0] == got["0"][0] and np.array_equal(got["1"][1], got["0"][1]) and np.array_equal(got["1"][2], got["0"][2])
+    ref = krylov_ref.cg(B, rhs, matvec_max=60, red=krylov_ref.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geometry=geo)))
+    assert got["1"][0] == ref["nMatvec"] and np.array_equal(got["1"][1], ref["residHistory"]) and np.array_equal(got["1"][2], ref["x"])
