@@ -384,6 +384,85 @@ __global__ __launch_bounds__(BLOCK, 8) void cb_pair(int T, int K, int n, int W, 
     }
 }
 
+// pair2 : VERDICT r4 item 3 priced -- the two ingests of a pair OVERLAPPED: tile B's stream and tile A's stream are DMA'd
+//         into TWO LDS buffers back to back, one wait, B's rows go to registers, then the phases walk A in the second
+//         buffer.  Costs twice the LDS per workgroup (36 KB: 4 resident workgroups per CU instead of 8).  HALF = 1 prices
+//         the occupancy loss alone: the production order of ingests, but with the doubled LDS allocation.
+template <int HALF>
+__global__ __launch_bounds__(BLOCK, 4) void cb_pair2(int T, int K, int n, int W, const int* __restrict__ ip,
+                                                     const int* __restrict__ cols, const double* __restrict__ vals,
+                                                     const double* __restrict__ x, double* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(x), 0, 0x7fffffff, 0x00020000);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    auto bufv = [&](int b) { return (double*)(smem + (size_t)b * RCAP * 12); };
+    auto bufc = [&](int b) { return (int*)(bufv(b) + RCAP); };
+    auto issue = [&](int t, int b, int& cur, int& fin) {
+        double* lv = bufv(b); int* lc = bufc(b);
+        const int row0 = t * ROWS, rowe = min(n, row0 + ROWS);
+        const int e0 = ip[row0], e1 = ip[rowe];
+        const int base = e0 & ~3, cnt = e1 - base;
+        const int last = (cnt > 0) ? ((cnt - 1) & ~3) : 0;
+        for (int c0 = wv * 256; c0 < cnt; c0 += 4 * 256) {
+            int j = c0 + 4 * lane; j = j < last ? j : last;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cols + base + j),
+                                             (__attribute__((address_space(3))) void*)(lc + c0), 16, 0, 0);
+        }
+        const int lastv = (cnt > 0) ? ((cnt - 1) & ~1) : 0;
+        for (int c0 = wv * 128; c0 < cnt; c0 += 4 * 128) {
+            int j = c0 + 2 * lane; j = j < lastv ? j : lastv;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vals + base + j),
+                                             (__attribute__((address_space(3))) void*)(lv + c0), 16, 0, 0);
+        }
+        cur = fin = 0;
+        const int r = row0 + threadIdx.x;
+        if (r < rowe) { cur = ip[r] - base; fin = ip[r + 1] - base; }
+    };
+    for (int pos = blockIdx.x; pos < T; pos += 2 * gridDim.x) {
+        unsigned ob[5]; double vb[5]; double sumb = 0.0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { ob[j] = 0xffffffffu; vb[j] = 0.0; }
+        const int posb = pos + gridDim.x;
+        const bool has_b = posb < T;
+        int curb = 0, finb = 0, cur, fin; double sum = 0.0;
+        if (HALF) {                                          // production order, doubled allocation
+            if (has_b) { issue(posb, 0, curb, finb); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        } else {
+            if (has_b) issue(posb, 0, curb, finb);
+            issue(pos, 1, cur, fin);                         // both streams in flight together
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (has_b) {
+            const double* lv = bufv(0); const int* lc = bufc(0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { const bool has = curb + j < finb; const int idx = has ? curb + j : 0; const unsigned cc = (unsigned)lc[idx] << 3; const double vv = lv[idx]; ob[j] = has ? cc : 0xffffffffu; vb[j] = has ? vv : 0.0; }
+        }
+        if (HALF) { __syncthreads(); issue(pos, 1, cur, fin); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        const double* lv = bufv(1); const int* lc = bufc(1);
+        for (int k = 0; k < K; ++k) {
+            const int c1 = (k + 1 < K) ? (k + 1) * W : 0x7fffffff;
+            const unsigned o_lo = (unsigned)(k * W) << 3, o_hi = (k + 1 < K) ? (unsigned)c1 << 3 : 0xffffffffu;
+            double xb[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { xb[j] = 0.0; if (ob[j] >= o_lo && ob[j] < o_hi) { const u2 w = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(xres, (int)ob[j], 0, 0)); xb[j] = __builtin_bit_cast(double, w); } }
+            for (;;) {
+                int ca = 0x7fffffff;
+                if (cur < fin) ca = lc[cur];
+                const bool oa = ca < c1;
+                if (oa) { const u2 w = __builtin_bit_cast(u2, __builtin_amdgcn_raw_buffer_load_b64(xres, ca << 3, 0, 0)); sum += lv[cur] * __builtin_bit_cast(double, w); cur += 1; }
+                if (!__any(oa)) break;
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { const bool in = ob[j] >= o_lo && ob[j] < o_hi; const double t = sumb + vb[j] * xb[j]; sumb = in ? t : sumb; }
+        }
+        { const long r = (long)pos * ROWS + threadIdx.x; if (r < n) y[r] = sum; }
+        if (has_b) { const long r = (long)posb * ROWS + threadIdx.x; if (r < n) y[r] = sumb; }
+        __syncthreads();
+    }
+}
+
 // gath : the raw cost of the gathers alone: out[lane] = sum of x[idx[j]] over a grid-stride range (no values, no rows)
 template <int U>
 __global__ __launch_bounds__(BLOCK) void gath(long nnz, const int* __restrict__ idx, const double* __restrict__ x, double* __restrict__ out) {
@@ -557,6 +636,18 @@ int main(int argc, char** argv) {
             for (int k = 0; k < NS; ++k) { long long lo = 1LL << 62, hi = 0; double av = 0; for (int b = 0; b < G; ++b) { long long v = h[(size_t)k * G + b] - t0; lo = std::min(lo, v); hi = std::max(hi, v); av += v; }
                 printf("  pair=%d stamp %d: min %.2f us  mean %.2f us  max %.2f us\n", pair, k, lo / 100.0, av / G / 100.0, hi / 100.0); }
             CK(hipFree(dts)); }
+        if (getenv("PAIR_OVL")) {                          // item 3 priced: overlapped ingests at twice the LDS / half the occupancy
+            const size_t lds2 = (size_t)RCAP * 24;
+            for (int G : {2048, 1024}) {
+                CK(hipMemset(dy, 0, 8L * n));
+                float m0 = timeit([&] { hipLaunchKernelGGL((cb_pair2<0>), dim3(G), dim3(BLOCK), lds2, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy); }, reps);
+                check("pair2 overlapped");
+                CK(hipMemset(dy, 0, 8L * n));
+                float m1 = timeit([&] { hipLaunchKernelGGL((cb_pair2<1>), dim3(G), dim3(BLOCK), lds2, 0, T, K, n, (int)W, dip, dix, ddv, dx, dy); }, reps);
+                check("pair2 serial");
+                printf("K=%2d pair2 grid=%4d (LDS %zu B per workgroup: 4 per CU): ingests overlapped %7.1f us, ingests in series %7.1f us\n", K, G, lds2, m0 * 1e3, m1 * 1e3);
+            }
+        }
         if (getenv("PAIR_ONLY")) { CK(hipFree(dseg)); CK(hipFree(dcols)); CK(hipFree(dvals)); CK(hipFree(dro)); continue; }
         if (getenv("REG_TS")) for (int mode = 1; mode <= 2; ++mode) {
             const int G = (g2 + 7) / 8 * 8; std::vector<long long> h((size_t)(K + 2) * G); long long* dts; CK(hipMalloc(&dts, 8 * h.size()));
