@@ -29,6 +29,12 @@ struct BEpi {    // v = A p, fused <r0, v>
         mk_store_stream(v + r, s, nt);
         acc[0] += r0[r] * s;
     }
+    static constexpr int NPF = 1;                         // pipelined kernels: r0[r] arrives as o[0]
+    __device__ const double *pf_vec(int) const { return r0; }
+    __device__ void row_pf(int64_t r, double s, const double *o, double *acc) {
+        mk_store_stream(v + r, s, nt);
+        acc[0] += o[0] * s;
+    }
 };
 
 struct GateB {   // loop test after ||r|| (bicgstab.py:139-145), then the product is counted (:101)
@@ -109,6 +115,14 @@ struct DEpi {    // t = A s, fused <t,s>, <t,t>, <r0,t>
         acc[0] += sum * s[r];
         acc[1] += sum * sum;
         acc[2] += r0[r] * sum;
+    }
+    static constexpr int NPF = 2;                         // pipelined kernels: s[r], r0[r] arrive as o[0], o[1]
+    __device__ const double *pf_vec(int j) const { return j == 0 ? s : r0; }
+    __device__ void row_pf(int64_t r, double sum, const double *o, double *acc) {
+        mk_store_stream(t + r, sum, nt);
+        acc[0] += sum * o[0];
+        acc[1] += sum * sum;
+        acc[2] += o[1] * sum;
     }
 };
 

@@ -26,6 +26,12 @@ struct BEpi {    // v = A p, fused <r0, v>; the product is counted by its gate
         mk_store_stream(v + r, s, nt);
         acc[0] += r0[r] * s;
     }
+    static constexpr int NPF = 1;                         // pipelined kernels: r0[r] arrives as o[0]
+    __device__ const double *pf_vec(int) const { return r0; }
+    __device__ void row_pf(int64_t r, double s, const double *o, double *acc) {
+        mk_store_stream(v + r, s, nt);
+        acc[0] += o[0] * s;
+    }
 };
 
 struct CountGate {   // no test, only `nMatvec += 1` (cgs.py:83, :95)
@@ -114,6 +120,14 @@ struct DEpi {    // Az = A z ; r -= alpha Az ; <r,r>, <r0,r>
         r[i] = rv;
         acc[0] += rv * rv;                                                    // cgs.py:99
         acc[1] += r0[i] * rv;                                                 // cgs.py:105
+    }
+    static constexpr int NPF = 2;                         // pipelined kernels: r[i], r0[i] arrive as o[0], o[1]
+    __device__ const double *pf_vec(int j) const { return j == 0 ? r : r0; }
+    __device__ void row_pf(int64_t i, double az, const double *o, double *acc) {
+        const double rv = o[0] - alpha * az;                                  // cgs.py:96
+        r[i] = rv;
+        acc[0] += rv * rv;                                                    // cgs.py:99
+        acc[1] += o[1] * rv;                                                  // cgs.py:105
     }
 };
 

@@ -390,6 +390,23 @@ struct MkHasRowX<Epi, std::void_t<decltype(std::declval<Epi &>().row_x((int64_t)
 typedef unsigned mk_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned mk_u4 __attribute__((ext_vector_type(4)));
 
+// optional epilogue hooks for kernels with a software pipeline (the brick march, mk_spmv_fmt9.h): an epilogue that reads
+// vectors at its own row (r0[r], r1[r], w[r] ...) declares them -- `static constexpr int NPF`, `const double *pf_vec(int j)`
+// -- and takes their values as arguments: `row_pf(r, s, o, acc)` = `row(r, s, acc)` with o[j] = pf_vec(j)[r], and, where the
+// epilogue's own vector is the product's input, `row_x_pf(r, s, xr, o, acc)`.  The kernel issues those loads at the TOP of a
+// step, before the prefetches of later planes, so that consuming them at the end of the step waits only for loads that are
+// older -- a load issued inside `row` is the youngest of the queue and waiting for it drains the whole pipeline.
+template <class Epi, class = void>
+struct MkHasRowPf : std::false_type {};
+template <class Epi>
+struct MkHasRowPf<Epi, std::void_t<decltype(std::declval<Epi &>().row_pf((int64_t)0, 0.0, (const double *)nullptr, (double *)nullptr))>>
+    : std::true_type {};
+template <class Epi, class = void>
+struct MkHasRowXPf : std::false_type {};
+template <class Epi>
+struct MkHasRowXPf<Epi, std::void_t<decltype(std::declval<Epi &>().row_x_pf((int64_t)0, 0.0, 0.0, (const double *)nullptr, (double *)nullptr))>>
+    : std::true_type {};
+
 // Staging buffer of the windowed path: product idx (relative to the 8-aligned start of the tile's stream) lives at
 // [idx & 7][idx >> 3] of an 8 x 257 array -- lane l writes its i-th product to [i][l] (consecutive lanes, consecutive
 // addresses: conflict-free ds_write_b64); column 256 holds zeros, so that pass 2 can mask a read by redirecting its

@@ -64,6 +64,16 @@ struct EpiK1 {
         mk_store_stream(t + i, tv, nt);
         acc[0] += vv * tv;                                                    // minres.py:245
     }
+    // pipelined kernels (brick march): r1[i] arrives as o[0], loaded at the top of the step
+    static constexpr int NPF = 1;
+    __device__ const double *pf_vec(int) const { return r1; }
+    __device__ void row_x_pf(int64_t i, double sum, double vv, const double *o, double *acc) {
+        mk_store_stream(v + i, vv, nt);
+        double tv = sum - shift * vv;                                         // minres.py:239-240
+        if (!first) tv = tv - c * o[0];                                       // minres.py:243
+        mk_store_stream(t + i, tv, nt);
+        acc[0] += vv * tv;                                                    // minres.py:245
+    }
     // r2 IS the product's input vector: where the kernel holds xin(r2[i]) = s * r2[i] already (pattern format: the
     // diagonal entry's LDS slot) it passes it, and r2 is not streamed a second time
     __device__ void row_x(int64_t i, double sum, double vv, double *acc) {

@@ -85,6 +85,9 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     static_assert(MK_PEN_R % 2 == 0 && MK_PEN_R % MK_PEN_H == 0, "ring geometry");
     constexpr bool ROWX = !PROG && MkHasRowX<Epi>::value;
     constexpr bool FUSE = MkHasFuse<Epi>::value;
+    // epilogue operands loaded at the top of a step (mk_device.h: row_pf / row_x_pf)
+    constexpr bool XPF = !PROG && MkHasRowXPf<Epi>::value;
+    constexpr bool RPF = !XPF && MkHasRowPf<Epi>::value;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int64_t L = A.pen_L, P = A.pen_P;
     const int nz = A.pen_nz, bx = A.pen_bx, bpp = A.pen_bpp, zc = A.pen_zc;
@@ -190,6 +193,16 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         };
         auto step = [&](int zz, int bo, const mk_d2 xm_, const mk_d2 xc_, const mk_d2 xp_, double hv, double ev, unsigned pp,
                         const mk_d2 (&vv)[7], auto &&reload, auto &&after) {
+            [[maybe_unused]] double oa[4], ob[4];             // the epilogue's own-row operands of rows c, c + 1 (<= 4 vectors)
+            if constexpr (XPF || RPF) {
+                static_assert(Epi::NPF <= 4, "at most four prefetched epilogue operands");
+#pragma unroll
+                for (int j = 0; j < Epi::NPF; ++j) {
+                    const mk_d2 o2 = *reinterpret_cast<const mk_d2 *>(epi.pf_vec(j) + (int64_t)zz * P + c);
+                    oa[j] = o2.x;
+                    ob[j] = o2.y;
+                }
+            }
             mk_d2 xm, xc, xp;
             xm.x = epi.xin(xm_.x); xm.y = epi.xin(xm_.y);
             xc.x = epi.xin(xc_.x); xc.y = epi.xin(xc_.y);
@@ -237,7 +250,13 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 sa = mk_rowprog(A, sa, x, r, epi);
                 sb = mk_rowprog(A, sb, x, r + 1, epi);
             }
-            if constexpr (ROWX) {
+            if constexpr (XPF) {
+                epi.row_x_pf(r, sa, xc.x, oa, acc);
+                epi.row_x_pf(r + 1, sb, xc.y, ob, acc);
+            } else if constexpr (RPF) {
+                epi.row_pf(r, sa, oa, acc);
+                epi.row_pf(r + 1, sb, ob, acc);
+            } else if constexpr (ROWX) {
                 epi.row_x(r, sa, xc.x, acc);
                 epi.row_x(r + 1, sb, xc.y, acc);
             } else {

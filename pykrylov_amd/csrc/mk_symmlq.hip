@@ -291,6 +291,17 @@ struct EpiK1 {
         mk_store_stream(t + i, tv, nt);
         acc[0] += vv * tv;                                                    // symmlq.py:305
     }
+    // pipelined kernels (brick march): vv = xin(r2[i]) comes from the kernel's registers, r1[i] arrives as o[0]
+    static constexpr int NPF = 1;
+    __device__ const double *pf_vec(int) const { return r1; }
+    __device__ void row_x_pf(int64_t i, double sum, double vv, const double *o, double *acc) {
+        mk_store_stream(v + i, vv, nt);
+        double tv = sum;
+        if (has_shift) tv = tv - shift * vv;                                  // symmlq.py:303
+        tv = tv - c * o[0];                                                   // symmlq.py:304
+        mk_store_stream(t + i, tv, nt);
+        acc[0] += vv * tv;                                                    // symmlq.py:305
+    }
 };
 
 struct OpK2 {

@@ -157,6 +157,18 @@ struct EpiP4 {   // u = A y ; w -= alpha u ; d = c d + y ; <w,w>, <r0,w>
         acc[0] += wv * wv;                                                    // tfqmr.py:118
         acc[1] += r0[i] * wv;                                                 // tfqmr.py:128
     }
+    static constexpr int NPF = 4;                         // pipelined kernels: w[i], d[i], y[i], r0[i] arrive as o[0..3]
+    __device__ const double *pf_vec(int j) const { return j == 0 ? w : (j == 1 ? d : (j == 2 ? y : r0)); }
+    __device__ void row_pf(int64_t i, double s, const double *o, double *acc) {
+        u[i] = s;
+        const double wv = o[0] - alpha * s;                                   // tfqmr.py:115
+        w[i] = wv;
+        double dv = o[1] * c1;                                                // tfqmr.py:116
+        dv = dv + o[2];                                                       // tfqmr.py:117
+        d[i] = dv;
+        acc[0] += wv * wv;                                                    // tfqmr.py:118
+        acc[1] += o[3] * wv;                                                  // tfqmr.py:128
+    }
 };
 
 struct OpP5 {
@@ -255,6 +267,14 @@ struct EpiP6 {   // u = A y ; v += u (INIT: v = u) ; <r0, v>
         const double vv = INIT ? s : v[i] + s;                                // tfqmr.py:83 / :150
         v[i] = vv;
         acc[0] += r0[i] * vv;                                                 // tfqmr.py:88
+    }
+    static constexpr int NPF = 2;                         // pipelined kernels: r0[i], v[i] arrive as o[0], o[1] (INIT: v unused)
+    __device__ const double *pf_vec(int j) const { return j == 0 ? r0 : v; }
+    __device__ void row_pf(int64_t i, double s, const double *o, double *acc) {
+        u[i] = s;
+        const double vv = INIT ? s : o[1] + s;                                // tfqmr.py:83 / :150
+        v[i] = vv;
+        acc[0] += o[0] * vv;                                                  // tfqmr.py:88
     }
 };
 

@@ -352,3 +352,39 @@ def test_fused_cg_negative_curvature_leaves_nothing_pending(monkeypatch):
     assert got["1"][0] == got["0"][0] and np.array_equal(got["1"][1], got["0"][1]) and np.array_equal(got["1"][2], got["0"][2])
     ref = krylov_ref.cg(B, rhs, matvec_max=60, red=krylov_ref.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geometry=geo)))
     assert got["1"][0] == ref["nMatvec"] and np.array_equal(got["1"][1], ref["residHistory"]) and np.array_equal(got["1"][2], ref["x"])
+
+
+@pytest.mark.parametrize("fmt", [9, 10])
+@pytest.mark.parametrize("solver", ["bicgstab", "cgs", "tfqmr", "minres", "symmlq"])
+def test_every_square_loop_on_the_march_bit_exact(solver, fmt):
+    """The other five square loops on the brick march (formats 9 and 10): their product epilogues take the vectors they
+    read at their own row as operands loaded at the top of a step (`row_pf` / `row_x_pf`, csrc/mk_device.h) -- same
+    operations, same order: history / iterate / counters equal the oracle run in the device's summation order, bit for bit."""
+    import pykrylov_amd as pk
+    A = csr_ref.poisson3d(128, 8, 14) if fmt == 9 else csr_ref.poisson3d_varcoef(128, 8, 14, seed=7)
+    n = A.shape[0]
+    rhs = A.matvec(np.ones(n)) + 0.05 * np.sin(np.arange(n))
+    op = op9(A, symmetric=True, fmt=fmt)
+    x0 = np.random.default_rng(8).standard_normal(n)
+    assert np.array_equal(op * x0, A.matvec(x0)) and fmt_of(op) == fmt
+    geo = gpu_order.launch_geometry(op)
+    red = krylov_ref.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES[solver], geometry=geo))
+    if solver in ("bicgstab", "cgs", "tfqmr"):
+        s = {"bicgstab": pk.BiCGSTAB, "cgs": pk.CGS, "tfqmr": pk.TFQMR}[solver](op)
+        s.solve(rhs, matvec_max=36)
+        ref = getattr(krylov_ref, solver)(A, rhs, matvec_max=36, red=red)
+        assert s.nMatvec == ref["nMatvec"] and s.residNorm == ref["residNorm"]
+        assert np.array_equal(s.x, ref["x"])
+    elif solver == "minres":
+        s = pk.Minres(op)
+        s.solve(rhs, show=False, check=False, shift=0.7, etol=0.0, rtol=1e-10, itnlim=40)
+        ref = krylov_ref.minres(A, rhs, shift=0.7, etol=0.0, rtol=1e-10, itnlim=40, check=False, red=red)
+        assert s.itn == ref["itn"] and np.array_equal(np.array(s.residHistory), np.array(ref["residHistory"]))
+        assert np.array_equal(s.x, ref["x"])
+    else:
+        s = pk.Symmlq(op)
+        s.solve(rhs, matvec_max=40, shift=0.7)
+        ref = krylov_ref.symmlq(A, rhs, matvec_max=40, shift=0.7, red=red)
+        assert s.nMatvec == ref["nMatvec"] and s.residNorm == ref["residNorm"]
+        assert np.array_equal(s.x, ref["x"])
+    assert fmt_of(op) == fmt
