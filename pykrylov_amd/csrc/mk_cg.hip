@@ -311,13 +311,16 @@ struct CgSolver : mk_solver {
     int setup(const double *rhs, const double *guess) override {
         if (!d_x) {
             int rc;
-            if ((rc = alloc_vec(&d_x, nx)) || (rc = alloc_vec(&d_r, n)) || (rc = alloc_vec(&d_p, nx)) ||
+            // (r with room for received entries too: fused passes on a slab exchange r's boundary planes, not p's)
+            if ((rc = alloc_vec(&d_x, nx)) || (rc = alloc_vec(&d_r, nx)) || (rc = alloc_vec(&d_p, nx)) ||
                 (rc = alloc_vec(&d_Ap, n)))
                 return rc;
         }
         const MkPlan *plan = A ? mk_csr_plan(A) : nullptr;
-        fused = want_fuse() && plan && (plan->fmt == 9 || plan->fmt == 10) && !precon_fn && !mk_comm_active() && A->ex.mode < 0 && A->nops == 0 &&
-                !A->comp_kind && nx == n;
+        // one device, or one rank's slab under a halo exchange (the march takes the neighbours' planes from the received entries)
+        const bool slab = plan && A->ex.mode == 0 && nx == n + A->ex.n_halo && (plan->pen_xlo >= 0 || plan->pen_xhi >= 0);
+        fused = want_fuse() && plan && (plan->fmt == 9 || plan->fmt == 10) && !precon_fn && A->nops == 0 && !A->comp_kind &&
+                ((!mk_comm_active() && A->ex.mode < 0 && nx == n) || slab);
         flushed = false;
         if (fused && !d_p2) {
             int rc;
@@ -371,14 +374,21 @@ struct CgSolver : mk_solver {
         if (fused) {
             const bool nt = mk_store_nt(A);
             if (it == 0) {                                  // nothing pending yet: the plain product on p = -r
+                if ((rc = exchange(d_p)) != MK_OK) return rc;
                 if (nt) mk_launch_spmv(this, d_p, CgSpmvEpiT<true>{d_p, d_Ap, 0.0});
                 else mk_launch_spmv(this, d_p, CgSpmvEpi{d_p, d_Ap, 0.0});
             } else {                                        // K1f: p_old = the other buffer
+                // a slab: the neighbours' planes of p are FORMED here like the own ones, from their p_old (kept behind the own rows
+                // of the p buffers since the pass before) and their r -- so it is r whose boundary planes travel, as soon as K2 of
+                // the pass before has written them; the interior planes' launch overlaps the messages as everywhere
+                if ((rc = exchange(d_r)) != MK_OK) return rc;
                 if (nt) mk_launch_spmv(this, pbuf(it - 1), CgFusedEpiT<true>{d_Ap, d_r, d_x, pbuf(it), d_dump, d_scal, 0.0, 0.0});
                 else mk_launch_spmv(this, pbuf(it - 1), CgFusedEpiT<false>{d_Ap, d_r, d_x, pbuf(it), d_dump, d_scal, 0.0, 0.0});
             }
+            if ((rc = allreduce(0, 1)) != MK_OK) return rc;
             mk_launch_stream(this, CgUpdateR{d_part, np_spmv, d_scal, d_status, par, prm.check_curvature, d_Ap, d_r,
                                              d_prec, 0.0, false}, n);
+            if ((rc = allreduce(1, 1)) != MK_OK) return rc;
             hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(MK_BLOCK), 0, stream, d_part, np_stream, d_scal, d_status, d_hist,
                                par, prm.matvec_max, next_halt());
             return MK_OK;

@@ -403,6 +403,8 @@ extern "C" int mk_csr_localize(mk_csr *A, int mode, int64_t col_begin, int64_t c
     MK_HIP(hipGetLastError());
     MK_HIP(hipStreamSynchronize(st));
     A->ncols = new_cols;
+    A->loc_lo = (mode == 0) ? lo : 0;                        // (the brick march of a slab takes the neighbours' planes from there)
+    A->loc_hi = (mode == 0) ? hi : 0;
     mk_csr_plan_reset(A);                                    // the columns changed: the windowed format is rebuilt
     if (halo_lo) *halo_lo = lo;
     if (halo_hi) *halo_hi = hi;

@@ -79,6 +79,11 @@ struct MkCsrView {
     // (pid = pattern byte per row, ptab = 64 bytes per pattern)
     int64_t pen_L, pen_P;
     int pen_nz, pen_bx, pen_bpp, pen_zc, pen_chunks;
+    // a rank's slab: offsets of the plane below / above in the input vector (-1: none, the march clamps as on one device); a
+    // launch covers the planes [pen_za, pen_zb) and [pen_ya, pen_yb), each cut into chunks of pen_zc planes (whole product:
+    // [0, nz) and nothing; overlapped halo exchange: the interior planes first, the slab's first and last planes afterwards)
+    int64_t pen_xlo, pen_xhi;
+    int pen_za, pen_zb, pen_ya, pen_yb;
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
     int rt_c0;               // first column of the phases (0; a column block's first column: its phases cover ITS slice of x)
@@ -268,6 +273,11 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.pen_bpp = P->pen_bpp;
         v.pen_zc = P->pen_zc;
         v.pen_chunks = P->pen_chunks;
+        v.pen_xlo = P->pen_xlo;
+        v.pen_xhi = P->pen_xhi;
+        v.pen_za = 0;
+        v.pen_zb = P->pen_nz;
+        v.pen_ya = v.pen_yb = 0;
     } else if (v.fmt == 3) {
         v.rt_cap = P->rt_cap;
         v.rt_k = P->rt_k;
@@ -299,9 +309,45 @@ static inline MkCsrView mk_view(const mk_csr *A) {
     return v;
 }
 
+// The brick march of a slab under an overlapped halo exchange: the planes that need no received entry -- all but the first
+// MK_PEN_R of a slab with a lower neighbour and the last 1 .. MK_PEN_R of one with an upper neighbour, so that the interior is a
+// whole number of pipelined rounds -- run while the messages travel, the others afterwards.  False: too few planes to split.
+static inline bool mk_pen_split(const MkPlan *P, int *za, int *zb) {
+    constexpr int R = 6;                                    // (= MK_PEN_R, mk_spmv_fmt9.h; asserted there)
+    const int nz = P->pen_nz;
+    const int lo = (P->pen_xlo >= 0) ? R : 0;
+    int hi_s = nz;
+    if (P->pen_xhi >= 0) hi_s = lo + ((nz - lo - 1) / R) * R;
+    if (hi_s - lo < R || (lo == 0 && hi_s == nz)) return false;
+    *za = lo;
+    *zb = hi_s;
+    return true;
+}
+static inline int mk_pen_items(const MkCsrView &v) {
+    const int n1 = (v.pen_zb - v.pen_za + v.pen_zc - 1) / v.pen_zc, n2 = (v.pen_yb - v.pen_ya + v.pen_zc - 1) / v.pen_zc;
+    const int64_t items = (int64_t)v.pen_bpp * (n1 + n2);
+    return (int)(items > MK_MAXP ? MK_MAXP : (items < 1 ? 1 : items));
+}
+
 // view of the interior (part 1) or boundary (part 2) tiles of a partitioned matrix; poff2 = grid of part 1
 static inline MkCsrView mk_view_part(const mk_csr *A, int part, int poff2) {
     MkCsrView v = mk_view(A);
+    if (v.fmt == 9 || v.fmt == 10) {                        // plane ranges instead of tile lists
+        int za = 0, zb = v.pen_nz;
+        mk_pen_split(mk_csr_plan(A), &za, &zb);             // (the caller checked that the slab splits)
+        if (part == 2) {
+            v.pen_za = 0;
+            v.pen_zb = za;
+            v.pen_ya = zb;
+            v.pen_yb = v.pen_nz;
+        } else {
+            v.pen_za = za;
+            v.pen_zb = zb;
+        }
+        v.poff = (part == 2) ? poff2 : 0;
+        v.part = part;
+        return v;
+    }
     v.tiles = A->ex.d_tiles + (part == 2 ? A->ex.n_int : 0);
     v.ntl = (part == 2) ? A->ex.n_bnd : A->ex.n_int;
     v.poff = (part == 2) ? poff2 : 0;

@@ -992,7 +992,13 @@ bool cover_build(const mk_csr *A, MkPlan &P, bool wide) {
 // is described EXACTLY by a 63-bit key, 9 bits per offset in column order: 0 = no entry, 1 + the value's dictionary code
 // otherwise.  Distinct keys (<= 256) are collected in the open-addressing set the dictionary uses, numbered in ascending
 // order (deterministic), and every row gets the number of its key: no hashing, nothing to verify.
-// stats: [0] smallest |offset| above 1, [1] largest |offset|, [2] longest row
+//
+// One rank's SLAB of such a matrix (rows of whole planes, columns localised to [own | plane below | plane above] by
+// mk_csr_localize mode 0) is of the class too: a received column of a first-plane row r is the -P neighbour iff it is
+// nrows + r, one of a last-plane row the +P neighbour iff it is nrows + lo + (r - (nrows - P)).  Localising renumbers in
+// place: a row keeps the storage order of its GLOBAL columns, which is the order the scalar loop adds in and the order of
+// the slots -- the builder insists on it (slots strictly ascending along every row), so the bits are those of one device.
+// stats: [0] smallest |offset| above 1, [1] largest |offset|, [2] longest row   (received columns, >= nrows, are not offsets)
 __global__ __launch_bounds__(MK_BLOCK) void pen_scan(int64_t nrows, const int32_t *__restrict__ ip,
                                                      const int32_t *__restrict__ ix, int *__restrict__ stats) {
     int mn = 0x7fffffff, mx = 0, ml = 0;
@@ -1001,6 +1007,7 @@ __global__ __launch_bounds__(MK_BLOCK) void pen_scan(int64_t nrows, const int32_
         ml = (hi - lo > ml) ? hi - lo : ml;
         if (hi - lo > 7) continue;                           // (the caller gives up on ml > 7)
         for (int j = lo; j < hi; ++j) {
+            if (ix[j] >= nrows) continue;
             const int64_t d = (int64_t)ix[j] - r;
             const int64_t a = d < 0 ? -d : d;
             if (a > 1) {
@@ -1022,24 +1029,42 @@ __global__ __launch_bounds__(MK_BLOCK) void pen_scan(int64_t nrows, const int32_
     }
 }
 
+// slab geometry of a localised matrix: rows, widths of the lower / upper window of received columns (0 or P)
+struct PenSlab {
+    int64_t nrows, lo, hi;
+};
+
+// position 0..6 of column `col` in row r (-1: outside the class)
+__device__ inline int pen_slot(int64_t col, int64_t r, int64_t L, int64_t P, const PenSlab &sl) {
+    if (col >= sl.nrows) {
+        const int64_t h = col - sl.nrows;
+        if (sl.lo == P && r < P && h == r) return 0;
+        if (sl.hi == P && r >= sl.nrows - P && h == sl.lo + (r - (sl.nrows - P))) return 6;
+        return -1;
+    }
+    const int64_t d = col - r;
+    if (d == -P) return 0;
+    if (d == -L) return 1;
+    if (d == -1) return 2;
+    if (d == 0) return 3;
+    if (d == 1) return 4;
+    if (d == L) return 5;
+    if (d == P) return 6;
+    return -1;
+}
+
 // the key of row r (0 = the row does not fit the class: an offset outside the set, or a value outside the dictionary)
 __device__ inline unsigned long long pen_row_key(const int32_t *__restrict__ ip, const int32_t *__restrict__ ix,
                                                  const double *__restrict__ data, const unsigned long long *dk, int count,
-                                                 int64_t r, int64_t L, int64_t P) {
+                                                 int64_t r, int64_t L, int64_t P, const PenSlab &sl) {
     const int lo = ip[r], hi = ip[r + 1];
     unsigned long long key = 0;
     if (hi - lo > 7 || hi == lo) return 0;
+    int kprev = -1;
     for (int j = lo; j < hi; ++j) {
-        const int64_t d = (int64_t)ix[j] - r;
-        int k;
-        if (d == -P) k = 0;
-        else if (d == -L) k = 1;
-        else if (d == -1) k = 2;
-        else if (d == 0) k = 3;
-        else if (d == 1) k = 4;
-        else if (d == L) k = 5;
-        else if (d == P) k = 6;
-        else return 0;
+        const int k = pen_slot(ix[j], r, L, P, sl);
+        if (k <= kprev) return 0;                            // (outside the class, or not stored in the order the march adds in)
+        kprev = k;
         const unsigned long long v = (unsigned long long)__double_as_longlong(data[j]);
         int c = 0;                                           // largest index with dk[c] <= v
 #pragma unroll
@@ -1054,7 +1079,7 @@ __device__ inline unsigned long long pen_row_key(const int32_t *__restrict__ ip,
 // pass 1 (sorted == null): every row's key into the set; pass 2: the number of the row's key among the sorted keys -> pid
 __global__ __launch_bounds__(MK_BLOCK) void pen_rows(int64_t nrows, const int32_t *__restrict__ ip, const int32_t *__restrict__ ix,
                                                      const double *__restrict__ data, const double *__restrict__ dict, int count,
-                                                     int64_t L, int64_t P, unsigned long long *table, int *state,
+                                                     int64_t L, int64_t P, PenSlab sl, unsigned long long *table, int *state,
                                                      const double *__restrict__ sorted, int nkeys, uint8_t *__restrict__ pid) {
     __shared__ unsigned long long dk[256], sk[256];
     dk[threadIdx.x] = (threadIdx.x < count) ? (unsigned long long)__double_as_longlong(dict[threadIdx.x]) : ~0ULL;
@@ -1062,7 +1087,7 @@ __global__ __launch_bounds__(MK_BLOCK) void pen_rows(int64_t nrows, const int32_
     __syncthreads();
     unsigned long long seen = 0;
     for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
-        const unsigned long long key = pen_row_key(ip, ix, data, dk, count, r, L, P);
+        const unsigned long long key = pen_row_key(ip, ix, data, dk, count, r, L, P, sl);
         if (key == 0) {
             state[1] = 1;
             return;
@@ -1103,29 +1128,23 @@ __global__ __launch_bounds__(MK_BLOCK) void pen_table(int nkeys, const double *_
 // format 10: per row the 7-bit presence mask, and the values in position-major order sval[k * nrows + r] (+0.0 where the row
 // has no entry at offset k); state[1] is raised by a row with an offset outside the class
 __global__ __launch_bounds__(MK_BLOCK) void pen_stream_fill(int64_t nrows, const int32_t *__restrict__ ip, const int32_t *__restrict__ ix,
-                                                            const double *__restrict__ data, int64_t L, int64_t P,
+                                                            const double *__restrict__ data, int64_t L, int64_t P, PenSlab sl,
                                                             uint8_t *__restrict__ pid, double *__restrict__ sval, int *state) {
     for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
         const int lo = ip[r], hi = ip[r + 1];
         double v[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         unsigned mask = 0;
         bool bad = hi - lo > 7;
+        int kprev = -1;
         for (int j = lo; j < hi && !bad; ++j) {
-            const int64_t d = (int64_t)ix[j] - r;
-            int k;
-            if (d == -P) k = 0;
-            else if (d == -L) k = 1;
-            else if (d == -1) k = 2;
-            else if (d == 0) k = 3;
-            else if (d == 1) k = 4;
-            else if (d == L) k = 5;
-            else if (d == P) k = 6;
-            else {
+            const int k = pen_slot(ix[j], r, L, P, sl);
+            if (k <= kprev) {                                // (outside the class, or not stored in the order the march adds in)
                 bad = true;
                 break;
             }
-            v[k] = data[j];
+            kprev = k;
             mask |= 1u << k;
+            v[k] = data[j];
         }
         if (bad) {
             state[1] = 1;
@@ -1154,6 +1173,8 @@ void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP) {
     P.pen_nz = (int)(A->nrows / PP);
     P.pen_bx = (int)(L / 128);
     P.pen_bpp = (int)(L / 128 * (PP / (4 * L)));
+    P.pen_xlo = A->loc_lo ? A->nrows : -1;                   // a slab: where the neighbours' planes sit in the input vector
+    P.pen_xhi = A->loc_hi ? A->nrows + A->loc_lo : -1;
     // chunks: the kernel keeps two workgroups per CU resident (its register ring), so 512 (brick, chunk) items fill the
     // chip in one round; more chunks only add pipeline fills and re-read two planes per chunk start (512^3, tools/
     // r05_pencil_variants.sh: 4 chunks of 132 planes 441 us, 8 of 66 436, one of 516 421).  At least 6 planes per chunk, a
@@ -1171,7 +1192,10 @@ void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP) {
 // want: 9 = dictionary + patterns only; 10 = also the streamed-value twin (format 10) when the matrix has too many values or
 // patterns for format 9
 bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
-    if (A->nrows != A->ncols || A->nnz > 7 * A->nrows || A->nrows < 1024 || A->alias || A->ex.mode >= 0) return false;
+    // square, or one rank's slab with its columns localised to [own | plane below | plane above] (halo exchange)
+    if (A->ncols != A->nrows + A->loc_lo + A->loc_hi || A->nnz > 7 * A->nrows || A->nrows < 1024 || A->alias || A->ex.mode == 1)
+        return false;
+    if (A->ex.mode == 0 && (A->ex.n_local != A->nrows || A->ex.n_halo != A->loc_lo + A->loc_hi)) return false;
     if (!forced && A->nrows < pencil_min_rows()) return false;
     hipStream_t st = mk_ctx().stream;
     int *d_stats = nullptr;
@@ -1201,6 +1225,8 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     if (h_stats[2] > 7 || L >= PP || L <= 1 || L % 128 != 0 || PP % (4 * L) != 0 || A->nrows % PP != 0 || A->nrows / PP < 2 ||
         L / 128 * (PP / (4 * L)) > (1 << 24))
         return drop();
+    if ((A->loc_lo != 0 && A->loc_lo != PP) || (A->loc_hi != 0 && A->loc_hi != PP)) return drop();   // (whole planes only)
+    const PenSlab sl{A->nrows, A->loc_lo, A->loc_hi};
     // the dictionary (values only: no per-nonzero words)
     int h_state[2] = {0, 0};
     if (hipMalloc((void **)&d_table, sizeof(unsigned long long) * DICT_SLOTS + 2 * sizeof(int)) != hipSuccess ||
@@ -1231,7 +1257,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
         hipMemsetAsync(d_pid, 0, (size_t)A->nrows + 64, st);
         hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
         hipLaunchKernelGGL(pen_stream_fill, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, L, PP,
-                           d_pid, d_sval, d_state);
+                           sl, d_pid, d_sval, d_state);
         if (!read_state() || h_state[1] || hipGetLastError() != hipSuccess) {
             hipFree(d_sval);
             return drop();
@@ -1255,7 +1281,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     // the rows' keys
     if (!reset_set()) return drop();
     hipLaunchKernelGGL(pen_rows, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, d_dict, ndict,
-                       L, PP, d_table, d_state, (const double *)nullptr, 0, (uint8_t *)nullptr);
+                       L, PP, sl, d_table, d_state, (const double *)nullptr, 0, (uint8_t *)nullptr);
     if (!read_state()) return drop();
     if (h_state[1] || h_state[0] > 256 || h_state[0] < 1) return stream_twin();
     const int nkeys = h_state[0];
@@ -1266,7 +1292,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     hipMemsetAsync(d_pid, 0, (size_t)A->nrows + 64, st);
     hipMemsetAsync(d_tab, 0, 64 * 256, st);
     hipLaunchKernelGGL(pen_rows, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, d_dict, ndict,
-                       L, PP, d_table, d_state, (const double *)d_keys, nkeys, d_pid);
+                       L, PP, sl, d_table, d_state, (const double *)d_keys, nkeys, d_pid);
     hipLaunchKernelGGL(pen_table, dim3(1), dim3(MK_BLOCK), 0, st, nkeys, d_keys, d_dict, d_tab);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return drop();
     hipFree(d_stats);
@@ -1393,7 +1419,7 @@ void mk_csr_march_pref(const mk_csr *A, int pref) {
     o->march_pref = pref;
     if (!o->plan.built) return;
     const bool march = o->plan.fmt == 9 || o->plan.fmt == 10;
-    if ((pref == 0 && march) || (pref == 1 && !march && o->nrows >= pencil_min_rows() && o->nnz <= 7 * o->nrows && o->ex.mode < 0)) {
+    if ((pref == 0 && march) || (pref == 1 && !march && o->nrows >= pencil_min_rows() && o->nnz <= 7 * o->nrows && o->ex.mode != 1)) {
         hipStreamSynchronize(mk_ctx().stream);
         plan_free(o->plan);
     }

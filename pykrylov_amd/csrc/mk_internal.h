@@ -143,6 +143,9 @@ struct MkPlan {
     // and chunks; d_pid holds the pattern byte per row, d_ptab 64 bytes per pattern {7 values, mask}, npat their number
     int64_t pen_L = 0, pen_P = 0;
     int pen_nz = 0, pen_bx = 0, pen_bpp = 0, pen_zc = 0, pen_chunks = 0;
+    // ... of one rank's slab of planes (columns localised to [own | plane below | plane above], mk_csr_localize mode 0): where
+    // the neighbours' planes start in the product's input vector (-1: the slab has no such neighbour)
+    int64_t pen_xlo = -1, pen_xhi = -1;
     double *d_carry = nullptr;     // per-lane accumulators of fused dots between the launches of a stepped product
     // column blocks (plain-CSR matrices whose x does not fit an XCD's L2): A = [A_0 | A_1 | ...] by column range,
     // each block a CSR matrix over all rows; a product runs block after block with the running row sums carried
@@ -167,6 +170,7 @@ struct MkReduced {
 
 struct mk_csr {
     int64_t nrows = 0, ncols = 0, nnz = 0;
+    int64_t loc_lo = 0, loc_hi = 0; // mk_csr_localize mode 0: widths of the lower / upper halo window (columns nrows .. ncols-1)
     int32_t *d_indptr = nullptr;
     int32_t *d_indices = nullptr;
     double *d_data = nullptr;

@@ -242,12 +242,26 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
                                  const Gate &gate = Gate()) {
     const mk_csr *A = s->A;
     if (timed) s->spmv_begin();
-    if (A->ex.pending) {
+    const MkPlan *plan = A->ex.pending ? mk_csr_plan(A) : nullptr;
+    const bool march = plan && (plan->fmt == 9 || plan->fmt == 10);
+    int za, zb;
+    if (A->ex.pending && march && !mk_pen_split(plan, &za, &zb)) {
+        int rc = mk_exchange_wait(A, s->stream);             // a slab of too few planes to split: the messages first
+        if (rc != MK_OK) return rc;
+        mk_spmv_launch_blocks(A, mk_grid_spmv_for(A), s->stream, x, epi, gate, [&] { return s->next_halt(); }, s->d_part);
+    } else if (A->ex.pending) {
         // halo exchange in flight: rows that need no received entry first, the others once the messages are in
         // (the two launches write disjoint ranges of the partial-sum slots)
         int g1, g2;
-        mk_grid_spmv_parts(A, A->ex.n_int, A->ex.n_bnd, &g1, &g2);
-        mk_spmv_launch_view(mk_view_part(A, 1, 0), g1, s->stream, x, epi, gate, s->next_halt(), s->d_part);
+        const MkCsrView v1 = mk_view_part(A, 1, 0);
+        if (march) {                                         // plane ranges of the brick march (mk_pen_split)
+            g1 = mk_pen_items(v1);
+            g2 = mk_pen_items(mk_view_part(A, 2, 0));
+            if (g1 + g2 > MK_MAXP) g1 = MK_MAXP - g2;
+        } else {
+            mk_grid_spmv_parts(A, A->ex.n_int, A->ex.n_bnd, &g1, &g2);
+        }
+        mk_spmv_launch_view(v1, g1, s->stream, x, epi, gate, s->next_halt(), s->d_part);
         int rc = mk_exchange_wait(A, s->stream);
         if (rc != MK_OK) return rc;
         mk_spmv_launch_view(mk_view_part(A, 2, g1), g2, s->stream, x, epi, gate, s->next_halt(), s->d_part);

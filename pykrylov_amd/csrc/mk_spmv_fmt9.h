@@ -83,6 +83,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                                                    double *smem, double (&acc)[NACC]) {
     constexpr int R = MK_PEN_R, RS = MK_PEN_RS, BUF = 6 * MK_PEN_RS;
     static_assert(MK_PEN_R % 2 == 0 && MK_PEN_R % MK_PEN_H == 0, "ring geometry");
+    static_assert(MK_PEN_R == 6, "mk_pen_split (mk_device.h) cuts a slab's boundary planes in rounds of 6");
     constexpr bool ROWX = !PROG && MkHasRowX<Epi>::value;
     constexpr bool FUSE = MkHasFuse<Epi>::value;
     // epilogue operands loaded at the top of a step (mk_device.h: row_pf / row_x_pf)
@@ -91,8 +92,16 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int64_t L = A.pen_L, P = A.pen_P;
     const int nz = A.pen_nz, bx = A.pen_bx, bpp = A.pen_bpp, zc = A.pen_zc;
-    const int64_t items = (int64_t)bpp * A.pen_chunks;
+    // this launch's planes: [pen_za, pen_zb) and [pen_ya, pen_yb) in chunks of zc (a whole product: [0, nz) and nothing)
+    const int nch1 = (A.pen_zb - A.pen_za + zc - 1) / zc, nch2 = (A.pen_yb - A.pen_ya + zc - 1) / zc;
+    const int64_t items = (int64_t)bpp * (nch1 + nch2);
     const int64_t last = A.nrows - 1;
+    // a rank's slab (mk_csr_localize mode 0): the planes below plane 0 / above plane nz - 1 are the neighbours', received
+    // behind the own rows of the input vector; on one device the march clamps into the grid (their entries are masked).
+    // Localising renumbers the columns in place and keeps every row's STORAGE order -- the order of the global columns --
+    // so the scalar loop adds the entry in the plane below first as everywhere: slot 0, the same bits as on one device.
+    const int64_t off_lo = A.pen_xlo >= 0 ? A.pen_xlo : (int64_t)0;
+    const int64_t off_hi = A.pen_xhi >= 0 ? A.pen_xhi : (int64_t)(nz - 1) * P;
     const uint8_t *pid = A.pid;
     // the pattern table, 16 words per pattern, behind the plane images (read-only after this copy)
     [[maybe_unused]] unsigned *ptl = reinterpret_cast<unsigned *>(smem + MK_PEN_LDS);
@@ -128,7 +137,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             bi = (int)(item % bpp);
             chunk = (int)(item / bpp);
         }
-        const int z0 = chunk * zc, z1 = (z0 + zc < nz) ? z0 + zc : nz;
+        const int zlim = chunk < nch1 ? A.pen_zb : A.pen_yb;
+        const int z0 = chunk < nch1 ? A.pen_za + chunk * zc : A.pen_ya + (chunk - nch1) * zc, z1 = (z0 + zc < zlim) ? z0 + zc : zlim;
         const int64_t b0 = (int64_t)(bi / bx) * 4 * L + (int64_t)(bi % bx) * 128;    // the brick's first row in plane 0
         const int64_t c = b0 + (int64_t)w * L + 2 * l;                                // this lane's rows c, c + 1 (in-plane index)
         // halo row of this lane: lanes 0..127 the line below the brick, 128..255 the line above; lanes 0..7 also the row
@@ -136,8 +146,9 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         const int64_t hc = tid < 128 ? b0 - L + tid : b0 + 4 * L + (tid - 128);
         const int64_t ec = b0 + (int64_t)(tid & 3) * L + ((tid & 4) ? 128 : -1);
         auto plane = [&](int p) -> mk_d2 {                    // the own rows of plane p (clamped into the grid: values of a
-            p = p < 0 ? 0 : (p > nz - 1 ? nz - 1 : p);       // plane that does not exist are never multiplied)
-            return *reinterpret_cast<const mk_d2 *>(x + (int64_t)p * P + c);
+            // plane that does not exist are never multiplied; a slab's neighbour planes come from the received entries)
+            const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
+            return *reinterpret_cast<const mk_d2 *>(x + o + c);
         };
         auto clampr = [&](int64_t r) { return r < 0 ? (int64_t)0 : (r > last ? last : r); };
         constexpr int H = MK_PEN_H;
@@ -156,9 +167,9 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             }
             pidr[d] = *reinterpret_cast<const uint16_t *>(pid + (int64_t)p * P + c);
         };
-        [[maybe_unused]] auto plane_of = [&](const double *v, int p) -> mk_d2 {
-            p = p < 0 ? 0 : (p > nz - 1 ? nz - 1 : p);
-            return *reinterpret_cast<const mk_d2 *>(v + (int64_t)p * P + c);
+        [[maybe_unused]] auto plane_of = [&](const double *v, int p) -> mk_d2 {     // (r of a slab's neighbour planes: received)
+            const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
+            return *reinterpret_cast<const mk_d2 *>(v + o + c);
         };
         // fuse: raw p_old of plane `pl` in pv with its r (and x) -> p (in pv) and x; both written out when the plane is one of
         // this chunk's own (anything else lands in the workgroup's dump rows: every store of the loop is unconditional)
@@ -167,13 +178,18 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 const mk_d2 po = pv;
                 pv.x = epi.fuse_pnew(po.x, rv.x);
                 pv.y = epi.fuse_pnew(po.y, rv.y);
-                if (store) {                                 // (compile-time constant at every call site)
+                if (store) {                                 // (compile-time constant at every call site of the pipelined loop)
                     const bool own = pl >= z0 && pl < z1;    // (workgroup uniform: a scalar select of the address)
                     double *dump = epi.fuse_dump + (int64_t)blockIdx.x * 1024 + 2 * tid;
                     mk_d2 xn;
                     xn.x = epi.fuse_xnew(xv.x, po.x);
                     xn.y = epi.fuse_xnew(xv.y, po.y);
-                    *reinterpret_cast<mk_d2 *>(own ? epi.fuse_p + (int64_t)pl * P + c : dump) = pv;
+                    // a slab's neighbour planes: the same p the neighbour forms for its own rows (same beta, same p_old and r
+                    // bits) is kept behind the own rows of the new p buffer -- the next pass's p_old there; x is the neighbour's
+                    double *pd = own ? epi.fuse_p + (int64_t)pl * P + c : dump;
+                    pd = (pl == -1 && A.pen_xlo >= 0) ? epi.fuse_p + off_lo + c : pd;
+                    pd = (pl == nz && A.pen_xhi >= 0) ? epi.fuse_p + off_hi + c : pd;
+                    *reinterpret_cast<mk_d2 *>(pd) = pv;
                     *reinterpret_cast<mk_d2 *>(own ? epi.fuse_x + (int64_t)pl * P + c : dump + 512) = xn;
                 }
             }
@@ -292,7 +308,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             // and the entry edge as the compiler models it would drain the pipeline on every round
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
             if constexpr (FUSE) {
-                transform(ring[0], rm1, rm1, z0 - 1, false);  // (the chunk below owns plane z0 - 1: formed, not written)
+                transform(ring[0], rm1, rm1, z0 - 1, true);   // (the chunk below owns plane z0 - 1: formed, written only where
+                                                              //  it is a slab's neighbour plane -- else into the dump rows)
                 transform(ring[1], r00, x00, z0, true);
             }
             int z = z0;
@@ -323,7 +340,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 // a chunk without pipelined rounds writes its first plane here; plane zz + 1 is formed and written now
                 const mk_d2 ra = plane_of(epi.fuse_r, zz - 1), rb = plane_of(epi.fuse_r, zz), rc = plane_of(epi.fuse_r, zz + 1);
                 const mk_d2 xb = plane_of(epi.fuse_x, zz), xcn = plane_of(epi.fuse_x, zz + 1);
-                transform(xm, ra, ra, zz - 1, false);
+                if (zz == z0) transform(xm, ra, ra, zz - 1, true);   // (written only as a slab's neighbour plane, see above)
+                else transform(xm, ra, ra, zz - 1, false);
                 if (zz == z0) transform(xc, rb, xb, zz, true);
                 else transform(xc, rb, rb, zz, false);
                 transform(xp, rc, xcn, zz + 1, true);

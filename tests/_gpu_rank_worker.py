@@ -73,6 +73,30 @@ def main():
                                          hist_err=rel_hist_err(s2.residHistory, ref2["residHistory"]), x_err=0.0)
         op.free()
 
+    # ---- the brick march (storage formats 9 / 10) on the ranks' slabs: neighbours' planes from the received entries, the
+    # product as interior planes + boundary planes around the exchange (tests/test_gpu_slab_march.py has the bit-level checks)
+    nxm, nym, nzm = 128, 8, 14 * nranks
+    Am = csr_ref.poisson3d(nxm, nym, nzm)
+    rhs_m = Am.matvec(np.ones(Am.shape[0]))
+    ref_m = kr.cg(Am, rhs_m, matvec_max=40)
+    for name, seed, fmt in (("cg3d_march9", None, 9), ("cg3d_march10", 5, 10)):
+        if seed is not None:
+            Am = csr_ref.poisson3d_varcoef(nxm, nym, nzm, seed=seed)
+            rhs_m = Am.matvec(np.ones(Am.shape[0]))
+            ref_m = kr.cg(Am, rhs_m, matvec_max=40)
+        op, ranges = dist.partition_poisson3d(world, nxm, nym, nzm, mode="halo", varcoef_seed=seed)
+        _lib.check(_lib.load().mk_csr_set_format(op.handle, fmt))
+        c0, c1 = ranges[rank]
+        s = CG(op)
+        s.solve(rhs_m[c0:c1], matvec_max=40)
+        got = ctypes.c_int32()
+        _lib.check(_lib.load().mk_csr_format_info(op.handle, ctypes.byref(got), None, None, None, None))
+        x = gather_x(world, s.x)
+        out[name + "/halo"] = dict(nMatvec=int(s.nMatvec), ref=int(ref_m["nMatvec"]), fmt=int(got.value),
+                                   hist_err=rel_hist_err(s.residHistory, ref_m["residHistory"]),
+                                   x_err=float(np.linalg.norm(x - ref_m["x"]) / np.linalg.norm(ref_m["x"])))
+        op.free()
+
     # ---- general matrices through the NumPy partition plans (pack kernel with a gather list)
     B = csr_ref.random_diagdom(2003, seed=3)              # prime: the all-gather path pads the last rank's block
     nb = B.shape[0]
