@@ -992,15 +992,16 @@ def main():
         if transport_used == "rccl" and not (tkind.value == 1 and tranks.value == world_size):
             raise SystemExit("bench.py: asked for RCCL over %d ranks but the communicator reports kind %d with %d ranks"
                              % (world_size, tkind.value, tranks.value))
-        # what one rank's kernels were budgeted at when its slab was run alone on one GPU (profiles/r03_slab_budget.txt):
+        # what one rank's kernels were budgeted at when its slab was run alone on one GPU (profiles/r05_slab_budget.txt: the
+        # brick march on the slab with fused passes -- interior planes, boundary planes, r update, scalar kernel, pack):
         # only the 8-way split of the 512^3 problem has a budget
         budget = None
         if world_size == 8 and name.startswith("poisson3d-512"):
-            budget = ({"kernels_per_pass_us": 443, "spmv_interior_us": 244, "spmv_boundary_us": 26, "update_xp_us": 106,
-                       "update_r_us": 62, "pack_us": 4.5} if name.endswith("-varcoef") else
-                      {"kernels_per_pass_us": 300, "spmv_interior_us": 108, "spmv_boundary_us": 18, "update_xp_us": 101,
-                       "update_r_us": 68, "pack_us": 4.5})
-            budget["source"] = "profiles/r03_slab_budget.txt (rank 3's slab alone on one GPU, rocprofv3 kernel trace)"
+            budget = ({"kernels_per_pass_us": 401, "fused_interior_us": 258, "fused_boundary_us": 64, "update_r_us": 69,
+                       "scalar_us": 5, "pack_us": 4} if name.endswith("-varcoef") else
+                      {"kernels_per_pass_us": 239, "fused_interior_us": 124, "fused_boundary_us": 41, "update_r_us": 67,
+                       "scalar_us": 4, "pack_us": 3})
+            budget["source"] = "profiles/r05_slab_budget.txt (rank 3's slab alone on one GPU, rocprofv3 kernel trace)"
         detail["per_rank_budget"] = budget
         ex = {first_mode: {"value": head["value"], "ms_per_step": head["ms_per_step"], "steps": args.steps,
                            "comm": head["comm"]}}
