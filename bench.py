@@ -901,6 +901,12 @@ def main():
         b_csr = spmv_bytes(n_l, info["op_shape"][1], info["nnz"])
         tm = info["timing"]
         spmv_us = tm["spmv_b2b_us"]
+        method = "one hipEvent pair around back-to-back launches on the solver stream"
+        if spmv_us is None and (info.get("comm") or {}).get("per_rank"):
+            # N > 1: this rank's product kernel alone (its whole slab in one launch, no exchange in front of it), 50 launches
+            # back to back between one HIP-event pair (the comm probe of run_cg) -- the same measurement on the rank's share
+            spmv_us = info["comm"]["per_rank"][rank].get("product_alone_us")
+            method = "rank %d's product kernel on its own slab: one hipEvent pair around 50 back-to-back launches" % rank
         inloop_us = 1e3 * tm["spmv_ms"] / tm["spmv_launches"] if tm["spmv_launches"] else None
         stencil = info["meta"]["stencil"]
         nnz_global = stencil * n_g - 2 * sum(n_g // g for g in info["meta"]["grid"])
@@ -933,7 +939,7 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_bytes": (traffic or {}).get("bytes"), "traffic_note": tnote,
                 "bytes_per_launch": b_fmt, "avg_launch_us": spmv_us, "launches_timed": info["launches"],
-                "method": "one hipEvent pair around back-to-back launches on the solver stream",
+                "method": method,
                 "inloop_event_pair_us": inloop_us,
                 "csr_bytes_per_launch": b_csr,
                 "csr_equivalent_GBs": (b_csr / (spmv_us * 1e-6) / 1e9) if spmv_us else None,

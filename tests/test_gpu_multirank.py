@@ -98,6 +98,8 @@ def test_bench_two_rank_path_smoke(launcher):
     assert line["n_gpus"] == nranks and line["steps"] == 12 and line["value"] > 0 and line["scaling"] == "strong"
     assert line["config"]["rows"] == 64 ** 3 and line["residual"]["recurrence"] > 0
     assert line["roofline"]["bound"] == "hbm"
+    # (N > 1: the dominant kernel on rank 0's slab, timed alone after the run -- never null in a line the driver records)
+    assert line["roofline"]["achieved"] > 0 and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["avg_launch_us"] > 0
     # the N > 1 line validates itself: the first 60 passes against the committed single-GPU device history (1e-12), and
     # the true residual ||b - A x_k|| (exchange + product + all-reduced norm) against the recurrence's after the timed region
     par = line["parity_vs_n1"]
