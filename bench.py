@@ -75,7 +75,10 @@ FMT_NAMES = {0: "csr (int32 columns + fp64 values, x gathered)",
              9: "z-marching bricks for 7-point-class matrices (one byte per ROW + value dictionary; every x entry loaded "
                 "once, the planes z-1, z, z+1 of a workgroup's rows ride in registers)",
              10: "z-marching bricks for 7-point-class matrices without a value dictionary (mask byte per row + seven fp64 values "
-                 "per row streamed position-major: 56 B per row; every x entry loaded once)"}
+                 "per row streamed position-major: 56 B per row; every x entry loaded once)",
+             11: "z-marching bricks for SYMMETRIC 7-point-class matrices without a value dictionary (mask byte per row + the diagonal "
+                 "and the three upper fp64 values per row streamed position-major: 32 B per row; the lower values are the "
+                 "neighbouring rows' upper ones, taken from registers / an LDS image of the plane's values)"}
 
 
 SHORT_FMT = {0: "fmt0 csr, x gathered", 1: "fmt1 windowed tiles: u16 slots + f64 values",
@@ -83,7 +86,8 @@ SHORT_FMT = {0: "fmt0 csr, x gathered", 1: "fmt1 windowed tiles: u16 slots + f64
              4: "fmt4 pattern byte/row + value dictionary (0 B/nnz)", 5: "fmt5 pattern byte/row + streamed f64 values (8 B/nnz)",
              6: "fmt6 wide tiles: u16 slots + f64 values (10 B/nnz)", 7: "fmt7 wide tiles: pattern byte/row + f64 values",
              8: "fmt8 wide tiles: pattern byte/row + value dictionary", 9: "fmt9 z-marching bricks: pattern byte/row + value dictionary (0 B/nnz)",
-             10: "fmt10 z-marching bricks: mask byte/row + streamed f64 values (56 B/row)"}
+             10: "fmt10 z-marching bricks: mask byte/row + streamed f64 values (56 B/row)",
+             11: "fmt11 z-marching bricks, symmetric: mask byte/row + diagonal and upper f64 values (32 B/row)"}
 BASELINE_CONFIG = {
     "poisson3d-512": "configs[4]: CG on 3-D 7-point Poisson 512^3 (diagonal 6, off-diagonals -1); fits one GPU, so the "
                      "1/2/4/8 series is strong scaling over this fixed problem",
@@ -930,9 +934,9 @@ def main():
                 traffic, tnote = ent, "measured with rocprofv3 PMC at this kernel build (%s)" % tj.get("measured", "?")
             elif ent:
                 tnote = "profiles/spmv_traffic.json was measured at another kernel build or format: not quoted"
-        kname = ("mk_spmv_kernel<CgFusedEpiT,MkNoGate,false,%d> (x,p update + SpMV + <p,Ap>)" % (12 if fmt["format"] == 10 else 11)
+        kname = ("mk_spmv_kernel<CgFusedEpiT,MkNoGate,false,%d> (x,p update + SpMV + <p,Ap>)" % {9: 11, 10: 12, 11: 13}.get(fmt["format"], 11)
                  if fused else
-                 "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,%d> (SpMV + fused <p,Ap>)" % {9: 11, 10: 12}.get(fmt["format"], fmt["format"]))
+                 "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,%d> (SpMV + fused <p,Ap>)" % {9: 11, 10: 12, 11: 13}.get(fmt["format"], fmt["format"]))
         roof = {"bound": "hbm", "kernel": kname, "fused_pass": fused,
                 "kernel_format": fmt["format_name"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

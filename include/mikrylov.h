@@ -207,9 +207,15 @@ MK_API int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn,
  *      row is its 7-bit presence mask and the values are streamed from seven position-major arrays (56 bytes per row,
  *      +0.0 where a row has no entry) -- what format 5 streams, with every x entry loaded once.  Chosen automatically
  *      (same size rule) when format 9 finds more than 256 values or patterns; asked for explicitly on any matrix of the class.
- * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 10 = the most compact format the matrix qualifies for;
+ *      Formats 9 .. 11 also serve ONE RANK'S SLAB of such a matrix -- whole planes, columns localised by mk_csr_localize
+ *      mode 0, halo exchange -- taking the neighbours' planes from the received entries.
+ *  11  format 10 for matrices that are SYMMETRIC bit for bit (what CG runs on): only the diagonal and the three upper values
+ *      of a row are stored and streamed (32 bytes per row); the lower ones are the neighbouring rows' upper values, which
+ *      the march has in registers (plane below) or passes through an LDS image of the plane's values (row before, line
+ *      below).  The builder verifies the symmetry entry by entry; a matrix that is not symmetric stays format 10.
+ * fmt = -1 restores the default (environment MK_SPMV_FORMAT, else 11 = the most compact format the matrix qualifies for;
  * format 3 is chosen automatically for scattered matrices with more than 5 MiB of x).  A request is an upper bound and
- * degrades silently (10 -> 9 -> 8, 8 -> 7 -> 6 -> 0, 5 -> 1, 4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the
+ * degrades silently (11 -> 10, 10 -> 9 -> 8, 8 -> 7 -> 6 -> 0, 5 -> 1, 4 -> 2 -> 1 -> 0, 3 -> 0): tiles with scattered columns always take the
  * gather path of format 0.
  * mk_csr_format_info reports what is in use: the format, the number of windowed tiles, the LDS chunks (128
  * doubles each) a workgroup reserves (format 3: the number of column phases), the dictionary size and the bytes of

@@ -319,7 +319,7 @@ struct CgSolver : mk_solver {
         const MkPlan *plan = A ? mk_csr_plan(A) : nullptr;
         // one device, or one rank's slab under a halo exchange (the march takes the neighbours' planes from the received entries)
         const bool slab = plan && A->ex.mode == 0 && nx == n + A->ex.n_halo && (plan->pen_xlo >= 0 || plan->pen_xhi >= 0);
-        fused = want_fuse() && plan && (plan->fmt == 9 || plan->fmt == 10) && !precon_fn && A->nops == 0 && !A->comp_kind &&
+        fused = want_fuse() && plan && mk_fmt_march(plan->fmt) && !precon_fn && A->nops == 0 && !A->comp_kind &&
                 ((!mk_comm_active() && A->ex.mode < 0 && nx == n) || slab);
         flushed = false;
         if (fused && !d_p2) {

@@ -298,7 +298,7 @@ extern "C" int mk_csr_set_exchange(mk_csr *A, int mode, int64_t n_local, int64_t
     if (A->comp_kind || A->host_fn)                          // (composites and shells have no arrays to split into tiles)
         return mk_fail(MK_ERR_UNSUPPORTED, "mk_csr_set_exchange: only a plain device matrix can carry an exchange plan "
                        "(partition the operands of a composite, not the composite)");
-    if (A->plan.built && (A->plan.fmt == 9 || A->plan.fmt == 10)) mk_csr_plan_reset(A);   // (single-device formats: rebuilt as 4 / 5)
+    if (A->plan.built && mk_fmt_march(A->plan.fmt)) mk_csr_plan_reset(A);   // (single-device formats: rebuilt as 4 / 5)
     MK_ARG(n_local == A->nrows);
     MK_ARG(n_local + n_halo == A->ncols);     // columns are already remapped to [local | halo]
     MkExchange &ex = A->ex;

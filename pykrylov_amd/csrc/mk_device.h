@@ -188,7 +188,7 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         if (g3 >= 8) g3 -= g3 % 8;
         return g3;
     }
-    if (P && (P->fmt == 9 || P->fmt == 10)) {                // one workgroup per (brick, chunk) item, at most MK_MAXP
+    if (P && mk_fmt_march(P->fmt)) {                         // one workgroup per (brick, chunk) item, at most MK_MAXP
         const int64_t items = (int64_t)P->pen_bpp * P->pen_chunks;
         return (int)(items > MK_MAXP ? MK_MAXP : items);
     }
@@ -261,7 +261,7 @@ static inline MkCsrView mk_view(const mk_csr *A) {
     v.part = 0;
     const MkPlan *P = mk_csr_plan(A);
     v.fmt = P ? P->fmt : 0;
-    if (v.fmt == 9 || v.fmt == 10) {
+    if (mk_fmt_march(v.fmt)) {
         v.pid = P->d_pid;
         v.sval = P->d_sval;                                  // (format 10: seven value arrays, position major)
         v.ptab = P->d_ptab;
@@ -332,7 +332,7 @@ static inline int mk_pen_items(const MkCsrView &v) {
 // view of the interior (part 1) or boundary (part 2) tiles of a partitioned matrix; poff2 = grid of part 1
 static inline MkCsrView mk_view_part(const mk_csr *A, int part, int poff2) {
     MkCsrView v = mk_view(A);
-    if (v.fmt == 9 || v.fmt == 10) {                        // plane ranges instead of tile lists
+    if (mk_fmt_march(v.fmt)) {                              // plane ranges instead of tile lists
         int za = 0, zb = v.pen_nz;
         mk_pen_split(mk_csr_plan(A), &za, &zb);             // (the caller checked that the slab splits)
         if (part == 2) {
@@ -629,6 +629,7 @@ constexpr int MK_FMT_WIDE_NT = 9;                    // 9 = 7 with non-temporal 
 constexpr int MK_FMT_PAIR = 10;                      // format 3 with a second tile per workgroup in registers (rows <= 5 entries)
 constexpr int MK_FMT_PENCIL = 11;                    // format 9: z-marching bricks (mk_spmv_fmt9.h)
 constexpr int MK_FMT_PENCIL_STREAM = 12;             // format 10: the same march with streamed values (no dictionary)
+constexpr int MK_FMT_PENCIL_SYM = 13;                // format 11: ... of a symmetric matrix (diagonal and upper values only)
 
 template <int FMT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
@@ -637,8 +638,9 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     else if constexpr (FMT == 1) mk_spmv_tiles_fmt1<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 3) mk_spmv_tiles_fmt3<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == MK_FMT_PAIR) mk_spmv_tiles_fmt3r<5, PROG>(A, x, epi, prod, xw, acc);
-    else if constexpr (FMT == MK_FMT_PENCIL) mk_spmv_tiles_fmt9<PROG, false>(A, x, epi, xw, acc);
-    else if constexpr (FMT == MK_FMT_PENCIL_STREAM) mk_spmv_tiles_fmt9<PROG, true>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL) mk_spmv_tiles_fmt9<PROG, false, false>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL_STREAM) mk_spmv_tiles_fmt9<PROG, true, false>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL_SYM) mk_spmv_tiles_fmt9<PROG, true, true>(A, x, epi, xw, acc);
     else if constexpr (FMT == MK_FMT_WIDE || FMT == MK_FMT_WIDE_DICT || FMT == MK_FMT_WIDE_NT)
         mk_spmv_tiles_wide<FMT == MK_FMT_WIDE_DICT, FMT == MK_FMT_WIDE_NT, PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT >= 5) mk_spmv_tiles_fmt5<PROG, FMT == 6>(A, x, epi, prod, xw, acc);
@@ -653,7 +655,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : ((FMT == 11 || FMT == 12) ? MK_PEN_OCC : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : ((FMT == 11 || FMT == 12 || FMT == 13) ? MK_PEN_OCC : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
@@ -738,6 +740,10 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
     } else if (v.fmt == 10) {                                // ... the same without a pattern table
         lds = sizeof(double) * (size_t)MK_PEN_LDS;
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_STREAM>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
+                           epi, gate, halt, partials);
+    } else if (v.fmt == 11) {                                // ... of a symmetric matrix: + the image of the plane's values
+        lds = sizeof(double) * (size_t)MK_PEN_LDS_SYM;
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_SYM>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
                            epi, gate, halt, partials);
     } else if (v.fmt == 4) {                                 // windows + pattern table, or the gather path's products
         size_t wtop = (size_t)(128 * v.wchunks + 2);

@@ -517,8 +517,8 @@ void plan_free(MkPlan &P) {
 int default_format() {
     static int f = [] {
         const char *e = getenv("MK_SPMV_FORMAT");
-        int v = e ? atoi(e) : 10;
-        return v < 0 ? 0 : (v > 10 ? 10 : v);
+        int v = e ? atoi(e) : 11;
+        return v < 0 ? 0 : (v > 11 ? 11 : v);
     }();
     return f;
 }
@@ -1156,6 +1156,42 @@ __global__ __launch_bounds__(MK_BLOCK) void pen_stream_fill(int64_t nrows, const
     }
 }
 
+// format 11: is the format-10 matrix symmetric bit for bit?  A lower entry (slot k = 0, 1, 2 at distance off = P, L, 1) must be
+// there exactly when row r - off has the mirrored upper entry (slot 6 - k), with the same bits; seen from every row this covers
+// every pair.  A slab's first plane is exempt at slot 0 (its -P entries mirror the NEIGHBOUR's +P entries: kept beside the four
+// arrays), its last plane's +P entries have no local mirror at all.  state[1] is raised by the first violation.
+__global__ __launch_bounds__(MK_BLOCK) void pen_sym_check(int64_t nrows, int64_t L, int64_t P, int64_t lo_rows,
+                                                          const uint8_t *__restrict__ pid, const double *__restrict__ sval,
+                                                          int *state) {
+    const int64_t off[3] = {P, L, 1};
+    for (int64_t r = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * MK_BLOCK) {
+        const unsigned m = pid[r];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k == 0 && r < lo_rows) continue;             // (a slab's first plane: the mirror lives on the rank below)
+            const int64_t q = r - off[k];
+            const bool have = (m >> k) & 1u;
+            const bool mirror = q >= 0 && ((pid[q] >> (6 - k)) & 1u);
+            if (have != mirror) bad = true;
+            else if (have && __double_as_longlong(sval[(int64_t)k * nrows + r]) != __double_as_longlong(sval[(int64_t)(6 - k) * nrows + q]))
+                bad = true;
+        }
+        if (bad) {
+            state[1] = 1;
+            return;
+        }
+    }
+}
+
+// ... then only the diagonal and the upper values are kept: sym[(k - 3) * nrows + r] = sval[k * nrows + r], k = 3 .. 6, and
+// behind them the -P values of the first plane (what a slab's first plane multiplies the plane below with; zeros otherwise)
+__global__ __launch_bounds__(MK_BLOCK) void pen_sym_pack(int64_t nrows, int64_t P, const double *__restrict__ sval,
+                                                         double *__restrict__ sym) {
+    for (int64_t i = (int64_t)blockIdx.x * MK_BLOCK + threadIdx.x; i < 4 * nrows + P; i += (int64_t)gridDim.x * MK_BLOCK)
+        sym[i] = i < 4 * nrows ? sval[3 * nrows + i] : sval[i - 4 * nrows];
+}
+
 // Below this many rows the windowed pattern format (fmt 4) keeps the matrix: a brick march needs a few thousand
 // (brick, chunk) items of >= 8 planes to fill the chip, and a cache-resident product is latency bound either way
 int64_t pencil_min_rows() {
@@ -1262,14 +1298,32 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
             hipFree(d_sval);
             return drop();
         }
+        P.fmt = 10;
+        P.sell_entries = 7 * A->nrows;
+        if (want >= 11) {                                    // format 11: symmetric bit for bit? then 4 of the 7 arrays do
+            double *d_sym = nullptr;
+            hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
+            hipLaunchKernelGGL(pen_sym_check, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, L, PP, A->loc_lo ? PP : (int64_t)0,
+                               d_pid, d_sval, d_state);
+            if (read_state() && !h_state[1] && hipGetLastError() == hipSuccess &&
+                hipMalloc((void **)&d_sym, sizeof(double) * (4 * (size_t)A->nrows + (size_t)PP) + 64) == hipSuccess) {
+                hipLaunchKernelGGL(pen_sym_pack, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, PP, d_sval, d_sym);
+                if (hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess) {
+                    hipFree(d_sval);
+                    d_sval = d_sym;
+                    P.fmt = 11;
+                    P.sell_entries = 4 * A->nrows + PP;
+                } else {
+                    hipFree(d_sym);
+                }
+            }
+        }
         hipFree(d_stats);
         hipFree(d_table);
         hipFree(d_dict);
         hipFree(d_keys);
-        P.fmt = 10;
         P.d_pid = d_pid;
         P.d_sval = d_sval;
-        P.sell_entries = 7 * A->nrows;
         P.npat = 0;
         pencil_geometry(A, P, L, PP);
         return true;
@@ -1418,7 +1472,7 @@ void mk_csr_march_pref(const mk_csr *A, int pref) {
     if (o->solver_users > 0 && o->plan.built) return;
     o->march_pref = pref;
     if (!o->plan.built) return;
-    const bool march = o->plan.fmt == 9 || o->plan.fmt == 10;
+    const bool march = mk_fmt_march(o->plan.fmt);
     if ((pref == 0 && march) || (pref == 1 && !march && o->nrows >= pencil_min_rows() && o->nnz <= 7 * o->nrows && o->ex.mode != 1)) {
         hipStreamSynchronize(mk_ctx().stream);
         plan_free(o->plan);
@@ -1427,7 +1481,7 @@ void mk_csr_march_pref(const mk_csr *A, int pref) {
 
 extern "C" int mk_csr_set_format(mk_csr *A, int fmt) {
     MK_REQUIRE_INIT();
-    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 10);
+    MK_ARG(A != nullptr && fmt >= -1 && fmt <= 11);
     if (A->base) return mk_fail(MK_ERR_ARG, "mk_csr_set_format: set the format on the matrix a composed operator was built from");
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
@@ -1441,12 +1495,12 @@ extern "C" int mk_csr_format_info(const mk_csr *A, int32_t *fmt, int64_t *tiles_
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
     if (fmt) *fmt = P->fmt;
-    if (P->fmt == 9 || P->fmt == 10) {                      // one byte per row + the pattern table (9) / seven values per row (10)
+    if (mk_fmt_march(P->fmt)) {                             // one byte per row + the pattern table (9) / seven (10) or four (11) values per row
         if (tiles_windowed) *tiles_windowed = 0;
         if (lds_chunks) *lds_chunks = 0;
         if (dict_size) *dict_size = P->ndict;
         if (matrix_bytes_per_product)
-            *matrix_bytes_per_product = A->nrows + (P->fmt == 9 ? 64 * (int64_t)P->npat : 56 * A->nrows);
+            *matrix_bytes_per_product = A->nrows + (P->fmt == 9 ? 64 * (int64_t)P->npat : (P->fmt == 10 ? 56 : 32) * A->nrows);
         return MK_OK;
     }
     const bool windowed = (P->fmt == 1 || P->fmt == 2 || P->fmt >= 4);
@@ -1526,7 +1580,7 @@ extern "C" int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t
     MK_REQUIRE_INIT();
     MK_ARG(A != nullptr);
     const MkPlan *P = mk_csr_plan(A);
-    const bool on = P->fmt == 9 || P->fmt == 10;
+    const bool on = mk_fmt_march(P->fmt);
     if (stride_line) *stride_line = on ? P->pen_L : 0;
     if (stride_plane) *stride_plane = on ? P->pen_P : 0;
     if (planes) *planes = on ? P->pen_nz : 0;

@@ -99,6 +99,7 @@ constexpr int MK_WCHUNK = 128;     // doubles per window chunk (one wave-level 1
 constexpr int MK_WCHUNKS_MAX = 16; // chunks per tile (4 per wave): 16 KiB of LDS windows at most
 constexpr int MK_WCHUNKS_WIDE = 32; // ... of the wide cover (8 per wave, 32 KiB), tiles of up to MK_WIDE_TILE nonzeros
 constexpr int MK_WIDE_TILE = 8192;
+static inline bool mk_fmt_march(int fmt) { return fmt >= 9 && fmt <= 11; }   // the brick-march formats (mk_spmv_fmt9.h)
 struct MkPlan {
     bool built = false;
     int fmt = 0;                   // 9 z-marching bricks: pattern byte per row + dictionary, 7-point-class matrices (below);

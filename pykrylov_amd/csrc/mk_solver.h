@@ -243,7 +243,7 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
     const mk_csr *A = s->A;
     if (timed) s->spmv_begin();
     const MkPlan *plan = A->ex.pending ? mk_csr_plan(A) : nullptr;
-    const bool march = plan && (plan->fmt == 9 || plan->fmt == 10);
+    const bool march = plan && mk_fmt_march(plan->fmt);
     int za, zb;
     if (A->ex.pending && march && !mk_pen_split(plan, &za, &zb)) {
         int rc = mk_exchange_wait(A, s->stream);             // a slab of too few planes to split: the messages first

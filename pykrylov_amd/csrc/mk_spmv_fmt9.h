@@ -74,14 +74,32 @@ constexpr int MK_PEN_RS = 132;                               // LDS row: [0] pad
 constexpr int MK_PEN_LDS = 3 * 6 * MK_PEN_RS + MK_BLOCK;     // doubles: two plane images of 6 rows + the dump rows (lanes without an
                                                              // edge row store there, at the same buffer offset as the others)
 
+// SYM (storage format 11): format 10 for matrices that are SYMMETRIC bit for bit -- what CG runs on.  Only the diagonal and the
+// upper offsets (+1, +L, +P) are stored, 32 B per row instead of 56: a(r, r-1) is row r-1's +1 value -- the left lane's, or
+// for a wave's first lane the west edge row's; a(r, r-L) is row r-L's +L value -- the lane one brick line below, or for the
+// first line the halo line's; a(r, r-P) is the +P value the lane itself loaded one plane earlier.  The first two travel
+// through an LDS image of the plane's values beside the image of x (written before the step's barrier, read after it), the
+// third stays in two registers.  A lower value is ANDed with the row's presence mask: the product's mask trick needs the VALUE
+// of an absent entry to be +0.0, and a clamped edge load may have fetched a stranger's.  The first plane of a rank's slab
+// takes its -P values (the neighbour's +P values) from an array of one plane behind the four value arrays.
+constexpr int MK_PEN_VB = 6 * 128 + 4 * MK_PEN_RS;           // doubles per buffer of the value image: 5 lines of +L values (halo
+                                                             // line, four brick lines) + a dump line, 4 lines of +1 values
+constexpr int MK_PEN_LDS_SYM = MK_PEN_LDS + 2 * MK_PEN_VB;
+
+// v where the mask is all ones, +0.0 where it is zero
+__device__ __forceinline__ double mk_pen_sel(double v, unsigned m) {
+    return __hiloint2double((int)((unsigned)__double2hiint(v) & m), (int)((unsigned)__double2loint(v) & m));
+}
+
 // STREAM (storage format 10): the same march for matrices of the class WITHOUT a value dictionary (variable coefficients):
 // the byte per row is the row's 7-bit presence mask itself and the values are streamed from seven arrays in column-position-
 // major order, sval[k * nrows + r] = the value at offset k of row r or +0.0 (one 16-byte non-temporal load per position and
 // lane and plane, two planes ahead): 56 B per row of values -- what fmt 5 streams -- with every x entry loaded once.
-template <bool PROG, bool STREAM, class Epi, int NACC>
+template <bool PROG, bool STREAM, bool SYM, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
                                                    double *smem, double (&acc)[NACC]) {
     constexpr int R = MK_PEN_R, RS = MK_PEN_RS, BUF = 6 * MK_PEN_RS;
+    static_assert(!SYM || STREAM, "the symmetric march streams its values");
     static_assert(MK_PEN_R % 2 == 0 && MK_PEN_R % MK_PEN_H == 0, "ring geometry");
     static_assert(MK_PEN_R == 6, "mk_pen_split (mk_device.h) cuts a slab's boundary planes in rounds of 6");
     constexpr bool ROWX = !PROG && MkHasRowX<Epi>::value;
@@ -121,6 +139,15 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     double *cdst = smem + (1 + w) * RS + 2 + 2 * l;
     double *hdst = smem + (tid < 128 ? 0 : 5) * RS + 2 + (tid & 127);
     double *edst = tid < 8 ? smem + (1 + (tid & 3)) * RS + ((tid & 4) ? 130 : 1) : smem + 2 * BUF + tid;
+    // SYM: the value image (per buffer: +L values [6][128] -- line 0 the halo line below the brick, 1..4 the brick's lines, 5 a
+    // dump line -- then +1 values [4][RS] with the west edge row's at [1])
+    [[maybe_unused]] double *vimg = smem + MK_PEN_LDS;
+    [[maybe_unused]] double *vl_own = vimg + (1 + w) * 128 + 2 * l, *vl_halo = vimg + (tid < 128 ? 0 : 5) * 128 + (tid & 127);
+    [[maybe_unused]] double *vw_own = vimg + 6 * 128 + w * RS + 2 + 2 * l;
+    [[maybe_unused]] double *vw_edge = tid < 4 ? vimg + 6 * 128 + tid * RS + 1 : vimg + 5 * 128 + (tid & 127);
+    [[maybe_unused]] const double *sv4 = SYM ? A.sval + A.nrows : nullptr, *sv5 = SYM ? A.sval + 2 * A.nrows : nullptr,
+                                  *sv6 = SYM ? A.sval + 3 * A.nrows : nullptr;     // (+1, +L, +P values; the diagonal's lead the block)
+    [[maybe_unused]] mk_d2 vlo{0.0, 0.0};                    // SYM: the +P values of the plane before = this plane's -P values
 
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         // item -> (brick, chunk).  Workgroup b runs on XCD b % 8 and every XCD has its own L2: with bricks dealt round robin the
@@ -155,6 +182,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         double hreg[H], ereg[H];
         mk_d2 ring[R];
         unsigned pidr[H];
+        [[maybe_unused]] double hvr[SYM ? H : 1], evr[SYM ? H : 1];     // SYM: +L values of the halo line below, +1 values of the west edge rows
         [[maybe_unused]] double hr[FUSE ? H : 1], er[FUSE ? H : 1];      // fuse: r at the halo rows
         [[maybe_unused]] mk_d2 rr[FUSE ? H : 1], xx[FUSE ? H : 1];      // fuse: r and x at the own rows of the plane to transform next
         auto halo = [&](int p, int d) {                       // plane p at the halo rows + the pattern bytes of the own rows
@@ -166,6 +194,10 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 er[d] = epi.fuse_r[clampr((int64_t)p * P + ec)];
             }
             pidr[d] = *reinterpret_cast<const uint16_t *>(pid + (int64_t)p * P + c);
+            if constexpr (SYM) {
+                hvr[d] = sv5[clampr((int64_t)p * P + hc)];
+                evr[d] = sv4[clampr((int64_t)p * P + ec)];
+            }
         };
         [[maybe_unused]] auto plane_of = [&](const double *v, int p) -> mk_d2 {     // (r of a slab's neighbour planes: received)
             const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
@@ -200,7 +232,12 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         };
         // one plane: slots (xm, xc, xp) = planes zz-1, zz, zz+1 at the own rows; hv / ev / pp = halo rows and pattern bytes of plane zz
         [[maybe_unused]] auto vals = [&](int p, int sl) {     // STREAM: the 14 values of the own rows of plane p
-            if constexpr (STREAM) {
+            if constexpr (SYM) {                             // diagonal, +1, +L, +P: slots 3 .. 6
+                p = p > nz - 1 ? nz - 1 : p;
+#pragma unroll
+                for (int k = 3; k < 7; ++k)
+                    vr[sl][k] = __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(A.sval + (int64_t)(k - 3) * A.nrows + (int64_t)p * P + c));
+            } else if constexpr (STREAM) {
                 p = p > nz - 1 ? nz - 1 : p;
 #pragma unroll
                 for (int k = 0; k < 7; ++k)
@@ -208,7 +245,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             }
         };
         auto step = [&](int zz, int bo, const mk_d2 xm_, const mk_d2 xc_, const mk_d2 xp_, double hv, double ev, unsigned pp,
-                        const mk_d2 (&vv)[7], auto &&reload, auto &&after) {
+                        const mk_d2 (&vv)[7], [[maybe_unused]] double hvv, [[maybe_unused]] double evv, auto &&reload, auto &&after) {
             [[maybe_unused]] double oa[4], ob[4];             // the epilogue's own-row operands of rows c, c + 1 (<= 4 vectors)
             if constexpr (XPF || RPF) {
                 static_assert(Epi::NPF <= 4, "at most four prefetched epilogue operands");
@@ -223,7 +260,27 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             xm.x = epi.xin(xm_.x); xm.y = epi.xin(xm_.y);
             xc.x = epi.xin(xc_.x); xc.y = epi.xin(xc_.y);
             xp.x = epi.xin(xp_.x); xp.y = epi.xin(xp_.y);
-            if constexpr (STREAM) {                          // the byte IS the mask; the values arrived with the plane
+            [[maybe_unused]] const int vbo = (bo / BUF) * MK_PEN_VB;
+            if constexpr (SYM) {                             // own values now, the three lower ones after the barrier
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    ma[k] = (unsigned)__builtin_amdgcn_sbfe((int)pp, k, 1);
+                    mb[k] = (unsigned)__builtin_amdgcn_sbfe((int)pp, 8 + k, 1);
+                }
+#pragma unroll
+                for (int k = 3; k < 7; ++k) {
+                    va[k] = vv[k].x;
+                    vb[k] = vv[k].y;
+                }
+                va[0] = mk_pen_sel(vlo.x, ma[0]);            // a(r, r - P) = the +P value of the same row one plane below
+                vb[0] = mk_pen_sel(vlo.y, mb[0]);
+                vb[2] = mk_pen_sel(vv[4].x, mb[2]);          // a(c + 1, c) = row c's +1 value
+                vlo = vv[6];
+                *reinterpret_cast<mk_d2 *>(vl_own + vbo) = vv[5];
+                *reinterpret_cast<mk_d2 *>(vw_own + vbo) = vv[4];
+                vl_halo[vbo] = hvv;
+                vw_edge[vbo] = evv;
+            } else if constexpr (STREAM) {                   // the byte IS the mask; the values arrived with the plane
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
                     va[k] = vv[k].x;
@@ -254,6 +311,12 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             const double *row = cdst + bo;
             const mk_d2 lo = *reinterpret_cast<const mk_d2 *>(row - RS), up = *reinterpret_cast<const mk_d2 *>(row + RS);
             const double we = row[-1], ea = row[2];
+            if constexpr (SYM) {
+                const mk_d2 vl = *reinterpret_cast<const mk_d2 *>(vl_own + vbo - 128);    // the line below this lane's
+                va[1] = mk_pen_sel(vl.x, ma[1]);
+                vb[1] = mk_pen_sel(vl.y, mb[1]);
+                va[2] = mk_pen_sel(vw_own[vbo - 1], ma[2]);  // a(c, c - 1) = row c - 1's +1 value
+            }
             const int64_t r = (int64_t)zz * P + c;
             const double na[7] = {xm.x, lo.x, we, xc.x, xc.y, up.x, xp.x}, nb[7] = {xm.y, lo.y, xc.x, xc.y, ea, up.y, xp.y};
             double sa = 0.0, sb = 0.0;
@@ -283,6 +346,10 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             }
             after();
         };
+        if constexpr (SYM) {                                  // the -P values of the chunk's first plane
+            const double *src = z0 > 0 ? sv6 + (int64_t)(z0 - 1) * P + c : (A.pen_xlo >= 0 ? A.sval + 4 * A.nrows + c : sv6 + c);
+            vlo = *reinterpret_cast<const mk_d2 *>(src);
+        }
         const int zfull = z0 + ((z1 - z0) / R) * R;          // planes of the pipelined rounds; the rest one by one below
         if (zfull > z0) {
             [[maybe_unused]] mk_d2 rm1{0.0, 0.0}, r00{0.0, 0.0}, x00{0.0, 0.0};
@@ -319,7 +386,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                     const int zz = z + d;
                     if constexpr (FUSE) transform(ring[(d + 2) % R], rr[(d + 1) % H], xx[(d + 1) % H], zz + 1, true);
                     step(zz, (d & 1) * BUF, ring[d], ring[(d + 1) % R], ring[(d + 2) % R], halo_val(hreg[d % H], hr[FUSE ? d % H : 0]),
-                         halo_val(ereg[d % H], er[FUSE ? d % H : 0]), pidr[d % H], vr[STREAM ? d % VD : 0], [&]() {
+                         halo_val(ereg[d % H], er[FUSE ? d % H : 0]), pidr[d % H], vr[STREAM ? d % VD : 0], hvr[SYM ? d % H : 0],
+                         evr[SYM ? d % H : 0], [&]() {
                              __builtin_amdgcn_sched_barrier(0);   // (the slots' last uses stay ABOVE their reloads)
                              ring[(d + R - 1) % R] = plane(zz + R - 2);   // the slot of plane zz - 2: dead since the last step
                              halo(zz + H, d % H);
@@ -347,7 +415,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 transform(xp, rc, xcn, zz + 1, true);
             }
             vals(zz, 0);
-            step(zz, ((zz - zfull) & 1) * BUF, xm, xc, xp, halo_val(hreg[0], hr[0]), halo_val(ereg[0], er[0]), pidr[0], vr[0], [] {}, [] {});
+            step(zz, ((zz - zfull) & 1) * BUF, xm, xc, xp, halo_val(hreg[0], hr[0]), halo_val(ereg[0], er[0]), pidr[0], vr[0], hvr[0], evr[0],
+                 [] {}, [] {});
         }
         __syncthreads();                                     // the next item's first plane image overwrites this LDS
     }

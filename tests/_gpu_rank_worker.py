@@ -79,8 +79,8 @@ def main():
     Am = csr_ref.poisson3d(nxm, nym, nzm)
     rhs_m = Am.matvec(np.ones(Am.shape[0]))
     ref_m = kr.cg(Am, rhs_m, matvec_max=40)
-    for name, seed, fmt in (("cg3d_march9", None, 9), ("cg3d_march10", 5, 10)):
-        if seed is not None:
+    for name, seed, fmt in (("cg3d_march9", None, 9), ("cg3d_march10", 5, 10), ("cg3d_march11", 5, 11)):
+        if seed is not None and fmt == 10:
             Am = csr_ref.poisson3d_varcoef(nxm, nym, nzm, seed=seed)
             rhs_m = Am.matvec(np.ones(Am.shape[0]))
             ref_m = kr.cg(Am, rhs_m, matvec_max=40)

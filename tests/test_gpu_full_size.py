@@ -253,9 +253,10 @@ def test_varcoef_512_runs_with_the_production_defaults(op512v):
     tiles, mbytes = ctypes.c_int64(), ctypes.c_int64()
     _lib.check(lib.mk_csr_format_info(op512v.handle, ctypes.byref(fmt), ctypes.byref(tiles), ctypes.byref(chunks),
                                       ctypes.byref(nd), ctypes.byref(mbytes)))
-    # round 5: the brick march with streamed values (format 10: 7 values + 1 mask byte per row) is the production default
-    assert fmt.value == 10 and tiles.value == 0
-    assert mbytes.value == 57 * N                                           # 56 B / row of values + 1 B / row
+    # round 5: the brick march with streamed values is the production default -- the matrix is symmetric bit for bit, so it is
+    # format 11: the diagonal and the three upper values of a row (32 B) + 1 mask byte per row
+    assert fmt.value == 11 and tiles.value == 0
+    assert mbytes.value == 33 * N
     o, s, p, nt = (ctypes.c_int32() for _ in range(4))
     _lib.check(lib.mk_csr_tile_order(op512v.handle, ctypes.byref(o), ctypes.byref(s), ctypes.byref(p), ctypes.byref(nt)))
     assert nt.value == 1

@@ -287,6 +287,89 @@ def test_format10_cg_fused_bit_exact_and_equal_to_the_three_kernel_pass(dims, mo
     assert runs["1"][0] == ref["nMatvec"] and np.array_equal(runs["1"][1], ref["residHistory"]) and np.array_equal(runs["1"][2], ref["x"])
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# storage format 11: format 10 for matrices that are symmetric bit for bit (the diagonal and the upper values only)
+# ---------------------------------------------------------------------------------------------------------------------
+def sym_banded(n, L, P, rng, drop=0.3):
+    """A symmetric band matrix of the class with all values different: upper entries (r, r + off), off in {1, L, P}, kept with
+    probability 1 - drop and mirrored; a diagonal everywhere (a few zeros, a negative zero, a denormal among them)."""
+    rows, cols, vals = [np.arange(n)], [np.arange(n)], [rng.standard_normal(n)]
+    vals[0][::97] = 0.0
+    vals[0][5::101] = -0.0
+    vals[0][7::103] = 2.0 ** -1060
+    for off in (1, L, P):
+        r = np.arange(n - off)
+        keep = rng.random(n - off) >= drop
+        v = rng.standard_normal(n - off)
+        rows += [r[keep], r[keep] + off]
+        cols += [r[keep] + off, r[keep]]
+        vals += [v[keep], v[keep]]
+    return csr_ref.from_coo(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), (n, n))
+
+
+@pytest.mark.parametrize("dims", [(128, 4, 2), (128, 8, 9), (256, 4, 13), (128, 12, 31), (256, 16, 24)])
+def test_format11_symmetric_product_bit_exact(dims):
+    A = csr_ref.poisson3d_varcoef(*dims, seed=7)
+    op = op9(A, fmt=11)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(A.shape[1])
+    y = op * x
+    assert fmt_of(op) == 11
+    assert np.array_equal(y, A.matvec(x))
+    x[::5] = 0.0
+    x[3::7] *= -1e200
+    assert np.array_equal(op * x, A.matvec(x))
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.3, 0.7])
+def test_format11_generic_symmetric_band(drop):
+    """No grid geometry (the +-1 entries cross line ends), any symmetric subset of the offsets, every value different; an
+    infinity in x next to entries a row does not have; the same matrix made unsymmetric in ONE value stays format 10."""
+    n, L, P = 128 * 8 * 11, 128, 1024
+    rng = np.random.default_rng(17)
+    A = sym_banded(n, L, P, rng, drop=drop)
+    op = op9(A, fmt=11)
+    x = rng.standard_normal(n)
+    assert np.array_equal(op * x, A.matvec(x)) and fmt_of(op) == 11
+    j = int(rng.integers(P, n - P))
+    x[j] = np.inf
+    with np.errstate(invalid="ignore"):
+        ref = A.matvec(x)
+    got = op * x
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert np.array_equal(got[fin], ref[fin])
+    B = csr_ref.RefCsr(A.indptr, A.indices, A.data.copy(), A.shape)
+    k = int(np.nonzero(B.indices[: B.indptr[n // 2]] > np.repeat(np.arange(n // 2), np.diff(B.indptr[: n // 2 + 1])))[0][-1])
+    B.data[k] = np.nextafter(B.data[k], np.inf)              # one upper value one ulp off its mirror
+    opb = op9(B, fmt=11)
+    x[j] = 1.0
+    assert np.array_equal(opb * x, B.matvec(x)) and fmt_of(opb) == 10
+
+
+@pytest.mark.parametrize("dims", [(128, 8, 9), (256, 8, 26)])
+def test_format11_cg_equals_format10_bit_for_bit(dims, monkeypatch):
+    """Same rows, same bits, same workgroup shares: CG on format 11 (fused passes and three-kernel passes) is the run on
+    format 10 to the last bit of the history and of the iterate."""
+    from pykrylov_amd import CG
+    A = csr_ref.poisson3d_varcoef(*dims, seed=7)
+    n = A.shape[0]
+    rhs = A.matvec(np.ones(n))
+    runs = {}
+    for fmt in (11, 10):
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("MK_CG_FUSE", fuse)
+            op = op9(A, symmetric=True, fmt=fmt)
+            assert _solver_is_fused(op, rhs) == (fuse == "1")
+            s = CG(op)
+            s.solve(rhs, matvec_max=150)
+            assert fmt_of(op) == fmt
+            runs[fmt, fuse] = (s.nMatvec, np.array(s.residHistory), s.x.copy())
+    base = runs[10, "0"]
+    for key, r in runs.items():
+        assert r[0] == base[0] and np.array_equal(r[1], base[1]) and np.array_equal(r[2], base[2]), key
+
+
 def test_automatic_march_follows_the_loop(monkeypatch):
     """The brick march is chosen per matrix but pays only for loops whose product epilogue loads nothing (CG, plain
     products): an automatically formatted matrix of the class is in format 9 for a plain product and for CG, goes back to

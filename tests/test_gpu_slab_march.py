@@ -71,7 +71,7 @@ def local_oracle(op):
     return csr_ref.RefCsr(ip, ix, dat, (int(op.shape[0]), int(op.shape[1])))
 
 
-@pytest.mark.parametrize("varcoef,fmt", [(False, 9), (True, 10)])
+@pytest.mark.parametrize("varcoef,fmt", [(False, 9), (True, 10), (True, 11)])
 @pytest.mark.parametrize("nr,rank,planes", [(4, 0, 7), (4, 2, 7), (4, 3, 7), (3, 1, 20), (2, 0, 2)])
 def test_slab_product_bit_exact(varcoef, fmt, nr, rank, planes):
     from pykrylov_amd import _lib
@@ -97,7 +97,7 @@ def test_slab_product_bit_exact(varcoef, fmt, nr, rank, planes):
         lib.mk_comm_destroy()
 
 
-@pytest.mark.parametrize("varcoef,fmt,fmt_ref", [(False, 9, 4), (True, 10, 5)])
+@pytest.mark.parametrize("varcoef,fmt,fmt_ref", [(False, 9, 4), (True, 10, 5), (True, 11, 5)])
 @pytest.mark.parametrize("nr,rank,planes", [(4, 1, 20), (4, 0, 14), (4, 3, 13), (4, 2, 7)])
 def test_cg_on_the_slab_two_launch_product(varcoef, fmt, fmt_ref, nr, rank, planes):
     """planes = 20 / 14 / 13: interior + boundary launches (both neighbours, upper only, lower only); 7: too few planes to
@@ -131,7 +131,7 @@ def test_cg_on_the_slab_two_launch_product(varcoef, fmt, fmt_ref, nr, rank, plan
     assert np.linalg.norm(x - x0) <= 1e-12 * np.linalg.norm(x0)
 
 
-@pytest.mark.parametrize("varcoef,fmt", [(False, 9), (True, 10)])
+@pytest.mark.parametrize("varcoef,fmt", [(False, 9), (True, 10), (True, 11)])
 @pytest.mark.parametrize("nr,rank,planes", [(4, 1, 20), (4, 0, 14), (4, 3, 13), (4, 2, 7), (2, 1, 3)])
 def test_fused_cg_passes_on_the_slab_change_no_bit(varcoef, fmt, nr, rank, planes, monkeypatch):
     """CG on a slab of the march runs FUSED passes too (csrc/mk_cg.hip): the neighbours' planes of p are formed on the spot
