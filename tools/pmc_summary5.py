@@ -38,7 +38,7 @@ def main():
                 fmt = int(k.rstrip(">").split(",")[-1])
                 ent = {"bytes": int(c["FETCH_SIZE"] * 2048 + c["WRITE_SIZE"] * 1024),
                        "read_bytes": int(c["FETCH_SIZE"] * 2048), "written_bytes": int(c["WRITE_SIZE"] * 1024),
-                       "format": {6: 5, 11: 9, 12: 10}.get(fmt, fmt), "kernel": k, "avg_us_in_trace": dur.get(k)}
+                       "format": {6: 5, 11: 9, 12: 10, 13: 11}.get(fmt, fmt), "kernel": k, "avg_us_in_trace": dur.get(k)}
                 if key and key.startswith("stencil27"):      # (template values 7 / 8 -> formats 7 / 8)
                     ent["format"] = fmt
                 if key and "CgFusedEpi" in k:                 # fused passes: THE product kernel of the workload
