@@ -29,6 +29,7 @@ enum { S_RY0 = 0, S_RY1 = 1, S_THRESH = 2, S_RESID = 3, S_RESID0 = 4, S_PAP = 5,
 template <bool NTY>
 struct CgSpmvEpiT {
     static constexpr int NACC = 1, SLOT0 = 0;
+    static constexpr bool SYM_MARCH = true;                  // (CG's matrices are symmetric: format 11, mk_device.h MkSymMarch)
     const double *p;
     double *Ap;
     double pr;
@@ -56,6 +57,7 @@ using CgSpmvEpi = CgSpmvEpiT<false>;
 template <bool NTY>
 struct CgFusedEpiT {
     static constexpr int NACC = 1, SLOT0 = 0;
+    static constexpr bool SYM_MARCH = true;
     double *Ap;
     const double *fuse_r;
     double *fuse_x, *fuse_p, *fuse_dump;

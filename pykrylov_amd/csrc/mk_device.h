@@ -427,6 +427,21 @@ struct MkHasPre<Epi, std::void_t<decltype(std::declval<Epi &>().pre((int64_t)0))
 // optional epilogue hook `void row_x(int64_t r, double s, double xr, double *acc)`: an epilogue whose own vector IS the
 // product's input (CG: <p, Ap>) takes x[r] from the kernel -- in the pattern format it sits in the tile's LDS window --
 // instead of loading it a second time through `pre`
+// Compile-time budget.  The brick-march kernels (unrolled, software-pipelined) are by far the most expensive instantiations of
+// mk_spmv_kernel, so an epilogue says where it can never meet them: `static constexpr bool NO_MARCH = true` -- the
+// least-squares loops' (their operators are rectangular; the march formats are for square 7-point-class matrices) -- and
+// `static constexpr bool SYM_MARCH = true` marks the few that may meet format 11, the symmetric twin (plain products and CG:
+// mk_csr_march_pref caps every other loop's matrix at format 10).  A launch that falls outside takes the CSR gather kernel
+// on the same arrays (format 0: same row sums bit for bit), which only a format forced by hand can bring about.
+template <class Epi, class = void>
+struct MkNoMarch : std::false_type {};
+template <class Epi>
+struct MkNoMarch<Epi, std::enable_if_t<Epi::NO_MARCH>> : std::true_type {};
+template <class Epi, class = void>
+struct MkSymMarch : std::false_type {};
+template <class Epi>
+struct MkSymMarch<Epi, std::enable_if_t<Epi::SYM_MARCH>> : std::true_type {};
+
 template <class Epi, class = void>
 struct MkHasRowX : std::false_type {};
 template <class Epi>
@@ -733,19 +748,31 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         const size_t w = sizeof(double) * (size_t)(128 * v.wchunks + 2) + sizeof(uint32_t) * (MK_SPMV_TILE + 16);
         lds = w > lds ? w : lds;
     }
-    if (v.fmt == 9) {                                        // two plane images of the brick + the dump row
-        lds = sizeof(double) * (size_t)MK_PEN_LDS + 64 * (size_t)v.npat;
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi,
-                           gate, halt, partials);
-    } else if (v.fmt == 10) {                                // ... the same without a pattern table
-        lds = sizeof(double) * (size_t)MK_PEN_LDS;
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_STREAM>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
-                           epi, gate, halt, partials);
-    } else if (v.fmt == 11) {                                // ... of a symmetric matrix: + the image of the plane's values
-        lds = sizeof(double) * (size_t)MK_PEN_LDS_SYM;
-        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_SYM>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
-                           epi, gate, halt, partials);
-    } else if (v.fmt == 4) {                                 // windows + pattern table, or the gather path's products
+    if (mk_fmt_march(v.fmt) && (MkNoMarch<Epi>::value || (v.fmt == 11 && !MkSymMarch<Epi>::value))) {
+        MkCsrView w = v;                                     // (see MkNoMarch: a format forced by hand on a loop that has no such kernel)
+        w.fmt = 0;
+        hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 0>), dim3(grid), dim3(MK_BLOCK), lds, st, w, x, epi, gate, halt, partials);
+        return;
+    }
+    if (mk_fmt_march(v.fmt)) {
+        if constexpr (!MkNoMarch<Epi>::value) {
+            if (v.fmt == 9) {                                // two plane images of the brick + the dump row
+                lds = sizeof(double) * (size_t)MK_PEN_LDS + 64 * (size_t)v.npat;
+                hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi,
+                                   gate, halt, partials);
+            } else if (v.fmt == 10) {                        // ... the same without a pattern table
+                lds = sizeof(double) * (size_t)MK_PEN_LDS;
+                hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_STREAM>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
+                                   epi, gate, halt, partials);
+            } else if constexpr (MkSymMarch<Epi>::value) {   // ... of a symmetric matrix: + the image of the plane's values
+                lds = sizeof(double) * (size_t)MK_PEN_LDS_SYM;
+                hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_SYM>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
+                                   epi, gate, halt, partials);
+            }
+        }
+        return;
+    }
+    if (v.fmt == 4) {                                        // windows + pattern table, or the gather path's products
         size_t wtop = (size_t)(128 * v.wchunks + 2);
         if (!v.allwin && wtop < (size_t)MK_PROD_LDS) wtop = (size_t)MK_PROD_LDS;
         lds = sizeof(double) * (wtop + MK_BLOCK) + 16 * (size_t)(v.npat * v.pmax + 1);   // windows, zeros, table
@@ -808,6 +835,7 @@ static inline void mk_spmv_launch_view(const MkCsrView &v, int grid, hipStream_t
 template <class Epi>
 struct MkPartialOf {
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = MkNoMarch<Epi>::value, SYM_MARCH = MkSymMarch<Epi>::value;
     Epi e;
     double *ysum;
     __device__ void prologue(double *s4) { e.prologue(s4); }
@@ -852,6 +880,7 @@ struct MkWrapBase<Epi, true> {
 template <class Epi, int SIGN>
 struct MkAddOf : MkWrapBase<Epi> {   // row sum = t1[r] + s  (or - s): `(A*x) + (B*x)`, linop.py:375-398, :403-426
     static constexpr int NACC = Epi::NACC, SLOT0 = Epi::SLOT0;
+    static constexpr bool NO_MARCH = MkNoMarch<Epi>::value, SYM_MARCH = MkSymMarch<Epi>::value;
     const double *t1;
     __device__ void prologue(double *s4) { this->e.prologue(s4); }
     __device__ double xin(double v) const { return this->e.xin(v); }
@@ -860,6 +889,7 @@ struct MkAddOf : MkWrapBase<Epi> {   // row sum = t1[r] + s  (or - s): `(A*x) + 
 template <class Epi>
 struct MkNoXin : MkWrapBase<Epi> {   // the outer product of `A*(B*x)`: its input B*x was formed from xin(x) already
     static constexpr int NACC = Epi::NACC, SLOT0 = Epi::SLOT0;
+    static constexpr bool NO_MARCH = MkNoMarch<Epi>::value, SYM_MARCH = MkSymMarch<Epi>::value;
     __device__ void prologue(double *s4) { this->e.prologue(s4); }
     __device__ double xin(double v) const { return v; }
     __device__ void row(int64_t r, double s, double *acc) { this->e.row(r, s, acc); }

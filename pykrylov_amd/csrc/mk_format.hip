@@ -1374,7 +1374,8 @@ int plan_build(const mk_csr *A) {
     MkPlan &P = A->plan;
     P.built = true;
     P.fmt = 0;
-    const int want = A->want_fmt >= 0 ? A->want_fmt : default_format();
+    int want = A->want_fmt >= 0 ? A->want_fmt : default_format();
+    if (want == 11 && A->no_sym) want = 10;                  // (format 11 has kernels for plain products and CG only)
     if (A->nnz == 0 || A->ntiles == 0 || !mk_ctx().ready || A->host_fn || A->comp_kind) return MK_OK;
     auto plain = [&]() -> int {                              // plain CSR: x too long for an L2?
         if (cblocks_build(A) != MK_OK) {                     // (separate launches per column block: off by default)
@@ -1468,6 +1469,17 @@ void mk_csr_plan_reset(const mk_csr *A) {
 // are alive on the matrix (their partial-sum counts were sized for the format in use) or the caller fixed the format.
 void mk_csr_march_pref(const mk_csr *A, int pref) {
     const mk_csr *o = A->base ? A->base : A;
+    if (!o->comp_kind && !o->host_fn && !(o->solver_users > 0 && o->plan.built)) {
+        // format 11 (the symmetric march) is CG's and plain products': any other loop gets the same matrix as format 10
+        const bool no_sym = (pref == 0);
+        if (no_sym != o->no_sym) {
+            o->no_sym = no_sym;
+            if (o->plan.built && ((no_sym && o->plan.fmt == 11) || (!no_sym && o->plan.fmt == 10 && o->want_fmt == 11))) {
+                hipStreamSynchronize(mk_ctx().stream);
+                plan_free(o->plan);
+            }
+        }
+    }
     if (o->want_fmt >= 9 || o->comp_kind || o->host_fn) return;
     if (o->solver_users > 0 && o->plan.built) return;
     o->march_pref = pref;

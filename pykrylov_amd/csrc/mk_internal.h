@@ -196,6 +196,8 @@ struct mk_csr {
     // the march's pipelined loop (CG, plain products): -1 no solver has asked yet (march allowed), 1 the last solver created
     // on this matrix was CG, 0 another loop (its products keep the windowed formats 4 / 5); mk_csr_march_pref, mk_format.hip
     mutable int march_pref = -1;
+    mutable bool no_sym = false;   // the last solver created on the matrix is not CG: a request for format 11 (symmetric march,
+                                   // CG's and plain products' kernels only) is served as format 10
     mutable int solver_users = 0;  // live solvers on this matrix (the preference only changes while there is none)
     mutable bool doomed = false;
     double *d_comp_tmp = nullptr;  // first product's row sums (sum / difference) or B x (product)

@@ -59,6 +59,7 @@ __device__ __forceinline__ double window_test(const double *bi, double *bo, bool
 // without, u and Mu are one vector, as in the reference where the names alias.  Same for N, v and Nv.
 struct EpiU {        // Mu <- A v - alpha Mu ; u = M(Mu) ; <u, Mu>
     static constexpr int NACC = 1, SLOT0 = SLOT_UU;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *blk;
     double *u;
     const double *dm;
@@ -84,6 +85,7 @@ struct EpiU {        // Mu <- A v - alpha Mu ; u = M(Mu) ; <u, Mu>
 
 struct OpNormU {     // beta ; u /= beta
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *part;
     int np;
     double *scal;
@@ -121,6 +123,7 @@ struct GateV {       // the A' product happens only if beta > 0 (lsqr.py:258)
 
 struct EpiV {        // Nv <- A' u - beta Nv ; v = N(Nv) ; <v, Nv>
     static constexpr int NACC = 1, SLOT0 = SLOT_VV;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *scal;
     double *v;
     const double *dn;
@@ -147,6 +150,7 @@ struct EpiV {        // Nv <- A' u - beta Nv ; v = N(Nv) ; <v, Nv>
 // is EpiV's row step on it, run identically by every rank (v is replicated)
 struct OpVt {        // Nv <- t - beta Nv ; v = N(Nv) ; <v, Nv>
     static constexpr int NACC = 1, SLOT0 = SLOT_VV;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *scal;
     const double *t;
     double *v;
@@ -179,6 +183,7 @@ struct OpVt {        // Nv <- t - beta Nv ; v = N(Nv) ; <v, Nv>
 
 struct OpScaleNv {   // Nv /= alpha where the solver's G4 did v /= alpha (lsqr.py:272): only with a preconditioner N
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *scal;
     const double *blk;   // the state block that holds the new alpha
     int need_beta;       // loop: the normalisation happens inside `if beta > 0` (lsqr.py:258-272)
@@ -253,6 +258,7 @@ struct Gate {        // finishes the previous pass: ddnorm, Acond, test3, stoppi
 
 struct OpN {         // G4
     static constexpr int NACC = 1, SLOT0 = SLOT_X;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *part;
     int np;
     double *scal;
@@ -439,6 +445,7 @@ struct Gate {        // finishes the previous pass: normx and the stopping rules
 
 struct OpN {
     static constexpr int NACC = 1, SLOT0 = SLOT_X;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *part;
     int np;
     double *scal;
@@ -586,6 +593,7 @@ struct CountGate {   // loop header `while itn < itnlim` (craig.py:296, craigmr.
 
 struct OpN {         // CRAIG G4: alpha, rotations, w / wbar / x, stopping tests
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *part;
     int np;
     double *scal;
@@ -687,6 +695,7 @@ struct OpN {         // CRAIG G4: alpha, rotations, w / wbar / x, stopping tests
 
 struct OpM {         // CRAIG G5: d = (u - beta_hat d) / alpha_hat ; r += tau d ; halts the loop if G4 said so
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *blk;      // block written by this pass's G4
     const double *u;
     double *d, *r;
@@ -720,6 +729,7 @@ struct OpM {         // CRAIG G5: d = (u - beta_hat d) / alpha_hat ; r += tau d 
 
 struct OpNmr {       // CRAIG-MR G4: alpha, v normalisation, all scalars (no n-space vectors besides v)
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *part;
     int np;
     double *scal;
@@ -790,6 +800,7 @@ struct OpNmr {       // CRAIG-MR G4: alpha, v normalisation, all scalars (no n-s
 
 struct OpMmr {       // CRAIG-MR G5: dbar, d, x (all of length m)
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *blk;
     const double *u;
     double *d, *dbar, *x;
@@ -901,6 +912,7 @@ __global__ __launch_bounds__(MK_BLOCK) void lls_init_kernel(const double *part, 
 
 struct OpInitN {     // v /= alpha and the solver's n-space start vectors
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *scal;
     int kind;
     double *v, *a, *b, *x;     // LSQR: a = w ; LSMR: a = h ; CRAIG: a = w, b = wbar, x
@@ -939,6 +951,7 @@ struct OpInitN {     // v /= alpha and the solver's n-space start vectors
 
 struct OpInitM {     // CRAIG: d = u / rho ; r = tau d.  CRAIG-MR: d = u / alpha_hat
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool NO_MARCH = true;         // (rectangular operators: mk_device.h MkNoMarch)
     const double *scal;
     int kind;
     const double *u;

@@ -216,6 +216,7 @@ __device__ __forceinline__ void mk_store_stream(double *p, double v, int nt) {
 
 struct MkPlainEpi {             // y = A x, nothing fused
     static constexpr int NACC = 0, SLOT0 = 0;
+    static constexpr bool SYM_MARCH = true;                  // (may meet format 11: mk_device.h MkSymMarch)
     double *y;
     __device__ void prologue(double *) {}
     __device__ double xin(double v) const { return v; }

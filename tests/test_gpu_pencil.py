@@ -471,3 +471,49 @@ def test_every_square_loop_on_the_march_bit_exact(solver, fmt):
         assert s.nMatvec == ref["nMatvec"] and s.residNorm == ref["residNorm"]
         assert np.array_equal(s.x, ref["x"])
     assert fmt_of(op) == fmt
+
+
+def test_format11_is_cgs_other_loops_get_format10():
+    """Format 11 has kernels for plain products and CG only (compile-time budget, csrc/mk_device.h MkSymMarch): a matrix asked
+    into format 11 serves any other loop as format 10 -- same bits as a matrix asked into format 10 -- and returns to 11 for CG."""
+    import pykrylov_amd as pk
+    A = csr_ref.poisson3d_varcoef(128, 8, 10, seed=7)
+    n = A.shape[0]
+    rhs = A.matvec(np.ones(n)) + 0.05 * np.sin(np.arange(n))
+    op = op9(A, symmetric=True, fmt=11)
+    x0 = np.random.default_rng(8).standard_normal(n)
+    assert np.array_equal(op * x0, A.matvec(x0)) and fmt_of(op) == 11
+    b = pk.BiCGSTAB(op)
+    b.solve(rhs, matvec_max=30)
+    assert fmt_of(op) == 10
+    op10 = op9(A, symmetric=True, fmt=10)
+    b10 = pk.BiCGSTAB(op10)
+    b10.solve(rhs, matvec_max=30)
+    assert b.nMatvec == b10.nMatvec and b.residNorm == b10.residNorm and np.array_equal(b.x, b10.x)
+    c = pk.CG(op)
+    c.solve(rhs, matvec_max=30)
+    assert fmt_of(op) == 11
+    c10 = pk.CG(op10)
+    c10.solve(rhs, matvec_max=30)
+    assert c.nMatvec == c10.nMatvec and np.array_equal(np.array(c.residHistory), np.array(c10.residHistory)) and np.array_equal(c.x, c10.x)
+
+
+def test_least_squares_loop_on_a_matrix_forced_into_a_march_format():
+    """The least-squares loops have no march kernels (their operators are rectangular; MkNoMarch): on a square matrix that a
+    caller forced into format 9 their products take the CSR gather kernel on the same arrays -- same row sums, so the run
+    follows the one on format 0 to rounding (the dots group differently)."""
+    from pykrylov_amd import lls
+    A = csr_ref.poisson3d(128, 4, 6)
+    n = A.shape[0]
+    b = A.matvec(np.ones(n)) + 0.1 * np.cos(np.arange(n))
+    runs = []
+    for fmt in (9, 0):
+        op = op9(A, symmetric=True, fmt=fmt)
+        s = lls.LSQRFramework(op)
+        s.solve(b, itnlim=40, show=False)
+        runs.append((s.itn, s.x.copy(), float(s.r1norm)))
+        x0 = np.random.default_rng(1).standard_normal(n)
+        assert np.array_equal(op * x0, A.matvec(x0)) and fmt_of(op) == fmt
+    assert runs[0][0] == runs[1][0] == 40
+    assert np.linalg.norm(runs[0][1] - runs[1][1]) <= 1e-10 * np.linalg.norm(runs[1][1])
+    assert abs(runs[0][2] - runs[1][2]) <= 1e-10 * runs[1][2]
