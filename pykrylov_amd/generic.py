@@ -249,13 +249,32 @@ class DeviceRun(object):
     # afterwards, so nothing of the probe survives but the choice.  A draw costs about 0.2 s and 4 GB (transient) at
     # 512^3 and pays back only after thousands of passes, which is why it is not the default: a solve that converges in
     # ~100 passes would get slower.  What was drawn is recorded in `self.placement`.
+    # AUTOMATIC, QUICK draws (round 5) for the one class where they decide the product kernel too: CG with fused passes on a
+    # brick-march matrix (formats 9 - 11) streams no matrix data to speak of, everything its kernels move lives in the solver's
+    # own vectors, and about three draws in eight land in the fast state (pass 1.72 instead of 1.88 ms at 512^3,
+    # profiles/r05_placement_draws_fused_march.txt).  There up to 6 draws of 2 + 6 passes run by themselves (about 25 ms each at
+    # 512^3; the search stops at the first draw 5 % faster than the first) unless MK_PLACEMENT_DRAWS / `placement_draws` says
+    # otherwise (1 = off).
+    def _auto_draw_class(self):
+        if self._params.kind != _lib.MK_CG:
+            return False
+        fmt = ctypes.c_int32(0)
+        try:
+            _lib.check(self.lib.mk_csr_format_info(self.op.handle, ctypes.byref(fmt), None, None, None, None))
+        except Exception:
+            return False
+        return 9 <= fmt.value <= 11
+
     def _draws(self):
         if self._setup_done or getattr(self, '_drawn', False):
             return 1
         want = getattr(self, 'placement_draws', None)
+        self._quick_draws = False
         if want is None:
             env = os.environ.get('MK_PLACEMENT_DRAWS')
-            want = int(env) if env else 1
+            want = int(env) if env else 0
+        if want == 0:                                        # nobody asked: the automatic rule
+            want, self._quick_draws = 6, True
         min_mb = float(os.environ.get('MK_PLACEMENT_MIN_MB', '256'))      # (tests lower it to draw on small problems)
         if want <= 1 or 8 * self.n <= min_mb * 1024 * 1024:
             return 1
@@ -263,6 +282,8 @@ class DeviceRun(object):
             return 1
         from .linop import CsrOperator
         if not isinstance(self.op, CsrOperator):             # (matrix-free shells: every pass calls back to the host)
+            return 1
+        if self._quick_draws and not self._auto_draw_class():
             return 1
         return min(want, 8)
 
@@ -290,10 +311,14 @@ class DeviceRun(object):
         spacers, best, best_t = [], self.handle, None
         t_probe = time.perf_counter()
         per_draw, chosen = [], 0
+        quick = getattr(self, '_quick_draws', False)
+        warm, passes = (2, 6) if quick else (4, 12)
         try:
-            best_t = self._timed_passes(self.handle)
+            best_t = first_t = self._timed_passes(self.handle, warm, passes)
             per_draw.append(1e3 * best_t)
             for k in range(1, draws):
+                if quick and best_t < 0.95 * first_t:        # (a draw in the fast state: stop looking)
+                    break
                 try:
                     sp_mb = int(os.environ.get('MK_PLACEMENT_SPACER_MB', '176'))
                     spacers.append(_lib.DeviceArray(((sp_mb + (sp_mb // 2) * k) << 20) // 8 + 512 * k, zero=False))
@@ -303,7 +328,7 @@ class DeviceRun(object):
                     break                                     # (no memory for another draw: keep what we have)
                 try:
                     self._apply_precon(h)
-                    t = self._timed_passes(h)
+                    t = self._timed_passes(h, warm, passes)
                 except Exception:
                     self.lib.mk_solver_destroy(h)
                     break
@@ -318,7 +343,8 @@ class DeviceRun(object):
             for sp in spacers:
                 sp.free()
             self.placement = {"count": len(per_draw), "chosen": chosen, "per_draw_ms_per_pass": per_draw,
-                              "probe_seconds": time.perf_counter() - t_probe, "passes_per_draw": 16}
+                              "probe_seconds": time.perf_counter() - t_probe, "passes_per_draw": warm + passes,
+                              "automatic": bool(quick)}
 
     def setup(self):
         draws = self._draws()
