@@ -54,10 +54,14 @@ using CgSpmvEpi = CgSpmvEpiT<false>;
 
 // K1f: the brick march's "fuse" hooks (mk_spmv_fmt9.h).  Only ever launched on a format-9 matrix; the other formats'
 // instantiations exist because the launcher is generic and are never run.
+#ifndef MK_FUSE_NT_DEF
+#define MK_FUSE_NT_DEF 7                                     // 1 nt loads of x, 2 nt stores of x, 4 nt stores of the new p (profiles/r05_fuse_nt_ab.txt: all three)
+#endif
 template <bool NTY>
 struct CgFusedEpiT {
     static constexpr int NACC = 1, SLOT0 = 0;
     static constexpr bool SYM_MARCH = true;
+    static constexpr int FUSE_NT = NTY ? MK_FUSE_NT_DEF : 0;  // vectors beyond the Infinity Cache: x / the new p past the caches too
     double *Ap;
     const double *fuse_r;
     double *fuse_x, *fuse_p, *fuse_dump;

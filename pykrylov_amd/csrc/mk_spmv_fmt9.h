@@ -104,6 +104,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     static_assert(MK_PEN_R == 6, "mk_pen_split (mk_device.h) cuts a slab's boundary planes in rounds of 6");
     constexpr bool ROWX = !PROG && MkHasRowX<Epi>::value;
     constexpr bool FUSE = MkHasFuse<Epi>::value;
+    constexpr int FNT = [] { if constexpr (MkHasFuse<Epi>::value) return (int)Epi::FUSE_NT; else return 0; }();
     // epilogue operands loaded at the top of a step (mk_device.h: row_pf / row_x_pf)
     constexpr bool XPF = !PROG && MkHasRowXPf<Epi>::value;
     constexpr bool RPF = !XPF && MkHasRowPf<Epi>::value;
@@ -203,6 +204,11 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
             return *reinterpret_cast<const mk_d2 *>(v + o + c);
         };
+        [[maybe_unused]] auto plane_of_x = [&](const double *v, int p) -> mk_d2 {   // x: read by its owner only
+            const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
+            if constexpr (FNT & 1) return __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(v + o + c));
+            else return *reinterpret_cast<const mk_d2 *>(v + o + c);
+        };
         // fuse: raw p_old of plane `pl` in pv with its r (and x) -> p (in pv) and x; both written out when the plane is one of
         // this chunk's own (anything else lands in the workgroup's dump rows: every store of the loop is unconditional)
         [[maybe_unused]] auto transform = [&](mk_d2 &pv, const mk_d2 rv, const mk_d2 xv, int pl, bool store) {
@@ -221,8 +227,11 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                     double *pd = own ? epi.fuse_p + (int64_t)pl * P + c : dump;
                     pd = (pl == -1 && A.pen_xlo >= 0) ? epi.fuse_p + off_lo + c : pd;
                     pd = (pl == nz && A.pen_xhi >= 0) ? epi.fuse_p + off_hi + c : pd;
-                    *reinterpret_cast<mk_d2 *>(pd) = pv;
-                    *reinterpret_cast<mk_d2 *>(own ? epi.fuse_x + (int64_t)pl * P + c : dump + 512) = xn;
+                    if constexpr (FNT & 4) __builtin_nontemporal_store(pv, reinterpret_cast<mk_d2 *>(pd));
+                    else *reinterpret_cast<mk_d2 *>(pd) = pv;
+                    mk_d2 *xd = reinterpret_cast<mk_d2 *>(own ? epi.fuse_x + (int64_t)pl * P + c : dump + 512);
+                    if constexpr (FNT & 2) __builtin_nontemporal_store(xn, xd);
+                    else *xd = xn;
                 }
             }
         };
@@ -356,7 +365,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             if constexpr (FUSE) {                             // r (and x) of the two planes the ring starts with
                 rm1 = plane_of(epi.fuse_r, z0 - 1);
                 r00 = plane_of(epi.fuse_r, z0);
-                x00 = plane_of(epi.fuse_x, z0);
+                x00 = plane_of_x(epi.fuse_x, z0);
             }
 #pragma unroll
             for (int d = 0; d < R - 1; ++d) {                 // (issue order = consumption order; slot R - 1 is loaded by step 0)
@@ -366,7 +375,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 if constexpr (FUSE) {
                     if (d < H) {                              // plane z0 + 1 + d -> slot (1 + d) % H
                         rr[(1 + d) % H] = plane_of(epi.fuse_r, z0 + 1 + d);
-                        xx[(1 + d) % H] = plane_of(epi.fuse_x, z0 + 1 + d);
+                        xx[(1 + d) % H] = plane_of_x(epi.fuse_x, z0 + 1 + d);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -393,7 +402,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                              halo(zz + H, d % H);
                              if constexpr (FUSE) {            // plane zz + 1 + H into the slot plane zz + 1 just left
                                  rr[(d + 1) % H] = plane_of(epi.fuse_r, zz + 1 + H);
-                                 xx[(d + 1) % H] = plane_of(epi.fuse_x, zz + 1 + H);
+                                 xx[(d + 1) % H] = plane_of_x(epi.fuse_x, zz + 1 + H);
                              }
                          }, [&]() { vals(zz + VD, d % VD); });   // (values: their slot is free once the row sums are formed)
                 }
@@ -407,7 +416,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 // planes zz - 1 and zz are formed again from p_old and r (x was updated when they were written: not touched);
                 // a chunk without pipelined rounds writes its first plane here; plane zz + 1 is formed and written now
                 const mk_d2 ra = plane_of(epi.fuse_r, zz - 1), rb = plane_of(epi.fuse_r, zz), rc = plane_of(epi.fuse_r, zz + 1);
-                const mk_d2 xb = plane_of(epi.fuse_x, zz), xcn = plane_of(epi.fuse_x, zz + 1);
+                const mk_d2 xb = plane_of_x(epi.fuse_x, zz), xcn = plane_of_x(epi.fuse_x, zz + 1);
                 if (zz == z0) transform(xm, ra, ra, zz - 1, true);   // (written only as a slab's neighbour plane, see above)
                 else transform(xm, ra, ra, zz - 1, false);
                 if (zz == z0) transform(xc, rb, xb, zz, true);
