@@ -252,9 +252,9 @@ class DeviceRun(object):
     # AUTOMATIC, QUICK draws (round 5) for the one class where they decide the product kernel too: CG with fused passes on a
     # brick-march matrix (formats 9 - 11) streams no matrix data to speak of, everything its kernels move lives in the solver's
     # own vectors, and about three draws in eight land in the fast state (pass 1.72 instead of 1.88 ms at 512^3,
-    # profiles/r05_placement_draws_fused_march.txt).  There up to 6 draws of 2 + 6 passes run by themselves (about 25 ms each at
-    # 512^3; the search stops at the first draw 5 % faster than the first) unless MK_PLACEMENT_DRAWS / `placement_draws` says
-    # otherwise (1 = off).
+    # profiles/r05_placement_draws_fused_march.txt).  There 6 draws of 2 + 6 passes run by themselves (about 25 ms each at
+    # 512^3; all six: the states come in four levels, and stopping at the first draw that beats the first one was seen to
+    # settle for a middle one) unless MK_PLACEMENT_DRAWS / `placement_draws` says otherwise (1 = off).
     def _auto_draw_class(self):
         if self._params.kind != _lib.MK_CG:
             return False
@@ -314,11 +314,9 @@ class DeviceRun(object):
         quick = getattr(self, '_quick_draws', False)
         warm, passes = (2, 6) if quick else (4, 12)
         try:
-            best_t = first_t = self._timed_passes(self.handle, warm, passes)
+            best_t = self._timed_passes(self.handle, warm, passes)
             per_draw.append(1e3 * best_t)
             for k in range(1, draws):
-                if quick and best_t < 0.95 * first_t:        # (a draw in the fast state: stop looking)
-                    break
                 try:
                     sp_mb = int(os.environ.get('MK_PLACEMENT_SPACER_MB', '176'))
                     spacers.append(_lib.DeviceArray(((sp_mb + (sp_mb // 2) * k) << 20) // 8 + 512 * k, zero=False))
