@@ -1,3 +1,6 @@
+"""Debug aid (round 5): where does the brick march on a slab differ from the scalar loop over the localised arrays?  Prints the
+mismatching rows (plane, in-plane index, stored column order) per rank / format; this is how the storage order of a localised
+row -- the order of its GLOBAL columns -- was found.  `python tools/dbg/slab_dbg.py` on a GPU box."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
