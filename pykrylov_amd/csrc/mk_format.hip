@@ -704,7 +704,20 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     if (!ok || h_max < 1) return MK_OK;
     const int cap = (h_max + 255) / 256 * 256;
     if (cap > RT_CAP_MAX) return MK_OK;                      // long rows: the chunked gather path
-    int64_t k = (xbytes + RT_SLICE_BYTES - 1) / RT_SLICE_BYTES;
+    // short rows and more tiles than resident workgroups: pairs of tiles, the second one in registers (mk_spmv_fmt3r.h).
+    // MK_RT_REG=0 keeps one tile per step (A/B measurements).
+    P.max_row = h_mm[1];
+    static const char *ereg = getenv("MK_RT_REG");
+    const int allow = ereg ? atoi(ereg) : 1;
+    const int rt_reg = (allow >= 1 && h_mm[1] <= 5 && A->ntiles > MK_MAXP && 8 * A->x_len() < ((int64_t)1 << 31)) ? 1 : 0;
+    static const char *estep = getenv("MK_RT_STEPPED");
+    const bool stepped = rt_reg && A->ntiles > 2 * (int64_t)MK_MAXP && (!estep || atoi(estep) > 0);
+    // column phases (speed only: a row's sum runs in column order whatever the phases).  Round 5 sweep (profiles/
+    // r05_scattered_phase_sweep.txt): a product of ONE step per workgroup is fastest with slices of about 1 MiB (config 3: 8 - 9
+    // phases, +1 % over the 6 of 1.5 MiB), a product of MANY steps with slices of 0.6 MiB (the 4e6-row `A v`: 12 - 16 phases,
+    // LSQR +7 %): two neighbouring slices then share an L2 and workgroups a phase apart still hit it
+    const int64_t slice = stepped ? (int64_t)640 << 10 : (int64_t)1 << 20;   // (column blocks set their own phases: cblocks_build)
+    int64_t k = (xbytes + slice - 1) / slice;
     static const char *env = getenv("MK_RT_PHASES");
     if (env && atoi(env) > 0) k = atoi(env);
     k = k < 1 ? 1 : (k > 64 ? 64 : k);
@@ -712,14 +725,8 @@ int resident_plan(const mk_csr *A, MkPlan &P, bool forced) {
     P.rt_cap = cap;
     P.rt_k = (int)k;
     P.rt_w = (int)((A->x_len() + k - 1) / k);
-    // short rows and more tiles than resident workgroups: pairs of tiles, the second one in registers (mk_spmv_fmt3r.h).
-    // MK_RT_REG=0 keeps one tile per step (A/B measurements).
-    P.max_row = h_mm[1];
-    static const char *ereg = getenv("MK_RT_REG");
-    const int allow = ereg ? atoi(ereg) : 1;
-    P.rt_reg = (allow >= 1 && h_mm[1] <= 5 && A->ntiles > MK_MAXP && 8 * A->x_len() < ((int64_t)1 << 31)) ? 1 : 0;
-    static const char *estep = getenv("MK_RT_STEPPED");
-    if (P.rt_reg && A->ntiles > 2 * (int64_t)MK_MAXP && (!estep || atoi(estep) > 0)) {
+    P.rt_reg = rt_reg;
+    if (stepped) {
         if (hipMalloc((void **)&P.d_carry, sizeof(double) * MK_CARRY_SLOTS * MK_MAXP * MK_BLOCK) != hipSuccess) P.d_carry = nullptr;
     }
     return MK_OK;
