@@ -40,6 +40,10 @@ typedef enum {
 
 /* ------------------------------------------------------------------ context ---- */
 MK_API int mk_version(void);
+/* Digest (16 hex digits) of the sources this binary was compiled from -- csrc/*.hip, csrc/*.h and this header, as
+ * pykrylov_amd/build.py `source_sha()` computes it -- or "unknown" for a build made without build.py.  The Python package
+ * refuses to load a library whose digest differs from its tree's (MIKRYLOV_ALLOW_STALE=1 overrides). */
+MK_API const char *mk_build_info(void);
 /* Bind the calling process to `device`, create the compute stream.  Idempotent. */
 MK_API int mk_init(int device);
 MK_API int mk_shutdown(void);
@@ -257,6 +261,19 @@ MK_API int mk_csr_launch_info(const mk_csr *A, int32_t *grid, int32_t *tile_map)
  * fused dots (test infrastructure). */
 MK_API int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t *stride_plane, int32_t *planes,
                               int32_t *planes_per_chunk, int32_t *chunks, int32_t *patterns);
+/* The same and the rest of the brick geometry as an array (round 6: any grid side; all zero when A is in another format):
+ *   info[0] storage format (9 / 10 / 11)      [1] L, line stride            [2] P, plane stride         [3] planes
+ *   [4] lines per plane = ceil(P / L)          [5] bricks per line = ceil(L / 128)                       [6] brick rows = ceil(lines / 4)
+ *   [7] planes per chunk                       [8] chunks                    [9] 2 = general geometry (partly empty bricks, pairs
+ *   at any 8-byte boundary: a lane whose row does not exist -- in-line position >= L or in-plane index >= P -- discards its
+ *   row sum), 0 = whole aligned bricks          [10] per: bricks per XCD of the XCD-contiguous deal, 0 = round robin
+ *   [11] row patterns (format 9).
+ * Item i of a launch whose grid is a multiple of 8 with per > 0: brick (i % 8) per + (i / 8) % per of chunk (i / 8) / per
+ * (8 per item slots per chunk; a slot whose brick number is >= bricks per plane is empty); otherwise brick i % bpp of
+ * chunk i / bpp.  Brick j starts at row (j / bx) 4L + (j % bx) 128 of a plane.  A 5-point matrix (one far stride M) is
+ * reported as L = 128, P = M: it is marched line by line.  At most `cap` entries are written (MK_MARCH_INFO_LEN exist). */
+#define MK_MARCH_INFO_LEN 12
+MK_API int mk_csr_march_info(const mk_csr *A, int64_t *info, int32_t cap);
 
 /* y = A x   (K1; `self.op * p`, pykrylov/cg/cg.py:115 and every other solver).
  * x_dev must be 16-byte aligned and readable up to an even number of entries (one entry of slack when ncols is odd;

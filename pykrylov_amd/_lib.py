@@ -59,6 +59,7 @@ class MkResult(ctypes.Structure):
 # name -> (restype, argtypes); must list every function declared in include/mikrylov.h
 PROTOTYPES = {
     "mk_version": (ctypes.c_int, []),
+    "mk_build_info": (ctypes.c_char_p, []),
     "mk_init": (ctypes.c_int, [ctypes.c_int]),
     "mk_shutdown": (ctypes.c_int, []),
     "mk_last_error": (ctypes.c_char_p, []),
@@ -94,6 +95,7 @@ PROTOTYPES = {
     "mk_csr_format_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i64), P(c_i32), P(c_i32), P(c_i64)]),
     "mk_csr_launch_info": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32)]),
     "mk_csr_pencil_info": (ctypes.c_int, [c_vp, P(c_i64), P(c_i64), P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
+    "mk_csr_march_info": (ctypes.c_int, [c_vp, P(c_i64), c_i32]),
     "mk_csr_colblocks": (ctypes.c_int, [c_vp, P(c_i32)]),
     "mk_csr_set_tile_order": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32]),
     "mk_csr_tile_order": (ctypes.c_int, [c_vp, P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
@@ -162,8 +164,31 @@ def load():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        check_build(lib)
         _lib = lib
     return _lib
+
+
+def tree_sha():
+    """Digest of the library sources of THIS tree (pykrylov_amd/build.py `source_sha`)."""
+    from . import build as _build
+    return _build.source_sha()
+
+
+def build_info(lib=None):
+    return (lib or load()).mk_build_info().decode(errors="replace")
+
+
+def check_build(lib):
+    """Refuse a binary compiled from other sources than the tree's: libmikrylov.so is git-ignored and travels prebuilt, so
+    nothing else ties what runs to what is read.  MIKRYLOV_ALLOW_STALE=1 (or an experiment build named by MIKRYLOV_LIB)
+    overrides."""
+    if os.environ.get("MIKRYLOV_ALLOW_STALE") == "1" or os.environ.get("MIKRYLOV_LIB"):
+        return
+    have, want = lib.mk_build_info().decode(errors="replace"), tree_sha()
+    if have != want:
+        raise ImportError("libmikrylov.so was built from other sources than this tree's (binary %s, tree %s): run "
+                          "`python -m pykrylov_amd.build`, or set MIKRYLOV_ALLOW_STALE=1 to load it anyway" % (have, want))
 
 
 def check(rc):

@@ -23,6 +23,24 @@ FLAGS = [
 ]
 
 
+def source_files():
+    """Every file libmikrylov.so is compiled from, in a fixed order."""
+    return (sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.h")))
+            + [os.path.join(HERE, "..", "include", "mikrylov.h")])
+
+
+def source_sha():
+    """Digest of the library's sources (names and contents): what mk_build_info() of a current binary returns."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in source_files():
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -44,11 +62,15 @@ def build(force=False, verbose=False, tag=None, defines=()):
     os.makedirs(OBJDIR, exist_ok=True)
     objs = []
     procs = []
+    sha = source_sha()
+    stamp = os.path.join(OBJDIR, "mk_buildinfo.sha")
+    sha_changed = not os.path.exists(stamp) or open(stamp).read().strip() != sha
     for src in srcs:
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        info = os.path.basename(src) == "mk_buildinfo.hip"   # the one unit that carries the digest (mk_build_info)
+        if force or _newer(obj, [src] + hdrs) or (info and sha_changed):
+            cmd = [hipcc] + FLAGS + (['-DMK_SOURCE_SHA="%s"' % sha] if info else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -62,6 +84,8 @@ def build(force=False, verbose=False, tag=None, defines=()):
             sys.stderr.write("hipcc failed on %s\n" % src)
     if failed:
         raise RuntimeError("libmikrylov build failed")
+    with open(stamp, "w") as fh:
+        fh.write(sha + "\n")
     stale = [o for o in glob.glob(os.path.join(OBJDIR, "*.o")) if o not in objs]
     for o in stale:
         os.remove(o)

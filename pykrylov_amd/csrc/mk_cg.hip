@@ -49,6 +49,17 @@ struct CgSpmvEpiT {
         else Ap[r] = s;
         acc[0] += xr * s;
     }
+    // the brick march on a general geometry (mk_spmv_fmt9.h, GEN): rows r, r + 1 where they exist -- a row that does not is
+    // stored into the dump row and adds +0.0 (the running sum is never -0.0: unchanged bit for bit)
+    __device__ void row2_m(int64_t r, mk_d2 s, mk_d2 xr, bool oka, bool okb, double *dump, double *acc) {
+        mk_d2u *d = reinterpret_cast<mk_d2u *>(okb ? Ap + r : dump);
+        if constexpr (NTY) __builtin_nontemporal_store(s, d);
+        else *d = s;
+        if (oka && !okb) Ap[r] = s.x;
+        const double ta = xr.x * s.x, tb = xr.y * s.y;
+        acc[0] += oka ? ta : 0.0;
+        acc[0] += okb ? tb : 0.0;
+    }
 };
 using CgSpmvEpi = CgSpmvEpiT<false>;
 
@@ -80,6 +91,15 @@ struct CgFusedEpiT {
         if constexpr (NTY) __builtin_nontemporal_store(s, Ap + r);
         else Ap[r] = s;
         acc[0] += xr * s;
+    }
+    __device__ void row2_m(int64_t r, mk_d2 s, mk_d2 xr, bool oka, bool okb, double *dump, double *acc) {   // (as CgSpmvEpiT's)
+        mk_d2u *d = reinterpret_cast<mk_d2u *>(okb ? Ap + r : dump);
+        if constexpr (NTY) __builtin_nontemporal_store(s, d);
+        else *d = s;
+        if (oka && !okb) Ap[r] = s.x;
+        const double ta = xr.x * s.x, tb = xr.y * s.y;
+        acc[0] += oka ? ta : 0.0;
+        acc[0] += okb ? tb : 0.0;
     }
 };
 
@@ -328,9 +348,16 @@ struct CgSolver : mk_solver {
         fused = want_fuse() && plan && mk_fmt_march(plan->fmt) && !precon_fn && A->nops == 0 && !A->comp_kind &&
                 ((!mk_comm_active() && A->ex.mode < 0 && nx == n) || slab);
         flushed = false;
-        if (fused && !d_p2) {
-            int rc;
-            if ((rc = alloc_vec(&d_p2, nx)) || (rc = alloc_vec(&d_dump, (int64_t)MK_MAXP * 1024))) return rc;
+        if (fused && !d_p2 && (alloc_vec(&d_p2, nx) != MK_OK || alloc_vec(&d_dump, (int64_t)MK_MAXP * 1024) != MK_OK)) fused = false;
+        if (mk_comm_active()) {
+            // The choice changes what travels: fused ranks exchange r's boundary planes and form the neighbours' p themselves,
+            // the others exchange p -- messages of the same size, so a disagreement would neither hang nor fail, it would
+            // multiply by the wrong vector.  (Ranks can differ: a slab one plane thinner falls below the march's row
+            // threshold, an allocation fails on one of them.)  So all ranks fuse, or none does.
+            double veto = fused ? 0.0 : 1.0;
+            int rc = mk_comm_allreduce_host(&veto, 1);
+            if (rc != MK_OK) return rc;
+            if (veto != 0.0) fused = false;
         }
         nmv0 = 0;
         mk_launch_stream(this, MkOpNegCopy{rhs, d_r}, n);                   // r = -rhs          cg.py:85

@@ -85,6 +85,8 @@ extern "C" int mk_shutdown(void) {
     hipFree(g_halt0);
     g_halt0 = nullptr;
     hipFree(c.d_scratch);
+    hipFree(c.pen_dump);
+    c.pen_dump = nullptr;
     hipFree(c.arena);
     hipHostFree(c.h_scratch);
     hipStreamDestroy(c.stream);

@@ -84,6 +84,13 @@ struct MkCsrView {
     // [0, nz) and nothing; overlapped halo exchange: the interior planes first, the slab's first and last planes afterwards)
     int64_t pen_xlo, pen_xhi;
     int pen_za, pen_zb, pen_ya, pen_yb;
+    // general geometry (round 6): pen_gen 2 = the plane is not tiled by whole aligned bricks (L % 128, P % 4L, odd strides): the GEN
+    // kernels only; 1 = an aligned geometry whose launch has leftover planes: the GEN kernel where the epilogue has one (its
+    // masked last round replaces the unpipelined planes); pen_per > 0: bricks per XCD of the XCD-contiguous deal;
+    // pen_xtop = the last index a 16-byte pair of the input vector may start at; pen_dump = where discarded rows are stored
+    int pen_gen, pen_per;
+    int64_t pen_xtop;
+    double *pen_dump;
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
     int rt_cap, rt_k, rt_w;
     int rt_c0;               // first column of the phases (0; a column block's first column: its phases cover ITS slice of x)
@@ -112,6 +119,7 @@ static inline int mk_xcd_chunks(const mk_csr *A) {
     return bytes <= (int64_t)200 * 1024 * 1024 ? 1 : 0;
 }
 const MkPlan *mk_csr_plan(const mk_csr *A);      // mk_format.hip: builds the windowed format on first use
+double *mk_pen_dump();                           // mk_format.hip: the dump rows of the general-geometry brick march (one per context)
 // stripe length (tiles, a power of two) of tile order 3; 0 = the matrix does not use it
 static inline const mk_csr *mk_owner(const mk_csr *A) { return A->base ? A->base : A; }
 static inline int mk_tile_stripe(const mk_csr *A) {
@@ -189,7 +197,7 @@ static inline int mk_grid_spmv_for(const mk_csr *A) {
         return g3;
     }
     if (P && mk_fmt_march(P->fmt)) {                         // one workgroup per (brick, chunk) item, at most MK_MAXP
-        const int64_t items = (int64_t)P->pen_bpp * P->pen_chunks;
+        const int64_t items = (int64_t)(P->pen_per > 0 ? 8 * P->pen_per : P->pen_bpp) * P->pen_chunks;
         return (int)(items > MK_MAXP ? MK_MAXP : items);
     }
     if (P && P->fmt == 3) {                                  // as many as fit at once with one tile in LDS each
@@ -278,6 +286,10 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.pen_za = 0;
         v.pen_zb = P->pen_nz;
         v.pen_ya = v.pen_yb = 0;
+        v.pen_gen = P->pen_gen;
+        v.pen_per = P->pen_per;
+        v.pen_xtop = A->x_len() - 2;
+        v.pen_dump = P->pen_gen ? mk_pen_dump() : nullptr;
     } else if (v.fmt == 3) {
         v.rt_cap = P->rt_cap;
         v.rt_k = P->rt_k;
@@ -323,9 +335,13 @@ static inline bool mk_pen_split(const MkPlan *P, int *za, int *zb) {
     *zb = hi_s;
     return true;
 }
+static inline bool mk_pen_tail_gen() {                      // (MK_PEN_TAIL_GEN=0: the unpipelined leftover planes of round 5, for A/B runs)
+    static const char *env = getenv("MK_PEN_TAIL_GEN");
+    return !env || atoi(env) != 0;
+}
 static inline int mk_pen_items(const MkCsrView &v) {
     const int n1 = (v.pen_zb - v.pen_za + v.pen_zc - 1) / v.pen_zc, n2 = (v.pen_yb - v.pen_ya + v.pen_zc - 1) / v.pen_zc;
-    const int64_t items = (int64_t)v.pen_bpp * (n1 + n2);
+    const int64_t items = (int64_t)(v.pen_per > 0 ? 8 * v.pen_per : v.pen_bpp) * (n1 + n2);   // (8 per == bpp on an aligned geometry)
     return (int)(items > MK_MAXP ? MK_MAXP : (items < 1 ? 1 : items));
 }
 
@@ -340,6 +356,12 @@ static inline MkCsrView mk_view_part(const mk_csr *A, int part, int poff2) {
             v.pen_zb = za;
             v.pen_ya = zb;
             v.pen_yb = v.pen_nz;
+            // the slab's last 1 .. R planes: fewer than a whole round go through the GEN kernel's masked round (where the
+            // epilogue has one) instead of one unpipelined plane after the other
+            if (!v.pen_gen && (v.pen_nz - zb) % 6 != 0 && mk_pen_tail_gen()) {
+                v.pen_gen = 1;
+                v.pen_dump = mk_pen_dump();
+            }
         } else {
             v.pen_za = za;
             v.pen_zb = zb;
@@ -645,6 +667,9 @@ constexpr int MK_FMT_PAIR = 10;                      // format 3 with a second t
 constexpr int MK_FMT_PENCIL = 11;                    // format 9: z-marching bricks (mk_spmv_fmt9.h)
 constexpr int MK_FMT_PENCIL_STREAM = 12;             // format 10: the same march with streamed values (no dictionary)
 constexpr int MK_FMT_PENCIL_SYM = 13;                // format 11: ... of a symmetric matrix (diagonal and upper values only)
+constexpr int MK_FMT_PENCIL_G = 14;                  // formats 9 / 10 / 11 on a general geometry (mk_spmv_fmt9.h, GEN): 14 / 15 / 16
+constexpr int MK_FMT_PENCIL_STREAM_G = 15;
+constexpr int MK_FMT_PENCIL_SYM_G = 16;
 
 template <int FMT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
@@ -653,9 +678,12 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     else if constexpr (FMT == 1) mk_spmv_tiles_fmt1<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == 3) mk_spmv_tiles_fmt3<PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT == MK_FMT_PAIR) mk_spmv_tiles_fmt3r<5, PROG>(A, x, epi, prod, xw, acc);
-    else if constexpr (FMT == MK_FMT_PENCIL) mk_spmv_tiles_fmt9<PROG, false, false>(A, x, epi, xw, acc);
-    else if constexpr (FMT == MK_FMT_PENCIL_STREAM) mk_spmv_tiles_fmt9<PROG, true, false>(A, x, epi, xw, acc);
-    else if constexpr (FMT == MK_FMT_PENCIL_SYM) mk_spmv_tiles_fmt9<PROG, true, true>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL) mk_spmv_tiles_fmt9<PROG, false, false, false>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL_STREAM) mk_spmv_tiles_fmt9<PROG, true, false, false>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL_SYM) mk_spmv_tiles_fmt9<PROG, true, true, false>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL_G) mk_spmv_tiles_fmt9<PROG, false, false, true>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL_STREAM_G) mk_spmv_tiles_fmt9<PROG, true, false, true>(A, x, epi, xw, acc);
+    else if constexpr (FMT == MK_FMT_PENCIL_SYM_G) mk_spmv_tiles_fmt9<PROG, true, true, true>(A, x, epi, xw, acc);
     else if constexpr (FMT == MK_FMT_WIDE || FMT == MK_FMT_WIDE_DICT || FMT == MK_FMT_WIDE_NT)
         mk_spmv_tiles_wide<FMT == MK_FMT_WIDE_DICT, FMT == MK_FMT_WIDE_NT, PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT >= 5) mk_spmv_tiles_fmt5<PROG, FMT == 6>(A, x, epi, prod, xw, acc);
@@ -670,7 +698,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : ((FMT == 11 || FMT == 12 || FMT == 13) ? MK_PEN_OCC : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : ((FMT >= 11 && FMT <= 16) ? MK_PEN_OCC : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
@@ -738,6 +766,14 @@ __global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 :
     if (A.part != 1) halt.template clear_tail<Epi::NACC, Epi::SLOT0>(partials, A.poff + (int)gridDim.x);
 }
 
+// does this loop's epilogue have a kernel for the plan's march format?  (No: mk_spmv_launch_fmt runs the CSR gather kernel
+// on the matrix's arrays instead -- over all rows, so a caller must not cut such a product into plane ranges.)
+template <class Epi>
+static inline bool mk_march_kernel_for(const MkPlan *P) {
+    if (!P || !mk_fmt_march(P->fmt) || MkNoMarch<Epi>::value) return false;
+    return MkSymMarch<Epi>::value || (P->fmt != 11 && P->pen_gen != 2);
+}
+
 // Launch the instantiation that matches the operator: plain matrices never pay for the row program, matrices
 // without windowed tiles never pay for the window code.
 template <class Epi, class Gate, bool PROG>
@@ -748,13 +784,31 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         const size_t w = sizeof(double) * (size_t)(128 * v.wchunks + 2) + sizeof(uint32_t) * (MK_SPMV_TILE + 16);
         lds = w > lds ? w : lds;
     }
-    if (mk_fmt_march(v.fmt) && (MkNoMarch<Epi>::value || (v.fmt == 11 && !MkSymMarch<Epi>::value))) {
+    if (mk_fmt_march(v.fmt) && (MkNoMarch<Epi>::value || ((v.fmt == 11 || v.pen_gen == 2) && !MkSymMarch<Epi>::value))) {
         MkCsrView w = v;                                     // (see MkNoMarch: a format forced by hand on a loop that has no such kernel)
         w.fmt = 0;
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 0>), dim3(grid), dim3(MK_BLOCK), lds, st, w, x, epi, gate, halt, partials);
         return;
     }
     if (mk_fmt_march(v.fmt)) {
+        if constexpr (MkSymMarch<Epi>::value) {              // general geometry / masked leftover round (mk_spmv_fmt9.h, GEN)
+            if (v.pen_gen) {
+                if (v.fmt == 9) {
+                    lds = sizeof(double) * (size_t)MK_PEN_LDS + 64 * (size_t)v.npat;
+                    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_G>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi,
+                                       gate, halt, partials);
+                } else if (v.fmt == 10) {
+                    lds = sizeof(double) * (size_t)MK_PEN_LDS;
+                    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_STREAM_G>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
+                                       epi, gate, halt, partials);
+                } else {
+                    lds = sizeof(double) * (size_t)MK_PEN_LDS_SYM;
+                    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_SYM_G>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
+                                       epi, gate, halt, partials);
+                }
+                return;
+            }
+        }
         if constexpr (!MkNoMarch<Epi>::value) {
             if (v.fmt == 9) {                                // two plane images of the brick + the dump row
                 lds = sizeof(double) * (size_t)MK_PEN_LDS + 64 * (size_t)v.npat;
@@ -823,6 +877,7 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
 template <class Epi, class Gate>
 static inline void mk_spmv_launch_view(const MkCsrView &v, int grid, hipStream_t st, const double *x, const Epi &epi,
                                        const Gate &gate, MkHalt halt, double *partials) {
+    if (grid < 1) grid = 1;                                  // (a launch never vanishes: every kernel hands the halt word on)
     if (v.nops > 0) mk_spmv_launch_fmt<Epi, Gate, true>(v, grid, st, x, epi, gate, halt, partials);
     else mk_spmv_launch_fmt<Epi, Gate, false>(v, grid, st, x, epi, gate, halt, partials);
 }

@@ -1210,12 +1210,24 @@ int64_t pencil_min_rows() {
 }
 
 // true: P holds format 9.  false: the matrix is not of the class (P untouched apart from freed scratch).
+// bricks per line, brick rows per plane (the last brick of a line / the last group of four lines may be partly empty)
+static inline int64_t pen_bx_of(int64_t L) { return (L + 127) / 128; }
+static inline int64_t pen_by_of(int64_t L, int64_t PP) { return ((PP + L - 1) / L + 3) / 4; }
+// whole aligned bricks (round 5's geometry; the vectors' 16-byte alignment is the C ABI's)?
+static inline bool pen_aligned(int64_t L, int64_t PP) { return L % 128 == 0 && PP % (4 * L) == 0; }
+
 void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP) {
     P.pen_L = L;
     P.pen_P = PP;
     P.pen_nz = (int)(A->nrows / PP);
-    P.pen_bx = (int)(L / 128);
-    P.pen_bpp = (int)(L / 128 * (PP / (4 * L)));
+    P.pen_ny = (int)((PP + L - 1) / L);
+    P.pen_bx = (int)pen_bx_of(L);
+    P.pen_bpp = (int)(pen_bx_of(L) * pen_by_of(L, PP));
+    static const char *env_gen = getenv("MK_PEN_GEN");       // (1: the general-geometry kernels on aligned geometries too, A/B runs)
+    P.pen_gen = (!pen_aligned(L, PP) || (env_gen && atoi(env_gen) == 1)) ? 2 : 0;
+    // XCD-contiguous deal: an eighth of the plane's bricks per XCD; on a general geometry ceil(bpp / 8) with empty item slots
+    // behind the last brick, from 64 bricks per plane on (below that the empty slots would idle whole XCDs)
+    P.pen_per = (P.pen_bpp % 8 == 0) ? P.pen_bpp / 8 : ((P.pen_gen && P.pen_bpp >= 64) ? (P.pen_bpp + 7) / 8 : 0);
     P.pen_xlo = A->loc_lo ? A->nrows : -1;                   // a slab: where the neighbours' planes sit in the input vector
     P.pen_xhi = A->loc_hi ? A->nrows + A->loc_lo : -1;
     // chunks: the kernel keeps two workgroups per CU resident (its register ring), so 512 (brick, chunk) items fill the
@@ -1264,10 +1276,15 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     if (hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return drop();
-    const int64_t L = h_stats[0], PP = h_stats[1];
-    if (h_stats[2] > 7 || L >= PP || L <= 1 || L % 128 != 0 || PP % (4 * L) != 0 || A->nrows % PP != 0 || A->nrows / PP < 2 ||
-        L / 128 * (PP / (4 * L)) > (1 << 24))
-        return drop();
+    // strides: the smallest and the largest |offset| above 1.  ONE far stride only (a 5-point stencil: offsets {0, +-1, +-M}) is
+    // marched line by line: planes of M rows, cut into lines of 128 rows that have no +-L entries (the kernels are index based)
+    int64_t L = h_stats[0], PP = h_stats[1];
+    if (h_stats[2] > 7 || L <= 1 || PP < L) return drop();
+    if (L == PP) L = 128;
+    if (L >= PP || A->nrows % PP != 0 || A->nrows / PP < 2 || pen_bx_of(L) * pen_by_of(L, PP) > (1 << 24)) return drop();
+    // partly empty bricks: at least half of the lanes must have rows (L = 132, 9 lines: 39 %; L = 37: 29 %)
+    if (!pen_aligned(L, PP) && 2 * PP < 512 * pen_bx_of(L) * pen_by_of(L, PP)) return drop();
+    const size_t slack = (size_t)(4 * L + 256);              // rows past the end that a lane without rows may index (GEN)
     if ((A->loc_lo != 0 && A->loc_lo != PP) || (A->loc_hi != 0 && A->loc_hi != PP)) return drop();   // (whole planes only)
     const PenSlab sl{A->nrows, A->loc_lo, A->loc_hi};
     // the dictionary (values only: no per-nonzero words)
@@ -1292,12 +1309,13 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     auto stream_twin = [&]() -> bool {                      // format 10: mask byte + seven value arrays
         if (want < 10) return drop();
         double *d_sval = nullptr;
-        if (hipMalloc((void **)&d_pid, (size_t)A->nrows + 64) != hipSuccess ||
-            hipMalloc((void **)&d_sval, sizeof(double) * 7 * (size_t)A->nrows + 64) != hipSuccess) {
+        if (hipMalloc((void **)&d_pid, (size_t)A->nrows + 64 + slack) != hipSuccess ||
+            hipMalloc((void **)&d_sval, sizeof(double) * (7 * (size_t)A->nrows + slack) + 64) != hipSuccess) {
             hipFree(d_sval);
             return drop();
         }
-        hipMemsetAsync(d_pid, 0, (size_t)A->nrows + 64, st);
+        hipMemsetAsync(d_pid, 0, (size_t)A->nrows + 64 + slack, st);
+        hipMemsetAsync(d_sval + 7 * (size_t)A->nrows, 0, sizeof(double) * slack + 64, st);
         hipMemsetAsync(d_state, 0, 2 * sizeof(int), st);
         hipLaunchKernelGGL(pen_stream_fill, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, L, PP,
                            sl, d_pid, d_sval, d_state);
@@ -1313,7 +1331,8 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
             hipLaunchKernelGGL(pen_sym_check, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, L, PP, A->loc_lo ? PP : (int64_t)0,
                                d_pid, d_sval, d_state);
             if (read_state() && !h_state[1] && hipGetLastError() == hipSuccess &&
-                hipMalloc((void **)&d_sym, sizeof(double) * (4 * (size_t)A->nrows + (size_t)PP) + 64) == hipSuccess) {
+                hipMalloc((void **)&d_sym, sizeof(double) * (4 * (size_t)A->nrows + (size_t)PP + slack) + 64) == hipSuccess) {
+                hipMemsetAsync(d_sym + 4 * (size_t)A->nrows + (size_t)PP, 0, sizeof(double) * slack + 64, st);
                 hipLaunchKernelGGL(pen_sym_pack, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, PP, d_sval, d_sym);
                 if (hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess) {
                     hipFree(d_sval);
@@ -1347,10 +1366,10 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     if (h_state[1] || h_state[0] > 256 || h_state[0] < 1) return stream_twin();
     const int nkeys = h_state[0];
     hipLaunchKernelGGL(dict_finalize, dim3(1), dim3(MK_BLOCK), 0, st, d_table, d_state, d_keys);
-    if (hipMalloc((void **)&d_pid, (size_t)A->nrows + 64) != hipSuccess ||
+    if (hipMalloc((void **)&d_pid, (size_t)A->nrows + 64 + slack) != hipSuccess ||
         hipMalloc((void **)&d_tab, 64 * 256) != hipSuccess)
         return drop();
-    hipMemsetAsync(d_pid, 0, (size_t)A->nrows + 64, st);
+    hipMemsetAsync(d_pid, 0, (size_t)A->nrows + 64 + slack, st);
     hipMemsetAsync(d_tab, 0, 64 * 256, st);
     hipLaunchKernelGGL(pen_rows, dim3(grid), dim3(MK_BLOCK), 0, st, A->nrows, A->d_indptr, A->d_indices, A->d_data, d_dict, ndict,
                        L, PP, sl, d_table, d_state, (const double *)d_keys, nkeys, d_pid);
@@ -1591,6 +1610,26 @@ extern "C" int mk_csr_set_colblocks(mk_csr *A, int32_t block_kb) {
     MK_HIP(hipStreamSynchronize(mk_ctx().stream));
     plan_free(A->plan);
     A->want_cb_kb = block_kb;
+    return MK_OK;
+}
+
+// dump rows of the general-geometry march (mk_spmv_fmt9.h, GEN): 512 doubles per workgroup of the largest grid; what lands
+// there is never read.  One per context, allocated on first use, released by mk_shutdown.
+double *mk_pen_dump() {
+    MkContext &c = mk_ctx();
+    if (!c.pen_dump && hipMalloc((void **)&c.pen_dump, sizeof(double) * 512 * (size_t)MK_MAXP) != hipSuccess) c.pen_dump = nullptr;
+    return c.pen_dump;
+}
+
+extern "C" int mk_csr_march_info(const mk_csr *A, int64_t *info, int32_t cap) {
+    MK_REQUIRE_INIT();
+    MK_ARG(A != nullptr && info != nullptr && cap >= 0);
+    const MkPlan *P = mk_csr_plan(A);
+    const bool on = mk_fmt_march(P->fmt);
+    const int64_t v[MK_MARCH_INFO_LEN] = {on ? P->fmt : 0, P->pen_L, P->pen_P, P->pen_nz, P->pen_ny, P->pen_bx,
+                                          P->pen_bx ? P->pen_bpp / P->pen_bx : 0, P->pen_zc, P->pen_chunks, P->pen_gen, P->pen_per,
+                                          P->npat};
+    for (int k = 0; k < cap && k < MK_MARCH_INFO_LEN; ++k) info[k] = on ? v[k] : 0;
     return MK_OK;
 }
 

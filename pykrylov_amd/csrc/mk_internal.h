@@ -40,6 +40,7 @@ struct MkContext {
     char *arena = nullptr;
     size_t arena_size = 0, arena_off = 0;
     int arena_live = 0;              // vectors carved and not yet returned
+    double *pen_dump = nullptr;      // dump rows of the general-geometry brick march (mk_pen_dump, mk_format.hip)
 };
 
 MkContext &mk_ctx();
@@ -144,6 +145,9 @@ struct MkPlan {
     // and chunks; d_pid holds the pattern byte per row, d_ptab 64 bytes per pattern {7 values, mask}, npat their number
     int64_t pen_L = 0, pen_P = 0;
     int pen_nz = 0, pen_bx = 0, pen_bpp = 0, pen_zc = 0, pen_chunks = 0;
+    // general geometry (round 6): 2 = partly empty bricks / unaligned pairs (GEN kernels only), 0 = whole aligned bricks;
+    // bricks per XCD of the XCD-contiguous deal (0: round robin); lines per plane
+    int pen_gen = 0, pen_per = 0, pen_ny = 0;
     // ... of one rank's slab of planes (columns localised to [own | plane below | plane above], mk_csr_localize mode 0): where
     // the neighbours' planes start in the product's input vector (-1: the slab has no such neighbour)
     int64_t pen_xlo = -1, pen_xhi = -1;

@@ -221,6 +221,11 @@ struct MkPlainEpi {             // y = A x, nothing fused
     __device__ void prologue(double *) {}
     __device__ double xin(double v) const { return v; }
     __device__ void row(int64_t r, double s, double *) { y[r] = s; }
+    // the brick march on a general geometry (mk_spmv_fmt9.h, GEN): rows r, r + 1 where they exist
+    __device__ void row2_m(int64_t r, mk_d2 s, mk_d2, bool oka, bool okb, double *dump, double *) {
+        *reinterpret_cast<mk_d2u *>(okb ? y + r : dump) = s;
+        if (oka && !okb) y[r] = s.x;
+    }
 };
 
 template <class Op>
@@ -246,8 +251,10 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
     const MkPlan *plan = A->ex.pending ? mk_csr_plan(A) : nullptr;
     const bool march = plan && mk_fmt_march(plan->fmt);
     int za, zb;
-    if (A->ex.pending && march && !mk_pen_split(plan, &za, &zb)) {
-        int rc = mk_exchange_wait(A, s->stream);             // a slab of too few planes to split: the messages first
+    if (A->ex.pending && march && (!mk_march_kernel_for<Epi>(plan) || !mk_pen_split(plan, &za, &zb))) {
+        // a slab of too few planes to split -- or a loop without a kernel for this march format, whose product runs as the
+        // CSR gather kernel over ALL rows (a plane range means nothing to it): the messages first, then one launch
+        int rc = mk_exchange_wait(A, s->stream);
         if (rc != MK_OK) return rc;
         mk_spmv_launch_blocks(A, mk_grid_spmv_for(A), s->stream, x, epi, gate, [&] { return s->next_halt(); }, s->d_part);
     } else if (A->ex.pending) {
@@ -258,6 +265,9 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
         if (march) {                                         // plane ranges of the brick march (mk_pen_split)
             g1 = mk_pen_items(v1);
             g2 = mk_pen_items(mk_view_part(A, 2, 0));
+            // (the kernels stride their items by the grid: a plane of >= 1024 bricks must not leave the interior launch a
+            //  grid of 0 -- at most half of the partial-sum slots for the boundary planes)
+            if (g2 > MK_MAXP / 2) g2 = MK_MAXP / 2;
             if (g1 + g2 > MK_MAXP) g1 = MK_MAXP - g2;
         } else {
             mk_grid_spmv_parts(A, A->ex.n_int, A->ex.n_bnd, &g1, &g2);

@@ -54,6 +54,40 @@ struct MkHasFuse : std::false_type {};
 template <class Epi>
 struct MkHasFuse<Epi, std::void_t<decltype(std::declval<Epi &>().fuse_r)>> : std::true_type {};
 
+// GENERAL GEOMETRY (round 6; template flag GEN).  The march above needs L % 128 == 0, P % 4L == 0: bricks tile the plane and every
+// pair of rows starts at a 16-byte boundary.  GEN lifts both: a plane of P rows is cut into lines of L rows (the last one may be
+// short), a line into ceil(L / 128) bricks, lines are grouped in fours -- the last brick of a line and the last group of a
+// plane are partly EMPTY.  A lane whose row does not exist (in-line position >= L, or in-plane index >= P) still loads at its
+// natural index -- which is what makes the +-1 neighbours across line ends come out right, index based as everything here --
+// clamped into the vector, computes a row sum from whatever it found, and DISCARDS it: its stores go to a dump row, its term of
+// a fused dot is replaced by +0.0 (selects, no branch: the loop body stays one basic block).  Pairs start at any 8-byte
+// boundary (odd L or P): 16-byte accesses through an 8-byte-aligned type; a pair that would start at the vector's LAST entry
+// is loaded one entry lower and shifted.  The same masking runs a chunk's LEFTOVER planes (planes % R != 0) as one more
+// pipelined round whose planes past the end are discarded, instead of one unpipelined plane after the other -- which is why
+// a slab's boundary launch takes this kernel on any geometry (mk_device.h).  Only epilogues that may meet format 11
+// (SYM_MARCH: plain products and CG) have GEN instantiations; they provide the masked pair hook
+//     void row2_m(int64_t r, mk_d2 s, mk_d2 xr, bool oka, bool okb, double *dump, double *acc)
+// = row_x(r, s.x, xr.x, acc) if oka; row_x(r + 1, s.y, xr.y, acc) if okb (okb implies oka).
+typedef mk_d2 mk_d2u __attribute__((aligned(8)));
+typedef uint16_t mk_u16u __attribute__((aligned(1)));
+template <class Epi, class = void>
+struct MkHasRow2M : std::false_type {};
+template <class Epi>
+struct MkHasRow2M<Epi, std::void_t<decltype(std::declval<Epi &>().row2_m((int64_t)0, mk_d2{}, mk_d2{}, false, false, (double *)nullptr,
+                                                                         (double *)nullptr))>> : std::true_type {};
+
+// the pair v[idx], v[idx + 1]; `top` = the last index a pair may start at (idx == top + 1: only v[idx] exists, it comes back in .x)
+template <bool NT>
+__device__ __forceinline__ mk_d2 mk_pen_ld2(const double *v, int64_t idx, int64_t top) {
+    const bool over = idx > top;
+    const mk_d2u *p = reinterpret_cast<const mk_d2u *>(v + (over ? top : idx));
+    mk_d2 t;
+    if constexpr (NT) t = __builtin_nontemporal_load(p);
+    else t = *p;
+    t.x = over ? t.y : t.x;
+    return t;
+}
+
 // one term of a row sum: s + v * x, x with its high word ANDed by m (0xffffffff: the row has the entry; 0: it has not, v = +0.0)
 __device__ __forceinline__ double mk_pen_term(double s, double v, unsigned m, double xk) {
     return s + v * __hiloint2double((int)((unsigned)__double2hiint(xk) & m), __double2loint(xk));
@@ -95,7 +129,7 @@ __device__ __forceinline__ double mk_pen_sel(double v, unsigned m) {
 // the byte per row is the row's 7-bit presence mask itself and the values are streamed from seven arrays in column-position-
 // major order, sval[k * nrows + r] = the value at offset k of row r or +0.0 (one 16-byte non-temporal load per position and
 // lane and plane, two planes ahead): 56 B per row of values -- what fmt 5 streams -- with every x entry loaded once.
-template <bool PROG, bool STREAM, bool SYM, class Epi, int NACC>
+template <bool PROG, bool STREAM, bool SYM, bool GEN, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
                                                    double *smem, double (&acc)[NACC]) {
     constexpr int R = MK_PEN_R, RS = MK_PEN_RS, BUF = 6 * MK_PEN_RS;
@@ -108,13 +142,20 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     // epilogue operands loaded at the top of a step (mk_device.h: row_pf / row_x_pf)
     constexpr bool XPF = !PROG && MkHasRowXPf<Epi>::value;
     constexpr bool RPF = !XPF && MkHasRowPf<Epi>::value;
+    static_assert(!GEN || !(XPF || RPF), "general geometry: plain products and CG only (no prefetched epilogue operands)");
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int64_t L = A.pen_L, P = A.pen_P;
     const int nz = A.pen_nz, bx = A.pen_bx, bpp = A.pen_bpp, zc = A.pen_zc;
     // this launch's planes: [pen_za, pen_zb) and [pen_ya, pen_yb) in chunks of zc (a whole product: [0, nz) and nothing)
     const int nch1 = (A.pen_zb - A.pen_za + zc - 1) / zc, nch2 = (A.pen_yb - A.pen_ya + zc - 1) / zc;
-    const int64_t items = (int64_t)bpp * (nch1 + nch2);
+    // GEN: the XCD-contiguous deal for ANY number of bricks per plane: XCD k takes the bricks [k per, (k + 1) per), per =
+    // ceil(bpp / 8); a chunk has 8 per item slots, the ones past the plane's last brick are empty (pen_per == 0: planes of
+    // fewer than 64 bricks, dealt round robin)
+    const bool xdeal = GEN && A.pen_per > 0 && (gridDim.x & 7) == 0;
+    const int64_t items = (int64_t)(xdeal ? 8 * A.pen_per : bpp) * (nch1 + nch2);
     const int64_t last = A.nrows - 1;
+    [[maybe_unused]] const int64_t xtop = A.pen_xtop;         // GEN: the last index a pair of the input vector may start at
+    [[maybe_unused]] double *gdump = GEN ? A.pen_dump + (int64_t)blockIdx.x * 512 + 2 * tid : nullptr;
     // a rank's slab (mk_csr_localize mode 0): the planes below plane 0 / above plane nz - 1 are the neighbours', received
     // behind the own rows of the input vector; on one device the march clamps into the grid (their entries are masked).
     // Localising renumbers the columns in place and keeps every row's STORAGE order -- the order of the global columns --
@@ -156,7 +197,18 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         // second time (fused CG kernel at 512^3: 4.98 GB read for 3.35 GB of operands, profiles/r05_*).  So XCD k takes the
         // k-th contiguous eighth of a plane's bricks (whole brick rows when the plane has a multiple of 8 of them).
         int bi, chunk;
-        if ((bpp & 7) == 0 && (gridDim.x & 7) == 0) {
+        if constexpr (GEN) {
+            if (xdeal) {
+                const int per = A.pen_per;
+                const int64_t q = item >> 3;
+                chunk = (int)(q / per);
+                bi = (int)(item & 7) * per + (int)(q % per);
+                if (bi >= bpp) continue;                      // (an empty slot: workgroup uniform)
+            } else {
+                bi = (int)(item % bpp);
+                chunk = (int)(item / bpp);
+            }
+        } else if ((bpp & 7) == 0 && (gridDim.x & 7) == 0) {
             const int per = bpp >> 3;
             const int64_t q = item >> 3;
             chunk = (int)(q / per);
@@ -169,6 +221,9 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         const int z0 = chunk < nch1 ? A.pen_za + chunk * zc : A.pen_ya + (chunk - nch1) * zc, z1 = (z0 + zc < zlim) ? z0 + zc : zlim;
         const int64_t b0 = (int64_t)(bi / bx) * 4 * L + (int64_t)(bi % bx) * 128;    // the brick's first row in plane 0
         const int64_t c = b0 + (int64_t)w * L + 2 * l;                                // this lane's rows c, c + 1 (in-plane index)
+        // GEN: do this lane's rows exist?  (in-line position below L, in-plane index below P; okb implies oka)
+        [[maybe_unused]] const int cx = (bi % bx) * 128 + 2 * l;
+        [[maybe_unused]] const bool oka = !GEN || (cx < L && c < P), okb = !GEN || (cx + 1 < L && c + 1 < P);
         // halo row of this lane: lanes 0..127 the line below the brick, 128..255 the line above; lanes 0..7 also the row
         // west / east of brick line tid & 3 (lanes >= 8 load lane (tid & 7)'s edge row again and drop it into the dump row)
         const int64_t hc = tid < 128 ? b0 - L + tid : b0 + 4 * L + (tid - 128);
@@ -176,7 +231,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         auto plane = [&](int p) -> mk_d2 {                    // the own rows of plane p (clamped into the grid: values of a
             // plane that does not exist are never multiplied; a slab's neighbour planes come from the received entries)
             const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
-            return *reinterpret_cast<const mk_d2 *>(x + o + c);
+            if constexpr (GEN) return mk_pen_ld2<false>(x, o + c, xtop);
+            else return *reinterpret_cast<const mk_d2 *>(x + o + c);
         };
         auto clampr = [&](int64_t r) { return r < 0 ? (int64_t)0 : (r > last ? last : r); };
         constexpr int H = MK_PEN_H;
@@ -194,7 +250,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 hr[d] = epi.fuse_r[clampr((int64_t)p * P + hc)];
                 er[d] = epi.fuse_r[clampr((int64_t)p * P + ec)];
             }
-            pidr[d] = *reinterpret_cast<const uint16_t *>(pid + (int64_t)p * P + c);
+            if constexpr (GEN) pidr[d] = *reinterpret_cast<const mk_u16u *>(pid + (int64_t)p * P + c);   // (the array has slack behind it)
+            else pidr[d] = *reinterpret_cast<const uint16_t *>(pid + (int64_t)p * P + c);
             if constexpr (SYM) {
                 hvr[d] = sv5[clampr((int64_t)p * P + hc)];
                 evr[d] = sv4[clampr((int64_t)p * P + ec)];
@@ -202,16 +259,18 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         };
         [[maybe_unused]] auto plane_of = [&](const double *v, int p) -> mk_d2 {     // (r of a slab's neighbour planes: received)
             const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
-            return *reinterpret_cast<const mk_d2 *>(v + o + c);
+            if constexpr (GEN) return mk_pen_ld2<false>(v, o + c, xtop);
+            else return *reinterpret_cast<const mk_d2 *>(v + o + c);
         };
         [[maybe_unused]] auto plane_of_x = [&](const double *v, int p) -> mk_d2 {   // x: read by its owner only
             const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
-            if constexpr (FNT & 1) return __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(v + o + c));
+            if constexpr (GEN) return mk_pen_ld2<(FNT & 1) != 0>(v, o + c, xtop);
+            else if constexpr (FNT & 1) return __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(v + o + c));
             else return *reinterpret_cast<const mk_d2 *>(v + o + c);
         };
         // fuse: raw p_old of plane `pl` in pv with its r (and x) -> p (in pv) and x; both written out when the plane is one of
         // this chunk's own (anything else lands in the workgroup's dump rows: every store of the loop is unconditional)
-        [[maybe_unused]] auto transform = [&](mk_d2 &pv, const mk_d2 rv, const mk_d2 xv, int pl, bool store) {
+        [[maybe_unused]] auto transform = [&](mk_d2 &pv, const mk_d2 rv, const mk_d2 xv, int pl, bool store, [[maybe_unused]] bool lv = true) {
             if constexpr (FUSE) {
                 const mk_d2 po = pv;
                 pv.x = epi.fuse_pnew(po.x, rv.x);
@@ -222,6 +281,27 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                     mk_d2 xn;
                     xn.x = epi.fuse_xnew(xv.x, po.x);
                     xn.y = epi.fuse_xnew(xv.y, po.y);
+                    if constexpr (GEN) {
+                        // the same targets; a lane writes its pair where both rows exist, a row alone where only the first does
+                        // (odd L or P: divergent, rare), nothing otherwise; `lv`: the step is one of the chunk's own (not a
+                        // discarded plane of the leftover round)
+                        double *pt = own ? epi.fuse_p + (int64_t)pl * P + c : nullptr;
+                        pt = (pl == -1 && A.pen_xlo >= 0) ? epi.fuse_p + off_lo + c : pt;
+                        pt = (pl == nz && A.pen_xhi >= 0) ? epi.fuse_p + off_hi + c : pt;
+                        pt = lv ? pt : nullptr;
+                        double *xt = (own && lv) ? epi.fuse_x + (int64_t)pl * P + c : nullptr;
+                        mk_d2u *pd = reinterpret_cast<mk_d2u *>((pt && okb) ? pt : dump);
+                        mk_d2u *xd = reinterpret_cast<mk_d2u *>((xt && okb) ? xt : dump + 512);
+                        if constexpr (FNT & 4) __builtin_nontemporal_store(pv, pd);
+                        else *pd = pv;
+                        if constexpr (FNT & 2) __builtin_nontemporal_store(xn, xd);
+                        else *xd = xn;
+                        if (oka && !okb) {
+                            if (pt) *pt = pv.x;
+                            if (xt) *xt = xn.x;
+                        }
+                        return;
+                    }
                     // a slab's neighbour planes: the same p the neighbour forms for its own rows (same beta, same p_old and r
                     // bits) is kept behind the own rows of the new p buffer -- the next pass's p_old there; x is the neighbour's
                     double *pd = own ? epi.fuse_p + (int64_t)pl * P + c : dump;
@@ -244,17 +324,22 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             if constexpr (SYM) {                             // diagonal, +1, +L, +P: slots 3 .. 6
                 p = p > nz - 1 ? nz - 1 : p;
 #pragma unroll
-                for (int k = 3; k < 7; ++k)
-                    vr[sl][k] = __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(A.sval + (int64_t)(k - 3) * A.nrows + (int64_t)p * P + c));
+                for (int k = 3; k < 7; ++k) {                 // (GEN: any 8-byte boundary; the arrays have slack behind them)
+                    if constexpr (GEN) vr[sl][k] = __builtin_nontemporal_load(reinterpret_cast<const mk_d2u *>(A.sval + (int64_t)(k - 3) * A.nrows + (int64_t)p * P + c));
+                    else vr[sl][k] = __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(A.sval + (int64_t)(k - 3) * A.nrows + (int64_t)p * P + c));
+                }
             } else if constexpr (STREAM) {
                 p = p > nz - 1 ? nz - 1 : p;
 #pragma unroll
-                for (int k = 0; k < 7; ++k)
-                    vr[sl][k] = __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(A.sval + (int64_t)k * A.nrows + (int64_t)p * P + c));
+                for (int k = 0; k < 7; ++k) {
+                    if constexpr (GEN) vr[sl][k] = __builtin_nontemporal_load(reinterpret_cast<const mk_d2u *>(A.sval + (int64_t)k * A.nrows + (int64_t)p * P + c));
+                    else vr[sl][k] = __builtin_nontemporal_load(reinterpret_cast<const mk_d2 *>(A.sval + (int64_t)k * A.nrows + (int64_t)p * P + c));
+                }
             }
         };
         auto step = [&](int zz, int bo, const mk_d2 xm_, const mk_d2 xc_, const mk_d2 xp_, double hv, double ev, unsigned pp,
-                        const mk_d2 (&vv)[7], [[maybe_unused]] double hvv, [[maybe_unused]] double evv, auto &&reload, auto &&after) {
+                        const mk_d2 (&vv)[7], [[maybe_unused]] double hvv, [[maybe_unused]] double evv, auto &&reload, auto &&after,
+                        [[maybe_unused]] bool live = true) {
             [[maybe_unused]] double oa[4], ob[4];             // the epilogue's own-row operands of rows c, c + 1 (<= 4 vectors)
             if constexpr (XPF || RPF) {
                 static_assert(Epi::NPF <= 4, "at most four prefetched epilogue operands");
@@ -334,6 +419,33 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 sa = mk_pen_term(sa, va[k], ma[k], na[k]);
                 sb = mk_pen_term(sb, vb[k], mb[k], nb[k]);
             }
+            if constexpr (GEN) {                              // rows that do not exist, planes past the chunk's end: discarded
+                const bool la = oka && live, lb = okb && live;
+                if constexpr (PROG) {
+                    if (la) sa = mk_rowprog(A, sa, x, r, epi);
+                    if (lb) sb = mk_rowprog(A, sb, x, r + 1, epi);
+                }
+                if constexpr (MkHasRow2M<Epi>::value) {
+                    mk_d2 s2;
+                    s2.x = sa;
+                    s2.y = sb;
+                    epi.row2_m(r, s2, xc, la, lb, gdump, acc);
+                } else if constexpr (ROWX) {
+                    if (la) epi.row_x(r, sa, xc.x, acc);
+                    if (lb) epi.row_x(r + 1, sb, xc.y, acc);
+                } else {
+                    if (la) {
+                        if constexpr (MkHasPre<Epi>::value) epi.pre(r);
+                        epi.row(r, sa, acc);
+                    }
+                    if (lb) {
+                        if constexpr (MkHasPre<Epi>::value) epi.pre(r + 1);
+                        epi.row(r + 1, sb, acc);
+                    }
+                }
+                after();
+                return;
+            }
             if constexpr (PROG) {
                 sa = mk_rowprog(A, sa, x, r, epi);
                 sb = mk_rowprog(A, sb, x, r + 1, epi);
@@ -357,9 +469,11 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         };
         if constexpr (SYM) {                                  // the -P values of the chunk's first plane
             const double *src = z0 > 0 ? sv6 + (int64_t)(z0 - 1) * P + c : (A.pen_xlo >= 0 ? A.sval + 4 * A.nrows + c : sv6 + c);
-            vlo = *reinterpret_cast<const mk_d2 *>(src);
+            if constexpr (GEN) vlo = *reinterpret_cast<const mk_d2u *>(src);
+            else vlo = *reinterpret_cast<const mk_d2 *>(src);
         }
-        const int zfull = z0 + ((z1 - z0) / R) * R;          // planes of the pipelined rounds; the rest one by one below
+        // planes of the pipelined rounds; the rest one by one below (GEN: one more round, its planes past z1 discarded)
+        const int zfull = GEN ? z0 + ((z1 - z0 + R - 1) / R) * R : z0 + ((z1 - z0) / R) * R;
         if (zfull > z0) {
             [[maybe_unused]] mk_d2 rm1{0.0, 0.0}, r00{0.0, 0.0}, x00{0.0, 0.0};
             if constexpr (FUSE) {                             // r (and x) of the two planes the ring starts with
@@ -393,7 +507,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
 #pragma unroll
                 for (int d = 0; d < R; ++d) {
                     const int zz = z + d;
-                    if constexpr (FUSE) transform(ring[(d + 2) % R], rr[(d + 1) % H], xx[(d + 1) % H], zz + 1, true);
+                    [[maybe_unused]] const bool live = !GEN || zz < z1;
+                    if constexpr (FUSE) transform(ring[(d + 2) % R], rr[(d + 1) % H], xx[(d + 1) % H], zz + 1, true, live);
                     step(zz, (d & 1) * BUF, ring[d], ring[(d + 1) % R], ring[(d + 2) % R], halo_val(hreg[d % H], hr[FUSE ? d % H : 0]),
                          halo_val(ereg[d % H], er[FUSE ? d % H : 0]), pidr[d % H], vr[STREAM ? d % VD : 0], hvr[SYM ? d % H : 0],
                          evr[SYM ? d % H : 0], [&]() {
@@ -404,7 +519,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                                  rr[(d + 1) % H] = plane_of(epi.fuse_r, zz + 1 + H);
                                  xx[(d + 1) % H] = plane_of_x(epi.fuse_x, zz + 1 + H);
                              }
-                         }, [&]() { vals(zz + VD, d % VD); });   // (values: their slot is free once the row sums are formed)
+                         }, [&]() { vals(zz + VD, d % VD); }, live);   // (values: their slot is free once the row sums are formed)
                 }
                 z += R;
             } while (z < zfull);

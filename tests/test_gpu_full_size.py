@@ -101,6 +101,84 @@ def test_spmv_symmetry_and_linearity(op512):
         b.free()
 
 
+def test_const_512_slabs_bit_exact_against_the_oracle(op512):
+    """The HEADLINE matrix (constant coefficients, storage format 9) multiplied by a RANDOM vector -- every product and every
+    add rounds (A*1 and A*i above are integer valued and exercise no rounding) -- on four 4-plane slabs (first, two
+    interior, last) bit for bit against the oracle's scalar left-to-right loop over the oracle's own rows
+    (csr_ref.poisson3d_c, rows=): VERDICT r5 thin spot (a).  Reference: pykrylov/linop/linop.py:356-360 (`op * x`)."""
+    from pykrylov_amd import _lib
+    lib = _lib.init()
+    rng = np.random.default_rng(2025)
+    xh = rng.standard_normal(N)
+    xh[::9] = 0.0
+    xh[4::13] *= 1e150
+    x = _lib.DeviceArray.from_numpy(xh)
+    y = _lib.DeviceArray(N)
+    op512.spmv_device(x.ptr, y.ptr)
+    fmt = ctypes.c_int32()
+    _lib.check(lib.mk_csr_format_info(op512.handle, ctypes.byref(fmt), None, None, None, None))
+    assert fmt.value == 9
+    yh = y.to_numpy()
+    assert np.isfinite(yh).all()
+    plane = M * M
+    for z0 in (0, 171, 340, M - 4):
+        a, b = z0 * plane, (z0 + 4) * plane
+        S = csr_ref.poisson3d_c(M, rows=(a, b))
+        indptr, indices, data = op512.csr_rows(a, b)
+        assert np.array_equal(indptr, S.indptr) and np.array_equal(indices, S.indices) and np.array_equal(data, S.data), z0
+        want = S.matvec(xh)
+        assert np.array_equal(yh[a:b], want), (z0, float(np.max(np.abs(yh[a:b] - want))))
+    for buf in (x, y):
+        buf.free()
+
+
+FUSE_CHILD = r'''
+import sys, ctypes, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+from pykrylov_amd import _lib, gallery
+from pykrylov_amd.generic import DeviceRun
+lib = _lib.init()
+M = 512
+N = M ** 3
+op = gallery.poisson3d(M) if sys.argv[1] == "const" else gallery.poisson3d_varcoef(M, seed=7)
+ones = _lib.DeviceArray.from_numpy(np.ones(N))
+rhs = _lib.DeviceArray(N)
+op.spmv_device(ones.ptr, rhs.ptr)
+run = DeviceRun(op, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=12, check_curvature=1)
+res = run.run()
+f = ctypes.c_int32()
+_lib.check(lib.mk_solver_fused(run.handle, ctypes.byref(f)))
+fmt = ctypes.c_int32()
+_lib.check(lib.mk_csr_format_info(op.handle, ctypes.byref(fmt), None, None, None, None))
+hist = np.array(run.history())
+x = run.x()
+print(repr((int(f.value), int(fmt.value), int(res.nMatvec), hist.tobytes().hex(), hashlib.sha256(x.tobytes()).hexdigest(),
+            x[::65537].tobytes().hex())))
+'''
+
+
+@pytest.mark.parametrize("which,fmt", [("const", 9), ("varcoef", 11)])
+def test_fused_passes_equal_three_kernel_passes_at_512(which, fmt):
+    """12 CG passes at 512^3 with MK_CG_FUSE=1 and =0 in child processes: the residual history, a SHA-256 of the whole iterate
+    and a strided sample of it are equal bit for bit -- at the size where the chunk count, the XCD deal and the non-temporal
+    instantiations differ from the small cases of tests/test_gpu_pencil.py (VERDICT r5 thin spot (b)).  Reference:
+    pykrylov/cg/cg.py:130-151."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for fuse in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", FUSE_CHILD % root, which], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, MK_CG_FUSE=fuse))
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        out[fuse] = eval(p.stdout.strip().splitlines()[-1])
+    assert out["1"][0] == 1 and out["0"][0] == 0                         # (the switch reached the solver)
+    assert out["1"][1] == out["0"][1] == fmt and out["1"][2] == out["0"][2] == 12
+    assert out["1"][3:] == out["0"][3:]
+
+
 def test_cg_recurrence_residual_is_true_residual(op512):
     """60 CG passes at 512^3 with everything resident in HBM: the residual norm the loop carries
     (cg.py:131,146,154) equals ||A x_k - b|| recomputed from the iterate, and the history decreases in the

@@ -1,5 +1,6 @@
 """Storage format 9 (csrc/mk_spmv_fmt9.h): z-marching bricks for 7-point-class matrices -- every column offset in
-{0, +-1, +-L, +-P}, L % 128 == 0, P % 4L == 0, <= 256 distinct values.  The product must be BIT-identical to the oracle's
+{0, +-1, +-L, +-P}, <= 256 distinct values; here on geometries of whole aligned bricks (L % 128 == 0, P % 4L == 0; any other
+grid side: tests/test_gpu_march_general.py).  The product must be BIT-identical to the oracle's
 scalar left-to-right CSR loop, the fused dots to the oracle run in the brick march's summation order (oracle/gpu_order.py
 `pencil`), for every loop that launches a product kernel; matrices outside the class must degrade to the windowed formats."""
 import ctypes
@@ -103,8 +104,8 @@ def test_generic_band_matrix_bit_exact(n, L, P, drop):
 def test_matrices_outside_the_class_degrade():
     from pykrylov_amd import CsrOperator, _lib
     rng = np.random.default_rng(1)
-    for A in (csr_ref.poisson3d(100, 8, 8),                   # L = 100: not a multiple of 128
-              csr_ref.poisson2d(256),                         # no plane stride
+    for A in (csr_ref.poisson3d(132, 9, 8),                   # less than half of the bricks' lanes would have rows
+              csr_ref.poisson2d(100),                         # one far stride, shorter than a brick line
               csr_ref.poisson3d_varcoef(128, 8, 8),           # > 256 distinct values (format 10's class: asked for 9 only)
               csr_ref.stencil27(128, 8, 4)):                  # 27 offsets
         for want in (9, 10):
