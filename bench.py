@@ -113,6 +113,8 @@ def _compact_roofline(r):
            "traffic": tb, "traffic_bytes": tb}
     if tb and r.get("bytes_per_launch"):
         out["traffic_ratio"] = sig(tb / float(r["bytes_per_launch"]), 4)
+    if tb:                                                   # a counter figure replayed from a committed profile, not collected now
+        out["traffic_source"] = str(r.get("traffic_source", "profiles/spmv_traffic.json"))[:72]
     if r.get("fused_pass"):
         out["fused_pass"] = True
     return out
@@ -135,9 +137,10 @@ def _compact_cg(b):
            "roofline": _compact_roofline(b["roofline"]),
            "iteration_frac": sig(b["iteration_roofline"]["frac_of_aggregate_hbm"], 4),
            "residual": {k: sig(res.get(k)) for k in ("true", "recurrence", "rel_gap", "ok")},
-           "parity_vs_n1": ({"ok": par.get("ok"), "rel_hist_err": sig(par.get("rel_hist_err"), 3), "passes": par.get("passes")}
-                            if par else None),
-           "placement_draws": {"count": (b.get("placement_draws") or {}).get("count", 1)}}
+           "parity_vs_n1": ({"ok": par.get("ok"), "rel_hist_err": sig(par.get("rel_hist_err"), 3), "passes": par.get("passes"),
+                             "fixture": "device-generated"} if par else None),
+           "placement_draws": {"count": (b.get("placement_draws") or {}).get("count", 1),
+                               "probe_s": sig((b.get("placement_draws") or {}).get("probe_seconds", 0.0), 3)}}
     if b.get("cpu_baseline"):
         out["cpu_baseline"] = _compact_cpu(b["cpu_baseline"])
     if b.get("cpu_baseline_all_cores"):
@@ -172,10 +175,23 @@ def compact_line(detail):
             line.setdefault("cg_other_workloads", {})[wname] = [sig(b["value"], 5), sig(b["roofline"]["frac"], 3),
                                                                 sig(b["iteration_roofline"]["frac_of_aggregate_hbm"], 3)]
     if detail.get("solver_loops"):
+        # [iterations/s, physical HBM fraction of the pass] and, for loops whose products are bound by the per-entry cost of
+        # divergent gathers (not by HBM), a third number: gather floor of the pass's products / their measured time
         loops = {"cg": [head["value"], head["iteration_frac"]]}
         for k, v in detail["solver_loops"].items():
-            loops[k.split("@")[0]] = [sig(v["value"], 5), sig(v["iteration_roofline"]["frac"], 3)]
+            e = [sig(v["value"], 5), sig(v["iteration_roofline"]["frac"], 3)]
+            if v.get("gather_bound"):
+                e.append(sig(v["gather_bound"]["frac_of_gather_floor"], 3))
+            loops[k.split("@")[0]] = e
         line["solver_loops"] = loops
+        line["solver_loops_cols"] = "it/s, hbm frac[, products' gather-floor frac: bound=gather]"
+    if detail.get("csr_plain"):
+        c = detail["csr_plain"]
+        line["csr_plain"] = {"fmt": c["format"], "us": sig(c["avg_product_us"], 5), "bytes": c["bytes_per_launch"],
+                             "frac": sig(c["frac"], 4), "traffic_ratio": sig(c.get("traffic_ratio"), 4),
+                             "what": "512^3 product forced to plain CSR, priced at 12nnz+4(n+1)+8ncols+8nrows"}
+    if detail.get("build_sha"):
+        line["build_sha"] = detail["build_sha"]
     if detail.get("transport"):
         line["transport"] = detail["transport"]
     if detail.get("exchange"):
@@ -452,7 +468,9 @@ def format_info(lib, op):
                                       ctypes.byref(nd), ctypes.byref(mbytes)))
     grid, tmap = ctypes.c_int32(), ctypes.c_int32()
     _lib.check(lib.mk_csr_launch_info(op.handle, ctypes.byref(grid), ctypes.byref(tmap)))
-    return {"format": fmt.value, "format_name": FMT_NAMES.get(fmt.value, "format %d" % fmt.value), "tiles_windowed": tiles.value,
+    march = (ctypes.c_int64 * 12)()
+    _lib.check(lib.mk_csr_march_info(op.handle, march, 12))
+    return {"march_general": bool(march[9]), "format": fmt.value, "format_name": FMT_NAMES.get(fmt.value, "format %d" % fmt.value), "tiles_windowed": tiles.value,
             "lds_window_chunks": chunks.value if fmt.value != 3 else 0,
             "column_phases": chunks.value if fmt.value == 3 else 0, "dictionary_size": nd.value,
             "matrix_bytes_per_product": mbytes.value, "grid": grid.value, "tile_order": tmap.value}
@@ -464,6 +482,9 @@ def colblocks(lib, op):
     _lib.check(lib.mk_csr_colblocks(op.handle, ctypes.byref(k)))
     return k.value
 
+
+GATHER_CLK = 2.9               # clocks per gathered entry and CU of the scattered products (measured)
+CLOCK_GHZ = 2.4                # MI355X engine clock
 
 LOOP_BYTES = {
     # bytes per pass BEYOND the products (each product priced at matrix data of its storage format + input once + output
@@ -542,6 +563,18 @@ def other_configs(lib, passes=400, warm=20, only=None):
             resid_min = min(resid_min, rn)
         return done_all, total_ms * 1e-3, resid_min, seg
 
+    def gather_bound(prods, entries):
+        """Products that gather x entry by entry (formats 0 / 3 on scattered columns) are bound by the per-entry cost of
+        divergent gathers -- 2.9 clocks per gathered entry and CU (profiles/r04_*phase_stamps*) -- before
+        HBM: floor = entries x 2.9 clk / 256 CUs at 2.4 GHz per product."""
+        floor_us = [e * GATHER_CLK / 256.0 / CLOCK_GHZ * 1e-3 for e in entries]
+        meas = [p[1] for p in prods]
+        if not all(meas):
+            return None
+        return {"bound": "gather", "clocks_per_entry_and_cu": GATHER_CLK, "clock_GHz": CLOCK_GHZ,
+                "floor_us_per_product": floor_us, "measured_us_per_product": meas,
+                "frac_of_gather_floor": sum(floor_us) / sum(meas)}
+
     def entry(name, key, done, dt, m, n, nnz, fmt_a, prods, extra):
         """prods: list of (label, avg_us, physical bytes, csr bytes) of the pass's product kernels."""
         b_prod = sum(p[2] for p in prods)
@@ -587,6 +620,7 @@ def other_configs(lib, passes=400, warm=20, only=None):
             entry(label, key, done, dt, n, n, op.nnz, fmt,
                   [("first (A p / A y)", us[0], b_fmt, b_csr), ("second (A z)", us[1], b_fmt, b_csr)],
                   {"column_blocks": colblocks(lib, op),
+                   "gather_bound": gather_bound([("", us[0]), ("", us[1])], [op.nnz, op.nnz]) if fmt["format"] in (0, 3) else None,
                    "spmv": spmv_entry(us[0], b_fmt, b_csr),
                    "data": "finite: re-set-up every %d passes, first 2 of each segment untimed; smallest residual norm seen "
                            "%.3e" % (seg, rmin)})
@@ -666,11 +700,50 @@ def other_configs(lib, passes=400, warm=20, only=None):
             entry("%s-rand4m-x-1m@1" % key, key, done, dt, m, n, op.nnz, fa,
                   [("A v (+ u update, <u,u>)", us[0], ba[0], ba[1]), ("A.T u (+ v update, <v,v>)", us[1], bt[0], bt[1])],
                   {"format_transpose": ft,
+                   "gather_bound": gather_bound([("", us[0]), ("", us[1])], [op.nnz, op.nnz])
+                   if fa["format"] in (0, 3) and ft["format"] in (0, 3) else None,
                    "data": "finite: re-set-up every %d passes, first 2 of each segment untimed; smallest residual norm seen "
                            "%.3e" % (seg, rmin)})
         rhs.free()
         At.free() if hasattr(At, "free") else None
         op.free()
+    return out
+
+
+def csr_plain_512(lib, m=512, launches=50):
+    """north_star's literal kernel -- coalesced reads of indptr / indices / data, x gathered -- on the headline matrix: the
+    512^3 constant-coefficient product forced to plain CSR (storage format 0), CG's product kernel (SpMV + fused <p, Ap>)
+    timed back to back and priced at SURVEY.md 8(d)'s B_spmv = 12 nnz + 4 (n + 1) + 8 ncols + 8 nrows, which here IS what
+    moves.  What a caller whose matrix is in no compressible class gets."""
+    from pykrylov_amd import _lib, gallery
+    from pykrylov_amd.generic import DeviceRun
+    n = m ** 3
+    op = gallery.poisson3d(m)
+    _lib.check(lib.mk_csr_set_format(op.handle, 0))
+    ones = _lib.DeviceArray.from_numpy(np.ones(n))
+    rhs = _lib.DeviceArray(n)
+    op.spmv_device(ones.ptr, rhs.ptr)
+    run = DeviceRun(op, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=1 << 60, check_curvature=1, placement_draws=1)
+    run.setup()
+    run.iterate(3)
+    us = run.time_product(0, launches)
+    fmt = format_info(lib, op)
+    b = spmv_bytes(n, n, op.nnz)
+    out = {"workload": "poisson3d-%d" % m, "format": fmt["format"], "kernel": "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,0> (SpMV + fused <p,Ap>)",
+           "avg_product_us": us, "launches_timed": launches, "bytes_per_launch": int(b), "achieved_GBs": b / us / 1e3,
+           "frac": b / us / 1e3 / HBM_PEAK_GBS, "traffic_ratio": None,
+           "note": "priced at SURVEY.md 8(d)'s CSR bytes: for this storage format they are the physical bytes"}
+    tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        ent = tj.get("csr_plain@1")
+        if ent and tj.get("kernel_source_sha") == kernel_source_sha() and ent.get("bytes"):
+            out["traffic_bytes"] = ent["bytes"]
+            out["traffic_ratio"] = ent["bytes"] / float(b)
+    run.close()
+    for buf in (ones, rhs):
+        buf.free()
+    op.free()
     return out
 
 
@@ -700,6 +773,9 @@ def main():
                          "of the N > 1 path on a single-GPU box, not a measurement")
     ap.add_argument("--all-configs", action="store_true", help="(kept for compatibility: all BASELINE configs are in the "
                                                                "default line now)")
+    ap.add_argument("--force-format", type=int, default=None,
+                    help="profiling aid: force this storage format on the workload's matrix (0 = plain CSR: north_star's "
+                         "literal kernel)")
     ap.add_argument("--only-other-configs", action="store_true",
                     help="profiling aid: run only configs[2] and configs[3] (BiCGSTAB random, MINRES shifted) and print them")
     args = ap.parse_args()
@@ -782,6 +858,8 @@ def main():
             mm = int(workload.split("-")[1])
             _lib.check(lib.mk_arena_reserve(arena_vecs * (8 * mm ** 3 + (4 << 20))))
         op, n_global, meta = build_workload(workload, world, exchange)
+        if args.force_format is not None:
+            _lib.check(lib.mk_csr_set_format(op.handle, args.force_format))
         n_local = getattr(op, "local_size", None) or op.shape[1]
         ones = _lib.DeviceArray.from_numpy(np.ones(op.shape[1]))
         rhs = _lib.DeviceArray(n_local)
@@ -813,10 +891,16 @@ def main():
                         check_curvature=1, spmv_event_stride=stride)
         run.setup()
         done_w = run.iterate(warmup)
+        # fused passes defer the last pass's x / p update (csrc/mk_cg.hip): asking for the iterate applies it.  Once in the
+        # warm-up (allocates the scratch vectors it is formed into while the loop runs), once INSIDE the timed region, so that
+        # the K timed passes include all of their vector work
+        px0 = ctypes.c_void_p()
+        _lib.check(lib.mk_solver_x(run.handle, ctypes.byref(px0)))
         device_sync()
         barrier()
         t0 = time.perf_counter()
         done = run.iterate(steps)
+        _lib.check(lib.mk_solver_x(run.handle, ctypes.byref(px0)))
         device_sync()
         elapsed = time.perf_counter() - t0
         if td is not None:
@@ -934,14 +1018,15 @@ def main():
                 traffic, tnote = ent, "measured with rocprofv3 PMC at this kernel build (%s)" % tj.get("measured", "?")
             elif ent:
                 tnote = "profiles/spmv_traffic.json was measured at another kernel build or format: not quoted"
-        kname = ("mk_spmv_kernel<CgFusedEpiT,MkNoGate,false,%d> (x,p update + SpMV + <p,Ap>)" % {9: 11, 10: 12, 11: 13}.get(fmt["format"], 11)
-                 if fused else
-                 "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,%d> (SpMV + fused <p,Ap>)" % {9: 11, 10: 12, 11: 13}.get(fmt["format"], fmt["format"]))
+        tfmt = {9: 11, 10: 12, 11: 13}.get(fmt["format"], fmt["format"]) + (3 if fmt.get("march_general") else 0)
+        kname = ("mk_spmv_kernel<CgFusedEpiT,MkNoGate,false,%d> (x,p update + SpMV + <p,Ap>)" % tfmt if fused else
+                 "mk_spmv_kernel<CgSpmvEpiT,MkNoGate,false,%d> (SpMV + fused <p,Ap>)" % tfmt)
         roof = {"bound": "hbm", "kernel": kname, "fused_pass": fused,
                 "kernel_format": fmt["format_name"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_bytes": (traffic or {}).get("bytes"), "traffic_note": tnote,
+                "traffic_source": "profiles/spmv_traffic.json (%s)" % json.load(open(tpath)).get("measured", "?") if traffic else None,
                 "bytes_per_launch": b_fmt, "avg_launch_us": spmv_us, "launches_timed": info["launches"],
                 "method": method,
                 "inloop_event_pair_us": inloop_us,
@@ -1006,12 +1091,14 @@ def main():
         # brick march on the slab with fused passes -- interior planes, boundary planes, r update, scalar kernel, pack):
         # only the 8-way split of the 512^3 problem has a budget
         budget = None
-        if world_size == 8 and name.startswith("poisson3d-512"):
-            budget = ({"kernels_per_pass_us": 401, "fused_interior_us": 258, "fused_boundary_us": 64, "update_r_us": 69,
-                       "scalar_us": 5, "pack_us": 4} if name.endswith("-varcoef") else
-                      {"kernels_per_pass_us": 239, "fused_interior_us": 124, "fused_boundary_us": 41, "update_r_us": 67,
-                       "scalar_us": 4, "pack_us": 3})
-            budget["source"] = "profiles/r05_slab_budget.txt (rank 3's slab alone on one GPU, rocprofv3 kernel trace)"
+        bpath = os.path.join(ROOT, "profiles", "r06_slab_budget.json")
+        if world_size == 8 and name.startswith("poisson3d-512") and os.path.exists(bpath):
+            bj = json.load(open(bpath))
+            budget = dict(bj.get("varcoef" if name.endswith("-varcoef") else "const") or {})
+            if budget:
+                budget["source"] = "profiles/r06_slab_budget.json (%s)" % bj.get("source", "?")
+            else:
+                budget = None
         detail["per_rank_budget"] = budget
         ex = {first_mode: {"value": head["value"], "ms_per_step": head["ms_per_step"], "steps": args.steps,
                            "comm": head["comm"]}}
@@ -1025,6 +1112,9 @@ def main():
         detail["exchange"] = ex
         head["roofline"]["note_multi"] = ("N > 1: the SpMV kernel is not timed alone (each launch is preceded by an "
                                           "exchange); see iteration_roofline and exchange.*.comm")
+    detail["build_sha"] = _lib.build_info(lib)
+    if not multi and name == "poisson3d-512" and not args.no_extra:
+        detail["csr_plain"] = csr_plain_512(lib)
     second = None
     if not multi and name == "poisson3d-512" and not args.no_extra:
         # the same grid with a VARIABLE coefficient field: no constant-coefficient compression applies, the product streams

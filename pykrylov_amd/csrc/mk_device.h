@@ -321,12 +321,22 @@ static inline MkCsrView mk_view(const mk_csr *A) {
     return v;
 }
 
-// The brick march of a slab under an overlapped halo exchange: the planes that need no received entry -- all but the first
-// MK_PEN_R of a slab with a lower neighbour and the last 1 .. MK_PEN_R of one with an upper neighbour, so that the interior is a
-// whole number of pipelined rounds -- run while the messages travel, the others afterwards.  False: too few planes to split.
-static inline bool mk_pen_split(const MkPlan *P, int *za, int *zb) {
+// The brick march of a slab under an overlapped halo exchange: the planes that need no received entry run while the
+// messages travel, the others afterwards.  `thin` (round 6; loops with general-geometry kernels: plain products and CG):
+// only the slab's FIRST and LAST plane wait for the messages -- one plane per (brick, chunk) item, run unpipelined: one memory
+// round trip -- and the interior's leftover planes go through the masked last round of the GEN kernel.  Otherwise (round 5) the
+// boundary launch takes the first MK_PEN_R planes of a slab with a lower neighbour and the last 1 .. MK_PEN_R of one with an
+// upper neighbour, so that the interior is a whole number of pipelined rounds.  False: too few planes to split.
+static inline bool mk_pen_split(const MkPlan *P, int *za, int *zb, bool thin = false) {
     constexpr int R = 6;                                    // (= MK_PEN_R, mk_spmv_fmt9.h; asserted there)
     const int nz = P->pen_nz;
+    if (thin) {
+        const int lo = (P->pen_xlo >= 0) ? 1 : 0, hi = (P->pen_xhi >= 0) ? nz - 1 : nz;
+        if (hi - lo < R || (lo == 0 && hi == nz)) return false;
+        *za = lo;
+        *zb = hi;
+        return true;
+    }
     const int lo = (P->pen_xlo >= 0) ? R : 0;
     int hi_s = nz;
     if (P->pen_xhi >= 0) hi_s = lo + ((nz - lo - 1) / R) * R;
@@ -346,25 +356,25 @@ static inline int mk_pen_items(const MkCsrView &v) {
 }
 
 // view of the interior (part 1) or boundary (part 2) tiles of a partitioned matrix; poff2 = grid of part 1
-static inline MkCsrView mk_view_part(const mk_csr *A, int part, int poff2) {
+static inline MkCsrView mk_view_part(const mk_csr *A, int part, int poff2, bool thin = false) {
     MkCsrView v = mk_view(A);
     if (mk_fmt_march(v.fmt)) {                              // plane ranges instead of tile lists
         int za = 0, zb = v.pen_nz;
-        mk_pen_split(mk_csr_plan(A), &za, &zb);             // (the caller checked that the slab splits)
+        mk_pen_split(mk_csr_plan(A), &za, &zb, thin);       // (the caller checked that the slab splits)
         if (part == 2) {
             v.pen_za = 0;
             v.pen_zb = za;
             v.pen_ya = zb;
             v.pen_yb = v.pen_nz;
-            // the slab's last 1 .. R planes: fewer than a whole round go through the GEN kernel's masked round (where the
-            // epilogue has one) instead of one unpipelined plane after the other
-            if (!v.pen_gen && (v.pen_nz - zb) % 6 != 0 && mk_pen_tail_gen()) {
-                v.pen_gen = 1;
-                v.pen_dump = mk_pen_dump();
-            }
         } else {
             v.pen_za = za;
             v.pen_zb = zb;
+            // thin split: the interior is no whole number of rounds any more -- its leftover planes take the GEN kernel's
+            // masked round (the epilogue has one: `thin` says so) instead of one unpipelined plane after the other
+            if (thin && !v.pen_gen && (zb - za) % 6 != 0) {
+                v.pen_gen = 1;
+                v.pen_dump = mk_pen_dump();
+            }
         }
         v.poff = (part == 2) ? poff2 : 0;
         v.part = part;

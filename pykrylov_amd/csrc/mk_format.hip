@@ -1280,7 +1280,12 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     // marched line by line: planes of M rows, cut into lines of 128 rows that have no +-L entries (the kernels are index based)
     int64_t L = h_stats[0], PP = h_stats[1];
     if (h_stats[2] > 7 || L <= 1 || PP < L) return drop();
-    if (L == PP) L = 128;
+    if (L == PP) {
+        // (measured, tools/r06_march_sizes.py: CG on 2000^2 16.8 k passes per second on either format, on 4000^2 3.86 k on the
+        //  windowed format 4 against 4.22 k marched: chosen automatically from four times the 3-D threshold on)
+        if (!forced && A->nrows < 4 * pencil_min_rows()) return drop();
+        L = 128;
+    }
     if (L >= PP || A->nrows % PP != 0 || A->nrows / PP < 2 || pen_bx_of(L) * pen_by_of(L, PP) > (1 << 24)) return drop();
     // partly empty bricks: at least half of the lanes must have rows (L = 132, 9 lines: 39 %; L = 37: 29 %)
     if (!pen_aligned(L, PP) && 2 * PP < 512 * pen_bx_of(L) * pen_by_of(L, PP)) return drop();
@@ -1493,9 +1498,25 @@ void mk_csr_plan_reset(const mk_csr *A) {
 // before it (512^3: MINRES 369 -> 292, SYMMLQ 357 -> 270, BiCGSTAB 254 -> 229; tools/r05_solvers_on_bricks.py).  So the
 // solver being created says what it is, and an automatically chosen format follows the last one -- unless other solvers
 // are alive on the matrix (their partial-sum counts were sized for the format in use) or the caller fixed the format.
+// a solver was created on (+1) / removed from (-1) A: counted on A's owner and on every matrix a composite borrows
+void mk_csr_count_users(const mk_csr *A, int delta) {
+    if (!A) return;
+    const mk_csr *o = A->base ? A->base : A;
+    o->solver_users += delta;
+    if (o->comp_kind == 4 && o->grid) {
+        for (const mk_csr *B : o->grid->blk) mk_csr_count_users(B, delta);
+    } else if (o->comp_kind) {
+        mk_csr_count_users(o->comp_a, delta);
+        if (o->comp_kind <= 3) mk_csr_count_users(o->comp_b, delta);
+    }
+}
+
 void mk_csr_march_pref(const mk_csr *A, int pref) {
     const mk_csr *o = A->base ? A->base : A;
-    if (!o->comp_kind && !o->host_fn && !(o->solver_users > 0 && o->plan.built)) {
+    // (live solvers -- on the matrix itself or on a composite that borrows it, mk_csr_count_users -- sized their partial-sum
+    //  counts for the format in use: the matrix keeps it while there is one)
+    const bool pinned = o->plan.built && o->solver_users > 0;
+    if (!o->comp_kind && !o->host_fn && !pinned) {
         // format 11 (the symmetric march) is CG's and plain products': any other loop gets the same matrix as format 10
         const bool no_sym = (pref == 0);
         if (no_sym != o->no_sym) {
@@ -1507,7 +1528,7 @@ void mk_csr_march_pref(const mk_csr *A, int pref) {
         }
     }
     if (o->want_fmt >= 9 || o->comp_kind || o->host_fn) return;
-    if (o->solver_users > 0 && o->plan.built) return;
+    if (pinned) return;
     o->march_pref = pref;
     if (!o->plan.built) return;
     const bool march = mk_fmt_march(o->plan.fmt);

@@ -226,6 +226,7 @@ int mk_csr_alloc(int64_t nrows, int64_t ncols, int64_t nnz, mk_csr **out);
 void mk_release_operand(const mk_csr *B);   // a borrower lets go: the matrix is destroyed now if its owner already asked for it
 void mk_csr_plan_reset(const mk_csr *A);    // drop the windowed format (it is rebuilt on the next product)
 void mk_csr_march_pref(const mk_csr *A, int pref);   // a solver is being created on A: 1 = CG, 0 = any other loop
+void mk_csr_count_users(const mk_csr *A, int delta); // a solver was created on / removed from A (and whatever A is composed of)
 
 // grid sizes -------------------------------------------------------------------------
 // Persistent-style grids: at most `cap` workgroups which stride over the work.  The caps are tuning

@@ -251,7 +251,8 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
     const MkPlan *plan = A->ex.pending ? mk_csr_plan(A) : nullptr;
     const bool march = plan && mk_fmt_march(plan->fmt);
     int za, zb;
-    if (A->ex.pending && march && (!mk_march_kernel_for<Epi>(plan) || !mk_pen_split(plan, &za, &zb))) {
+    const bool thin = MkSymMarch<Epi>::value && mk_pen_tail_gen();   // (mk_pen_split: only the first and the last plane wait)
+    if (A->ex.pending && march && (!mk_march_kernel_for<Epi>(plan) || !mk_pen_split(plan, &za, &zb, thin))) {
         // a slab of too few planes to split -- or a loop without a kernel for this march format, whose product runs as the
         // CSR gather kernel over ALL rows (a plane range means nothing to it): the messages first, then one launch
         int rc = mk_exchange_wait(A, s->stream);
@@ -261,10 +262,10 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
         // halo exchange in flight: rows that need no received entry first, the others once the messages are in
         // (the two launches write disjoint ranges of the partial-sum slots)
         int g1, g2;
-        const MkCsrView v1 = mk_view_part(A, 1, 0);
+        const MkCsrView v1 = mk_view_part(A, 1, 0, thin);
         if (march) {                                         // plane ranges of the brick march (mk_pen_split)
             g1 = mk_pen_items(v1);
-            g2 = mk_pen_items(mk_view_part(A, 2, 0));
+            g2 = mk_pen_items(mk_view_part(A, 2, 0, thin));
             // (the kernels stride their items by the grid: a plane of >= 1024 bricks must not leave the interior launch a
             //  grid of 0 -- at most half of the partial-sum slots for the boundary planes)
             if (g2 > MK_MAXP / 2) g2 = MK_MAXP / 2;
@@ -275,7 +276,7 @@ static inline int mk_launch_spmv(mk_solver *s, const double *x, const Epi &epi, 
         mk_spmv_launch_view(v1, g1, s->stream, x, epi, gate, s->next_halt(), s->d_part);
         int rc = mk_exchange_wait(A, s->stream);
         if (rc != MK_OK) return rc;
-        mk_spmv_launch_view(mk_view_part(A, 2, g1), g2, s->stream, x, epi, gate, s->next_halt(), s->d_part);
+        mk_spmv_launch_view(mk_view_part(A, 2, g1, thin), g2, s->stream, x, epi, gate, s->next_halt(), s->d_part);
     } else {
         mk_spmv_launch_blocks(A, mk_grid_spmv_for(A), s->stream, x, epi, gate, [&] { return s->next_halt(); }, s->d_part);
     }

@@ -72,7 +72,7 @@ mk_solver::~mk_solver() {
     if (mk_ctx().ready) hipStreamSynchronize(mk_ctx().stream);
     if (precon_op) mk_release_operand(precon_op);
     if (At) mk_release_operand(At);
-    if (A && counted_user) (A->base ? A->base : A)->solver_users -= 1;
+    if (A && counted_user) mk_csr_count_users(A, -1);
     if (A) mk_release_operand(A);
     hipFree(d_ones);
     hipFree(d_ptmp);
@@ -106,7 +106,22 @@ int mk_solver::alloc_vec(double **out, int64_t len) {
     const size_t bytes = sizeof(double) * (size_t)(len > 0 ? len : 1) + 16;
     MkContext &c = mk_ctx();
     const size_t step = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);   // 2 MiB granules
-    if (c.arena && c.arena_off + step <= c.arena_size) {     // carved from the arena reserved before the matrix
+    // placement experiment (round 6, tools/r06_placement_offsets.py): MK_ARENA_SKEW="s0,s1,..." shifts the k-th vector carved
+    // from the arena by s_k bytes (multiples of 256) -- the relative phase of the loop's write streams, chosen instead of drawn
+    size_t skew = 0;
+    if (c.arena) {
+        static const char *env = getenv("MK_ARENA_SKEW");
+        if (env) {
+            int k = 0;
+            for (const char *q = env; *q; ++k) {
+                const long v = strtol(q, const_cast<char **>(&q), 10);
+                if (k == c.arena_live) skew = (size_t)(v > 0 ? v : 0) & ~(size_t)255;
+                if (*q == ',') ++q;
+            }
+        }
+    }
+    if (c.arena && c.arena_off + skew + step <= c.arena_size) {     // carved from the arena reserved before the matrix
+        c.arena_off += skew;
         p = reinterpret_cast<double *>(c.arena + c.arena_off);
         c.arena_off += step;
         c.arena_live += 1;
@@ -288,7 +303,7 @@ extern "C" int mk_solver_create(const mk_csr *A, const mk_params *params, mk_sol
         delete s;
         return rc;
     }
-    (A->base ? A->base : A)->solver_users += 1;
+    mk_csr_count_users(A, 1);
     s->counted_user = true;
     *out = s;
     return MK_OK;

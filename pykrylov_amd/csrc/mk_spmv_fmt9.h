@@ -473,7 +473,9 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             else vlo = *reinterpret_cast<const mk_d2 *>(src);
         }
         // planes of the pipelined rounds; the rest one by one below (GEN: one more round, its planes past z1 discarded)
-        const int zfull = GEN ? z0 + ((z1 - z0 + R - 1) / R) * R : z0 + ((z1 - z0) / R) * R;
+        // (GEN, a chunk of one or two planes -- a slab's boundary launch: one plane after the other, one memory round trip
+        //  each, instead of a whole round's pipeline fill for them)
+        const int zfull = GEN ? (z1 - z0 > 2 ? z0 + ((z1 - z0 + R - 1) / R) * R : z0) : z0 + ((z1 - z0) / R) * R;
         if (zfull > z0) {
             [[maybe_unused]] mk_d2 rm1{0.0, 0.0}, r00{0.0, 0.0}, x00{0.0, 0.0};
             if constexpr (FUSE) {                             // r (and x) of the two planes the ring starts with

@@ -483,6 +483,8 @@ def test_bench_compact_line_on_a_real_detail_file():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "config", "iteration_frac", "residual",
               "parity_vs_n1", "solver_loops", "cg_other_workloads"):
         assert line[k] == printed[k], k
+    assert line["parity_vs_n1"]["fixture"] == "device-generated"       # (a device history: regression evidence, not oracle parity)
+    assert line["roofline"].get("traffic_source", "").startswith("profiles/spmv_traffic.json") or not line["roofline"]["traffic"]
     assert line["config"]["workload"] == "CG poisson3d-512" and line["roofline"]["frac"] == printed["roofline"]["frac"]
     assert line["second_workload"]["workload"] == "CG poisson3d-512-varcoef"
     assert line["cpu_baseline"]["sample_rows"] == 134217728 and line["cpu_baseline"]["extrapolated"] is False
