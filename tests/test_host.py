@@ -1,6 +1,7 @@
 """CPU-only checks of the host logic: CSR builders, MatrixMarket reader, operator protocol,
 and that libmikrylov.so loads and exports every symbol its header declares."""
 import os
+import sys
 import re
 
 import numpy as np
@@ -488,3 +489,39 @@ def test_bench_compact_line_on_a_real_detail_file():
     assert line["config"]["workload"] == "CG poisson3d-512" and line["roofline"]["frac"] == printed["roofline"]["frac"]
     assert line["second_workload"]["workload"] == "CG poisson3d-512-varcoef"
     assert line["cpu_baseline"]["sample_rows"] == 134217728 and line["cpu_baseline"]["extrapolated"] is False
+
+
+def test_stale_binary_is_refused(tmp_path):
+    """libmikrylov.so is git-ignored and travels prebuilt: `mk_build_info()` carries the digest of the sources it was compiled
+    from (pykrylov_amd/build.py `source_sha`, compiled into csrc/mk_buildinfo.hip) and `_lib.load()` refuses a binary whose
+    digest is not the tree's.  Here: a copy of the tree with ONE header changed by a comment must refuse the (unchanged)
+    binary, load it with MIKRYLOV_ALLOW_STALE=1, and the real tree must load and report its own digest."""
+    import shutil
+    import subprocess
+    src = os.path.join(ROOT, "pykrylov_amd")
+    if not os.path.exists(os.path.join(src, "libmikrylov.so")):
+        pytest.skip("library not built")
+    from pykrylov_amd import _lib, build
+    assert _lib.build_info() == build.source_sha() and len(build.source_sha()) == 16
+    dst = tmp_path / "tree"
+    (dst / "pykrylov_amd" / "csrc").mkdir(parents=True)
+    (dst / "include").mkdir()
+    for f in os.listdir(src):
+        if f.endswith(".py"):
+            shutil.copy(os.path.join(src, f), dst / "pykrylov_amd" / f)
+    for f in os.listdir(os.path.join(src, "csrc")):
+        shutil.copy(os.path.join(src, "csrc", f), dst / "pykrylov_amd" / "csrc" / f)
+    shutil.copytree(os.path.join(src, "lls"), dst / "pykrylov_amd" / "lls")
+    shutil.copy(os.path.join(ROOT, "include", "mikrylov.h"), dst / "include" / "mikrylov.h")
+    os.symlink(os.path.join(src, "libmikrylov.so"), dst / "pykrylov_amd" / "libmikrylov.so")
+    code = "import sys; sys.path.insert(0, %r); from pykrylov_amd import _lib; _lib.load(); print('LOADED', _lib.build_info())" % str(dst)
+    env = {k: v for k, v in os.environ.items() if k not in ("MIKRYLOV_ALLOW_STALE", "MIKRYLOV_LIB")}
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert ok.returncode == 0 and "LOADED " + build.source_sha() in ok.stdout, ok.stderr[-2000:]     # the copy is current
+    with open(dst / "pykrylov_amd" / "csrc" / "mk_spmv_fmt9.h", "a") as fh:
+        fh.write("// an edit the binary does not know about\n")
+    bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert bad.returncode != 0 and "built from other sources" in bad.stderr, bad.stdout + bad.stderr[-2000:]
+    forced = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, MIKRYLOV_ALLOW_STALE="1"),
+                            cwd=str(tmp_path))
+    assert forced.returncode == 0 and "LOADED" in forced.stdout, forced.stderr[-2000:]
