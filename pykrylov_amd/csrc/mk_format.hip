@@ -1289,6 +1289,11 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     if (L >= PP || A->nrows % PP != 0 || A->nrows / PP < 2 || pen_bx_of(L) * pen_by_of(L, PP) > (1 << 24)) return drop();
     // partly empty bricks: at least half of the lanes must have rows (L = 132, 9 lines: 39 %; L = 37: 29 %)
     if (!pen_aligned(L, PP) && 2 * PP < 512 * pen_bx_of(L) * pen_by_of(L, PP)) return drop();
+    // ... and chosen AUTOMATICALLY only where the march wins (tools/r06_march_sizes.py, profiles/r06_march_sizes.txt: CG passes
+    // per second, windowed -> march): bricks at least 90 % full from the usual 2^21 rows on (250^3 2 901 -> 3 931, 500^3 430 -> 584),
+    // bricks 78 % full (L = 200, 300, 400) only from 2^24 rows on (200^3, 8 M rows: 7 828 -> 6 506; 300^3 1 982 -> 2 220; 400^3
+    // 884 -> 939)
+    if (!forced && !pen_aligned(L, PP) && 10 * PP < 9 * 512 * pen_bx_of(L) * pen_by_of(L, PP) && A->nrows < ((int64_t)1 << 24)) return drop();
     const size_t slack = (size_t)(4 * L + 256);              // rows past the end that a lane without rows may index (GEN)
     if ((A->loc_lo != 0 && A->loc_lo != PP) || (A->loc_hi != 0 && A->loc_hi != PP)) return drop();   // (whole planes only)
     const PenSlab sl{A->nrows, A->loc_lo, A->loc_hi};
