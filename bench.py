@@ -89,8 +89,7 @@ SHORT_FMT = {0: "fmt0 csr, x gathered", 1: "fmt1 windowed tiles: u16 slots + f64
              10: "fmt10 z-marching bricks: mask byte/row + streamed f64 values (56 B/row)",
              11: "fmt11 z-marching bricks, symmetric: mask byte/row + diagonal and upper f64 values (32 B/row)"}
 BASELINE_CONFIG = {
-    "poisson3d-512": "configs[4]: CG on 3-D 7-point Poisson 512^3 (diagonal 6, off-diagonals -1); fits one GPU, so the "
-                     "1/2/4/8 series is strong scaling over this fixed problem",
+    "poisson3d-512": "configs[4]: CG, 3-D 7-point Poisson 512^3 (diagonal 6, off-diagonals -1); fits one GPU: 1/2/4/8 = strong scaling",
     "poisson3d-512-varcoef": "configs[4]'s grid with a variable coefficient field (no constant-coefficient compression "
                              "applies: the product streams 8 B per nonzero)",
     "poisson2d-1000": "configs[1]", "bicgstab": "configs[2]", "minres": "configs[3]"}
@@ -124,7 +123,7 @@ def _compact_cpu(c):
     if not c:
         return None
     out = {k: sig(c.get(k)) for k in ("value", "unit", "cores", "kind", "extrapolated", "sample_rows")}
-    out["sample"] = str(c.get("sample_short") or c.get("sample", ""))[:96]
+    out["sample"] = str(c.get("sample_short") or c.get("sample", ""))[:64]
     return out
 
 
@@ -170,7 +169,10 @@ def compact_line(detail):
         if wname == name:
             continue
         if wname.startswith("poisson3d-512"):                 # the second workload: a block of the headline's shape
-            line["second_workload"] = _compact_cg(b)
+            sec = _compact_cg(b)                              # (less what the byte budget cannot afford twice)
+            sec.pop("cpu_baseline_all_cores", None)
+            sec["roofline"].pop("traffic_bytes", None)
+            line["second_workload"] = sec
         else:                                                 # [iterations/s, SpMV physical frac, iteration physical frac]
             line.setdefault("cg_other_workloads", {})[wname] = [sig(b["value"], 5), sig(b["roofline"]["frac"], 3),
                                                                 sig(b["iteration_roofline"]["frac_of_aggregate_hbm"], 3)]
@@ -184,12 +186,12 @@ def compact_line(detail):
                 e.append(sig(v["gather_bound"]["frac_of_gather_floor"], 3))
             loops[k.split("@")[0]] = e
         line["solver_loops"] = loops
-        line["solver_loops_cols"] = "it/s, hbm frac[, products' gather-floor frac: bound=gather]"
+        line["solver_loops_cols"] = "it/s, hbm frac[, gather-floor frac of the products: bound=gather]"
     if detail.get("csr_plain"):
         c = detail["csr_plain"]
         line["csr_plain"] = {"fmt": c["format"], "us": sig(c["avg_product_us"], 5), "bytes": c["bytes_per_launch"],
                              "frac": sig(c["frac"], 4), "traffic_ratio": sig(c.get("traffic_ratio"), 4),
-                             "what": "512^3 product forced to plain CSR, priced at 12nnz+4(n+1)+8ncols+8nrows"}
+                             "what": "512^3 product forced to fmt 0, priced at SURVEY 8(d) B_spmv"}
     if detail.get("build_sha"):
         line["build_sha"] = detail["build_sha"]
     if detail.get("transport"):
@@ -394,7 +396,7 @@ def cpu_baseline_full_size(names, passes=3, threads=(1,)):
             "value": passes / dt, "unit": "iterations/s", "cores": th, "kind": "port", "extrapolated": False,
             "sample_rows": int(n), "sample_nnz": int(A.nnz), "seconds_per_pass": dt / passes,
             "matrix_generation_seconds": t_gen,
-            "sample_short": "%d CG passes of the workload itself after 1 untimed; CSR product on %d thread(s)" % (passes, th),
+            "sample_short": "%d CG passes of the workload itself, 1 untimed; %d thread(s)" % (passes, th),
             "sample": "%d CG passes of %s itself (%d rows, %d nnz) after 1 untimed pass; NumPy updates and np.dot on one "
                       "thread, C CSR product on %d OpenMP thread(s)" % (passes, name, n, A.nnz, th),
             "host_cpus": os.cpu_count(), "residual_after": float(res["residHistory"][-1])}}
