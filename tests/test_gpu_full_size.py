@@ -179,6 +179,58 @@ def test_fused_passes_equal_three_kernel_passes_at_512(which, fmt):
     assert out["1"][3:] == out["0"][3:]
 
 
+def test_500_cubed_general_geometry_bit_exact_slabs_and_true_residual():
+    """The general-geometry march (round 6) at ITS full size: 3-D Poisson 500^3 (1.25e8 rows; the grid side of the
+    reference's largest CG test, pykrylov/cg/tests/test_diagdom.py:53) is formatted automatically as storage format 9 on
+    partly empty bricks; a random-x product on four 4-plane slabs (first, two interior, last) equals the oracle's scalar
+    loop over the oracle's own rows bit for bit, and 60 fused CG passes end with recurrence residual = true residual."""
+    from pykrylov_amd import _lib, gallery
+    from pykrylov_amd.generic import DeviceRun
+    lib = _lib.init()
+    m = 500
+    n = m ** 3
+    op = gallery.poisson3d(m)
+    rng = np.random.default_rng(500)
+    xh = rng.standard_normal(n)
+    xh[::9] = 0.0
+    xh[4::13] *= 1e150
+    x = _lib.DeviceArray.from_numpy(xh)
+    y = _lib.DeviceArray(n)
+    op.spmv_device(x.ptr, y.ptr)
+    info = (ctypes.c_int64 * 12)()
+    _lib.check(lib.mk_csr_march_info(op.handle, info, 12))
+    assert (info[0], info[1], info[2], info[3], info[9]) == (9, m, m * m, m, 2), list(info)
+    yh = y.to_numpy()
+    plane = m * m
+    for z0 in (0, 167, 331, m - 4):
+        a, b = z0 * plane, (z0 + 4) * plane
+        S = csr_ref.poisson3d_c(m, rows=(a, b))
+        want = S.matvec(xh)
+        assert np.array_equal(yh[a:b], want), (z0, float(np.max(np.abs(yh[a:b] - want))))
+    ones = _lib.DeviceArray.from_numpy(np.ones(n))
+    rhs = _lib.DeviceArray(n)
+    op.spmv_device(ones.ptr, rhs.ptr)
+    run = DeviceRun(op, _lib.MK_CG, rhs, None, abstol=0.0, reltol=0.0, matvec_max=60, check_curvature=1)
+    res = run.run()
+    hist = run.history()
+    f = ctypes.c_int32()
+    _lib.check(lib.mk_solver_fused(run.handle, ctypes.byref(f)))
+    assert res.nMatvec == 60 and len(hist) == 61 and res.definite and f.value == 1
+    assert hist[0] == np.sqrt(6.0 * (m - 2) ** 2 + 48.0 * (m - 2) + 72.0)      # ||A 1||^2 is an integer: exact in any order
+    px = ctypes.c_void_p()
+    _lib.check(lib.mk_solver_x(run.handle, ctypes.byref(px)))
+    ax = _lib.DeviceArray(n)
+    _lib.check(lib.mk_spmv(op.handle, px.value, ax.ptr))
+    _lib.check(lib.mk_axpy(n, -1.0, rhs.ptr, ax.ptr))
+    true_res = ctypes.c_double()
+    _lib.check(lib.mk_nrm2(n, ax.ptr, ctypes.byref(true_res)))
+    assert abs(true_res.value - hist[-1]) <= 1e-10 * hist[0] and hist[-1] < 0.2 * hist[0]
+    run.close()
+    for buf in (x, y, ones, rhs, ax):
+        buf.free()
+    op.free()
+
+
 def test_cg_recurrence_residual_is_true_residual(op512):
     """60 CG passes at 512^3 with everything resident in HBM: the residual norm the loop carries
     (cg.py:131,146,154) equals ||A x_k - b|| recomputed from the iterate, and the history decreases in the

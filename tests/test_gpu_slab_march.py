@@ -71,11 +71,16 @@ def local_oracle(op):
     return csr_ref.RefCsr(ip, ix, dat, (int(op.shape[0]), int(op.shape[1])))
 
 
+# (nx, ny): whole aligned bricks, and a general geometry (round 6: lines of 100 rows, planes of 9 lines -- partly empty bricks,
+# the general-geometry kernels on the slab, its boundary planes run one by one)
+GRIDS = [(128, 8), (100, 9)]
+
+
+@pytest.mark.parametrize("nx,ny", GRIDS)
 @pytest.mark.parametrize("varcoef,fmt", [(False, 9), (True, 10), (True, 11)])
 @pytest.mark.parametrize("nr,rank,planes", [(4, 0, 7), (4, 2, 7), (4, 3, 7), (3, 1, 20), (2, 0, 2)])
-def test_slab_product_bit_exact(varcoef, fmt, nr, rank, planes):
+def test_slab_product_bit_exact(varcoef, fmt, nr, rank, planes, nx, ny):
     from pykrylov_amd import _lib
-    nx, ny = 128, 8
     lib, world, op = build_slab(nx, ny, planes * nr, nr, rank, varcoef, fmt)
     try:
         n_local, ncols = int(op.shape[0]), int(op.shape[1])
@@ -97,14 +102,14 @@ def test_slab_product_bit_exact(varcoef, fmt, nr, rank, planes):
         lib.mk_comm_destroy()
 
 
+@pytest.mark.parametrize("nx,ny", GRIDS)
 @pytest.mark.parametrize("varcoef,fmt,fmt_ref", [(False, 9, 4), (True, 10, 5), (True, 11, 5)])
-@pytest.mark.parametrize("nr,rank,planes", [(4, 1, 20), (4, 0, 14), (4, 3, 13), (4, 2, 7)])
-def test_cg_on_the_slab_two_launch_product(varcoef, fmt, fmt_ref, nr, rank, planes):
+@pytest.mark.parametrize("nr,rank,planes", [(4, 1, 20), (4, 0, 14), (4, 3, 13), (4, 2, 7), (4, 1, 23)])
+def test_cg_on_the_slab_two_launch_product(varcoef, fmt, fmt_ref, nr, rank, planes, nx, ny):
     """planes = 20 / 14 / 13: interior + boundary launches (both neighbours, upper only, lower only); 7: too few planes to
     split, the messages are waited for first."""
     from pykrylov_amd import _lib
     from pykrylov_amd.generic import DeviceRun
-    nx, ny = 128, 8
     res = {}
     for f in (fmt, fmt_ref):
         lib, world, op = build_slab(nx, ny, planes * nr, nr, rank, varcoef, f)
@@ -131,17 +136,18 @@ def test_cg_on_the_slab_two_launch_product(varcoef, fmt, fmt_ref, nr, rank, plan
     assert np.linalg.norm(x - x0) <= 1e-12 * np.linalg.norm(x0)
 
 
+@pytest.mark.parametrize("nx,ny", GRIDS)
 @pytest.mark.parametrize("varcoef,fmt", [(False, 9), (True, 10), (True, 11)])
-@pytest.mark.parametrize("nr,rank,planes", [(4, 1, 20), (4, 0, 14), (4, 3, 13), (4, 2, 7), (2, 1, 3)])
-def test_fused_cg_passes_on_the_slab_change_no_bit(varcoef, fmt, nr, rank, planes, monkeypatch):
+@pytest.mark.parametrize("nr,rank,planes", [(4, 1, 20), (4, 0, 14), (4, 3, 13), (4, 2, 7), (2, 1, 3), (4, 1, 23)])
+def test_fused_cg_passes_on_the_slab_change_no_bit(varcoef, fmt, nr, rank, planes, nx, ny, monkeypatch):
     """CG on a slab of the march runs FUSED passes too (csrc/mk_cg.hip): the neighbours' planes of p are formed on the spot
     from their p_old (kept behind the own rows of the p buffers) and their r, so it is r's boundary planes that travel.
     Same operations on the same values, same launches and workgroup shares: history, iterate, residual vector and search
     direction equal the three-kernel pass on the same slab bit for bit -- through interior + boundary launches (20 / 14 /
-    13 planes) and through the whole-slab launch (7 / 3 planes)."""
+    13 planes; 23: an interior of 21 planes, three whole rounds and a masked one) and through the whole-slab launch (7 / 3 planes).
+    Round 6: only the slab's first and last plane wait for the messages (run one plane at a time), on both geometries."""
     from pykrylov_amd import _lib
     from pykrylov_amd.generic import DeviceRun
-    nx, ny = 128, 8
     res = {}
     for fuse in ("1", "0"):
         monkeypatch.setenv("MK_CG_FUSE", fuse)
