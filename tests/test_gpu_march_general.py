@@ -23,10 +23,25 @@ def march_info(op):
     return dict(zip(keys, list(info)))
 
 
-# (nx, ny, nz): line lengths below / above 128 and 256, odd lengths, planes of 5 .. 13 lines, plane counts that leave 1 .. 5
-# planes over after whole rounds of six
+def expected_geometry(L, P, two_d=False):
+    """(gen, bricks per line, brick rows) the builder must choose (csrc/mk_format.hip pencil_geometry / pen_linear): whole aligned
+    bricks -> 0; LINEAR bricks (3) where lines fill the 4 x 128 bricks to less than 90 % (and always for 5-point matrices), unless
+    MK_PEN_LIN=0; the general line bricks (2) otherwise."""
+    import os
+    bx, by = -(-L // 128), -(-(-(-P // L)) // 4)
+    aligned = L % 128 == 0 and P % (4 * L) == 0
+    lin_env = os.environ.get("MK_PEN_LIN")
+    lin = P >= 512 and lin_env != "0" and (two_d or (2 <= L <= 512 and (lin_env == "1" or (not aligned and 10 * P < 9 * 512 * bx * by))))
+    if lin:
+        return 3, 1, -(-P // 512)
+    return (0 if aligned else 2), bx, by
+
+
+# (nx, ny, nz): line lengths below / above 128 and 256, odd lengths, planes of 5 .. 15 lines, plane counts that leave 1 .. 5
+# planes over after whole rounds of six.  The first ten fill the 4 x 128 bricks to 50 .. 85 % (linear bricks), the last six to
+# more than 90 % (general line bricks: partly empty last brick of a line, partly empty last group of lines, odd L, odd P)
 GRIDS = [(100, 8, 8), (100, 9, 7), (200, 8, 5), (250, 7, 13), (101, 8, 5), (101, 9, 11), (129, 12, 4), (500, 5, 3), (384, 6, 9),
-         (90, 13, 8)]
+         (90, 13, 8), (250, 8, 5), (500, 8, 3), (128, 15, 5), (250, 15, 4), (255, 8, 5), (255, 15, 3)]
 
 
 @pytest.mark.parametrize("dims", GRIDS)
@@ -39,8 +54,9 @@ def test_general_grid_product_bit_exact(dims, fmt):
     y = op * x
     info = march_info(op)
     assert info["fmt"] == fmt, info
-    assert (info["L"], info["P"], info["planes"], info["gen"]) == (dims[0], dims[0] * dims[1], dims[2], 2), info
-    assert info["bx"] == -(-dims[0] // 128) and info["by"] == -(-dims[1] // 4)
+    gen, bx, by = expected_geometry(dims[0], dims[0] * dims[1])
+    assert gen in (2, 3) and (info["L"], info["P"], info["planes"], info["gen"]) == (dims[0], dims[0] * dims[1], dims[2], gen), info
+    assert (info["bx"], info["by"]) == (bx, by), info
     assert np.array_equal(y, A.matvec(x))
     x[::7] = 0.0
     x[5::11] *= 1e300
@@ -61,11 +77,13 @@ def test_five_point_matrix_is_marched_line_by_line(m, fmt):
     x = np.random.default_rng(1).standard_normal(m * m)
     assert np.array_equal(op * x, A.matvec(x))
     info = march_info(op)
-    assert (info["fmt"], info["L"], info["P"], info["planes"], info["gen"]) == (fmt, 128, m, m, 2), info
+    gen = expected_geometry(128, m, two_d=True)[0]
+    assert (info["fmt"], info["L"], info["P"], info["planes"], info["gen"]) == (fmt, 128, m, m, gen), info
 
 
 @pytest.mark.parametrize("n,L,P,drop", [(700 * 9, 100, 700, 0.0), (750 * 8, 100, 750, 0.3), (909 * 7, 101, 909, 0.5),
-                                        (1155 * 6, 165, 1155, 0.2)])
+                                        (1155 * 6, 165, 1155, 0.2), (2000 * 6, 250, 2000, 0.3), (3825 * 4, 255, 3825, 0.2),
+                                        (1530 * 5, 510, 1530, 0.1)])
 def test_general_band_matrix_bit_exact(n, L, P, drop):
     """No grid geometry: +-1 entries across line ends (a lane past the end of its line holds the NEXT line's first rows: the
     natural index), any subset of the offsets, P not a multiple of L, odd strides, zeros / negative zero / denormals among the
@@ -91,22 +109,31 @@ def test_general_band_matrix_bit_exact(n, L, P, drop):
         assert np.array_equal(got[fin], ref[fin])
 
 
-@pytest.mark.parametrize("n,L,P,drop", [(700 * 9, 100, 700, 0.3), (909 * 7, 101, 909, 0.0)])
+@pytest.mark.parametrize("n,L,P,drop", [(700 * 9, 100, 700, 0.3), (909 * 7, 101, 909, 0.0), (2000 * 6, 250, 2000, 0.4), (3825 * 4, 255, 3825, 0.2)])
 def test_general_symmetric_band_format11(n, L, P, drop):
     rng = np.random.default_rng(n + 1)
     A = sym_banded(n, L, P, rng, drop=drop)
     op = op9(A, fmt=11)
     x = rng.standard_normal(n)
     assert np.array_equal(op * x, A.matvec(x)) and fmt_of(op) == 11
-    assert march_info(op)["gen"] == 2
+    assert march_info(op)["gen"] == expected_geometry(L, P)[0]
+    j = int(rng.integers(P, n - P))
+    x[j] = np.inf
+    with np.errstate(invalid="ignore"):
+        ref = A.matvec(x)
+    got = op * x
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = np.isfinite(ref)
+    assert np.array_equal(got[fin], ref[fin])
 
 
 def test_sparse_bricks_degrade():
-    """Less than half of a brick's lanes with rows (L = 132 in planes of 9 lines: 39 %; L = 37: 29 %) -> the
-    windowed formats keep the matrix, as does a matrix with offsets outside the class."""
+    """Line bricks less than half full and no linear bricks to take over (planes of 500 and of 185 rows: shorter than one linear
+    brick; 49 % and 18 % of the line bricks' lanes) -> the windowed formats keep the matrix, as does a matrix with offsets
+    outside the class."""
     from pykrylov_amd import CsrOperator, _lib
     rng = np.random.default_rng(1)
-    for A in (csr_ref.poisson3d(132, 9, 8), csr_ref.poisson3d(37, 40, 6), csr_ref.stencil27(100, 8, 4)):
+    for A in (csr_ref.poisson3d(100, 5, 20), csr_ref.poisson3d(37, 5, 40), csr_ref.stencil27(100, 8, 4)):
         for want in (9, 10):
             op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
             _lib.check(_lib.init().mk_csr_set_format(op.handle, want))
@@ -115,7 +142,8 @@ def test_sparse_bricks_degrade():
             assert fmt_of(op) not in (9, 10, 11) and march_info(op)["L"] == 0
 
 
-@pytest.mark.parametrize("dims,fmt", [((100, 9, 7), 9), ((250, 7, 13), 9), ((101, 9, 11), 11), ((200, 8, 20), 11)])
+@pytest.mark.parametrize("dims,fmt", [((100, 9, 7), 9), ((250, 7, 13), 9), ((101, 9, 11), 11), ((200, 8, 20), 11), ((250, 8, 13), 9),
+                                      ((255, 15, 8), 11), ((500, 8, 7), 11)])
 def test_cg_on_a_general_grid_bit_exact_fused_and_unfused(dims, fmt, monkeypatch):
     """CG with <p, Ap> fused into the march of a general geometry: history, iterate and matvec count equal the oracle run in
     the march's summation order bit for bit, and the fused passes (x / p update inside the next product kernel) equal the
@@ -140,7 +168,7 @@ def test_cg_on_a_general_grid_bit_exact_fused_and_unfused(dims, fmt, monkeypatch
         assert fmt_of(op) == fmt
         out[fuse] = res
         geo = gpu_order.launch_geometry(op)
-    assert geo[1][0] == "pencil" and geo[1][6] == 2
+    assert geo[1][0] == "pencil" and geo[1][6] == expected_geometry(dims[0], dims[0] * dims[1])[0]
     for a, b in zip(out["1"], out["0"]):
         assert a[0] == b[0] and a[3] == b[3] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     ref = krylov_ref.cg(A, rhs, matvec_max=150, red=krylov_ref.Reductions(gpu_order.GpuDots(n, gpu_order.SPMV_SITES["cg"], geometry=geo)))
@@ -218,3 +246,15 @@ print(repr(out))
         res[gen] = eval(p.stdout.strip().splitlines()[-1])
     assert [r[0] for r in res["0"]] == [0, 0] and [r[0] for r in res["1"]] == [2, 2]
     assert [r[1:] for r in res["0"]] == [r[1:] for r in res["1"]]
+
+
+def test_the_same_on_line_bricks_only():
+    """MK_PEN_LIN=0 keeps the 4 x 128 line bricks on every geometry (their partly empty bricks at 50 .. 85 % fill): the product,
+    band-matrix and CG cases of this file again in a child process (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "general_grid_product or band or cg_on_a_general_grid or five_point"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MK_PEN_LIN="0"), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
