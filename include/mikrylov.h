@@ -266,14 +266,13 @@ MK_API int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t *st
  *   [4] lines per plane = ceil(P / L)          [5] bricks per line = ceil(L / 128)                       [6] brick rows = ceil(lines / 4)
  *   [7] planes per chunk                       [8] chunks                    [9] 2 = general geometry (partly empty bricks, pairs
  *   at any 8-byte boundary: a lane whose row does not exist -- in-line position >= L or in-plane index >= P -- discards its
- *   row sum), 3 = linear bricks (see [12]), 0 = whole aligned bricks          [10] per: bricks per XCD of the XCD-contiguous deal, 0 = round robin
- *   [11] row patterns (format 9)                [12] halo length of LINEAR bricks ([9] == 3: a brick is 512 consecutive rows of the
- *   plane, brick j starts at row 512 j, lane t owns the rows 512 j + 2 t and + 1; [5] = 1, [6] = bricks per plane), else 0.
+ *   row sum), 0 = whole aligned bricks          [10] per: bricks per XCD of the XCD-contiguous deal, 0 = round robin
+ *   [11] row patterns (format 9).
  * Item i of a launch whose grid is a multiple of 8 with per > 0: brick (i % 8) per + (i / 8) % per of chunk (i / 8) / per
  * (8 per item slots per chunk; a slot whose brick number is >= bricks per plane is empty); otherwise brick i % bpp of
  * chunk i / bpp.  Brick j starts at row (j / bx) 4L + (j % bx) 128 of a plane.  A 5-point matrix (one far stride M) is
  * reported as L = 128, P = M: it is marched line by line.  At most `cap` entries are written (MK_MARCH_INFO_LEN exist). */
-#define MK_MARCH_INFO_LEN 13
+#define MK_MARCH_INFO_LEN 12
 MK_API int mk_csr_march_info(const mk_csr *A, int64_t *info, int32_t cap);
 
 /* y = A x   (K1; `self.op * p`, pykrylov/cg/cg.py:115 and every other solver).

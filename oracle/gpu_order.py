@@ -130,23 +130,18 @@ def pencil_partials(w, y, grid, L, P, nz, zc, chunks, gen=0, per=-1):
     otherwise brick i % bpp of chunk i // bpp (per < 0: round 5's rule, per = bpp / 8 when that is whole).  Lane (wave v,
     lane l) owns the rows z P + c and z P + c + 1, c = brick start + v L + 2 l, and adds their terms plane by plane through
     the chunk, row c first; on a general geometry (`gen`) a row that does not exist -- in-line position >= L or in-plane
-    index >= P -- adds +0.0, which leaves the running sum unchanged bit for bit.  gen == 3: LINEAR bricks (csrc/mk_spmv_fmt9l.h) --
-    brick j is the rows 512 j .. 512 j + 511 of a plane, lane t owns 512 j + 2 t and + 1."""
-    pad = max(4 * L + 256, 1024)
+    index >= P -- adds +0.0, which leaves the running sum unchanged bit for bit."""
+    pad = 4 * L + 256
     prod = np.zeros((nz, P + pad))
     prod[:, :P] = (np.asarray(w, dtype=np.float64) * np.asarray(y, dtype=np.float64)).reshape(nz, P)
-    linear = gen == 3                                        # csrc/mk_spmv_fmt9l.h: a brick is 512 consecutive rows of the plane
-    bx = 1 if linear else (L + 127) // 128
-    bpp = (P + 511) // 512 if linear else bx * (((P + L - 1) // L + 3) // 4)
+    bx = (L + 127) // 128
+    bpp = bx * (((P + L - 1) // L + 3) // 4)
     if per < 0:
         per = bpp // 8 if bpp % 8 == 0 else 0
     xdeal = per > 0 and grid % 8 == 0
     items = (8 * per if xdeal else bpp) * chunks
     lane_c = (np.arange(4)[:, None] * L + 2 * np.arange(64)[None, :]).reshape(-1)       # lane t = 64 v + l
     lane_x = np.tile(2 * np.arange(64), 4)                                              # position in the brick's 128 columns
-    if linear:                                               # lane t owns the rows 512 j + 2 t and + 1 of brick j
-        lane_c = 2 * np.arange(256)
-        lane_x = np.zeros(256, dtype=np.int64)
     acc = np.zeros((grid, BLOCK))
     for first in range(0, items, grid):                      # round k of every workgroup (vectorised over workgroups)
         it = np.arange(first, min(first + grid, items))
@@ -159,11 +154,11 @@ def pencil_partials(w, y, grid, L, P, nz, zc, chunks, gen=0, per=-1):
             bi, ch = it % bpp, it // bpp
         if len(it) == 0:
             continue
-        b0 = bi * 512 if linear else (bi // bx) * 4 * L + (bi % bx) * 128
+        b0 = (bi // bx) * 4 * L + (bi % bx) * 128
         cols = b0[:, None] + lane_c[None, :]                 # (workgroups, 256): in-plane index of row c
         cx = (bi % bx)[:, None] * 128 + lane_x[None, :]
-        oka = ((cx < L) | linear) & (cols < P)
-        okb = ((cx + 1 < L) | linear) & (cols + 1 < P)
+        oka = (cx < L) & (cols < P)
+        okb = (cx + 1 < L) & (cols + 1 < P)
         cols = np.minimum(cols, P + pad - 2)
         for zi in range(zc):
             z = ch * zc + zi

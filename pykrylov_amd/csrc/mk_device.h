@@ -88,8 +88,7 @@ struct MkCsrView {
     // kernels only; 1 = an aligned geometry whose launch has leftover planes: the GEN kernel where the epilogue has one (its
     // masked last round replaces the unpipelined planes); pen_per > 0: bricks per XCD of the XCD-contiguous deal;
     // pen_xtop = the last index a 16-byte pair of the input vector may start at; pen_dump = where discarded rows are stored
-    int pen_gen, pen_per;                                   // (pen_gen 3: LINEAR bricks, mk_spmv_fmt9l.h; pen_lh = their halo length)
-    int pen_lh;
+    int pen_gen, pen_per;
     int64_t pen_xtop;
     double *pen_dump;
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
@@ -289,7 +288,6 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.pen_ya = v.pen_yb = 0;
         v.pen_gen = P->pen_gen;
         v.pen_per = P->pen_per;
-        v.pen_lh = P->pen_lh;
         v.pen_xtop = A->x_len() - 2;
         v.pen_dump = P->pen_gen ? mk_pen_dump() : nullptr;
     } else if (v.fmt == 3) {
@@ -671,7 +669,6 @@ __device__ __forceinline__ void mk_load_meta(const MkCsrView &A, int64_t p, int6
 #include "mk_spmv_fmt5.h"
 #include "mk_spmv_fmtw.h"
 #include "mk_spmv_fmt9.h"
-#include "mk_spmv_fmt9l.h"
 
 constexpr int MK_FMT_WIDE = 7;                       // template values of the wide kernels (6 = format 5, non-temporal):
 constexpr int MK_FMT_WIDE_DICT = 8;                  // 7 streams values (fmt 6, 7), 8 takes them from the dictionary (fmt 8),
@@ -683,9 +680,6 @@ constexpr int MK_FMT_PENCIL_SYM = 13;                // format 11: ... of a symm
 constexpr int MK_FMT_PENCIL_G = 14;                  // formats 9 / 10 / 11 on a general geometry (mk_spmv_fmt9.h, GEN): 14 / 15 / 16
 constexpr int MK_FMT_PENCIL_STREAM_G = 15;
 constexpr int MK_FMT_PENCIL_SYM_G = 16;
-constexpr int MK_FMT_PENCIL_L = 17;                  // formats 9 / 10 / 11 on linear bricks (mk_spmv_fmt9l.h): 17 / 18 / 19
-constexpr int MK_FMT_PENCIL_STREAM_L = 18;
-constexpr int MK_FMT_PENCIL_SYM_L = 19;
 
 template <int FMT, bool PROG, class Epi, int NACC>
 __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *__restrict__ x, Epi &epi,
@@ -700,9 +694,6 @@ __device__ __forceinline__ void mk_spmv_tiles(const MkCsrView &A, const double *
     else if constexpr (FMT == MK_FMT_PENCIL_G) mk_spmv_tiles_fmt9<PROG, false, false, true>(A, x, epi, xw, acc);
     else if constexpr (FMT == MK_FMT_PENCIL_STREAM_G) mk_spmv_tiles_fmt9<PROG, true, false, true>(A, x, epi, xw, acc);
     else if constexpr (FMT == MK_FMT_PENCIL_SYM_G) mk_spmv_tiles_fmt9<PROG, true, true, true>(A, x, epi, xw, acc);
-    else if constexpr (FMT == MK_FMT_PENCIL_L) mk_spmv_tiles_fmt9l<PROG, false, false>(A, x, epi, xw, acc);
-    else if constexpr (FMT == MK_FMT_PENCIL_STREAM_L) mk_spmv_tiles_fmt9l<PROG, true, false>(A, x, epi, xw, acc);
-    else if constexpr (FMT == MK_FMT_PENCIL_SYM_L) mk_spmv_tiles_fmt9l<PROG, true, true>(A, x, epi, xw, acc);
     else if constexpr (FMT == MK_FMT_WIDE || FMT == MK_FMT_WIDE_DICT || FMT == MK_FMT_WIDE_NT)
         mk_spmv_tiles_wide<FMT == MK_FMT_WIDE_DICT, FMT == MK_FMT_WIDE_NT, PROG>(A, x, epi, prod, xw, acc);
     else if constexpr (FMT >= 5) mk_spmv_tiles_fmt5<PROG, FMT == 6>(A, x, epi, prod, xw, acc);
@@ -717,7 +708,7 @@ struct MkNoGate {
 };
 
 template <class Epi, class Gate, bool PROG, int FMT>
-__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : ((FMT >= 11 && FMT <= 19) ? MK_PEN_OCC : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
+__global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 : ((FMT >= 11 && FMT <= 16) ? MK_PEN_OCC : ((FMT == 7 || FMT == 9) ? 4 : (FMT >= 4 ? 7 : 4)))) void mk_spmv_kernel(MkCsrView A, const double *__restrict__ x, Epi epi,
                                                            Gate gate, MkHalt halt, double *__restrict__ partials) {
     // fmt 0 / 1: products [MK_PROD_LDS doubles], then the windows.  fmt 2 has no product staging: its windows and
     // packed words share the space the gather path of uncovered tiles uses for products (never live together)
@@ -790,7 +781,7 @@ __global__ __launch_bounds__(MK_BLOCK, (FMT == 0 || FMT == 3 || FMT == 10) ? 8 :
 template <class Epi>
 static inline bool mk_march_kernel_for(const MkPlan *P) {
     if (!P || !mk_fmt_march(P->fmt) || MkNoMarch<Epi>::value) return false;
-    return MkSymMarch<Epi>::value || (P->fmt != 11 && P->pen_gen < 2);
+    return MkSymMarch<Epi>::value || (P->fmt != 11 && P->pen_gen != 2);
 }
 
 // Launch the instantiation that matches the operator: plain matrices never pay for the row program, matrices
@@ -803,7 +794,7 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
         const size_t w = sizeof(double) * (size_t)(128 * v.wchunks + 2) + sizeof(uint32_t) * (MK_SPMV_TILE + 16);
         lds = w > lds ? w : lds;
     }
-    if (mk_fmt_march(v.fmt) && (MkNoMarch<Epi>::value || ((v.fmt == 11 || v.pen_gen >= 2) && !MkSymMarch<Epi>::value))) {
+    if (mk_fmt_march(v.fmt) && (MkNoMarch<Epi>::value || ((v.fmt == 11 || v.pen_gen == 2) && !MkSymMarch<Epi>::value))) {
         MkCsrView w = v;                                     // (see MkNoMarch: a format forced by hand on a loop that has no such kernel)
         w.fmt = 0;
         hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, 0>), dim3(grid), dim3(MK_BLOCK), lds, st, w, x, epi, gate, halt, partials);
@@ -811,22 +802,6 @@ static inline void mk_spmv_launch_fmt(const MkCsrView &v, int grid, hipStream_t 
     }
     if (mk_fmt_march(v.fmt)) {
         if constexpr (MkSymMarch<Epi>::value) {              // general geometry / masked leftover round (mk_spmv_fmt9.h, GEN)
-            if (v.pen_gen == 3) {                            // ... on linear bricks (mk_spmv_fmt9l.h)
-                if (v.fmt == 9) {
-                    lds = sizeof(double) * (size_t)MK_PENL_LDS + 64 * (size_t)v.npat;
-                    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_L>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x, epi,
-                                       gate, halt, partials);
-                } else if (v.fmt == 10) {
-                    lds = sizeof(double) * (size_t)MK_PENL_LDS;
-                    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_STREAM_L>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
-                                       epi, gate, halt, partials);
-                } else {
-                    lds = sizeof(double) * (size_t)MK_PENL_LDS_SYM;
-                    hipLaunchKernelGGL((mk_spmv_kernel<Epi, Gate, PROG, MK_FMT_PENCIL_SYM_L>), dim3(grid), dim3(MK_BLOCK), lds, st, v, x,
-                                       epi, gate, halt, partials);
-                }
-                return;
-            }
             if (v.pen_gen) {
                 if (v.fmt == 9) {
                     lds = sizeof(double) * (size_t)MK_PEN_LDS + 64 * (size_t)v.npat;

@@ -1216,20 +1216,7 @@ static inline int64_t pen_by_of(int64_t L, int64_t PP) { return ((PP + L - 1) / 
 // whole aligned bricks (round 5's geometry; the vectors' 16-byte alignment is the C ABI's)?
 static inline bool pen_aligned(int64_t L, int64_t PP) { return L % 128 == 0 && PP % (4 * L) == 0; }
 
-// LINEAR bricks (mk_spmv_fmt9l.h): 512 consecutive rows of the plane, the +-L neighbours from a flat image with a halo of L
-// entries either side (one 16-byte load per side and lane up to L = 512).  Taken where lines fill the 4 x 128 bricks badly
-// (< 90 %), and for 5-point matrices (no +-L entries: a halo of 2).  MK_PEN_LIN = 0 / 1: never / wherever L <= 512 (A/B runs).
-static inline bool pen_linear(int64_t L, int64_t PP, bool two_d) {
-    static const char *env = getenv("MK_PEN_LIN");
-    if (env && atoi(env) == 0) return false;
-    if (PP < 512) return false;
-    if (two_d) return true;
-    if (L > 512 || L < 2) return false;
-    if (env && atoi(env) == 1) return true;
-    return !pen_aligned(L, PP) && 10 * PP < 9 * 512 * pen_bx_of(L) * pen_by_of(L, PP);
-}
-
-void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP, bool two_d) {
+void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP) {
     P.pen_L = L;
     P.pen_P = PP;
     P.pen_nz = (int)(A->nrows / PP);
@@ -1238,13 +1225,6 @@ void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP, bool two
     P.pen_bpp = (int)(pen_bx_of(L) * pen_by_of(L, PP));
     static const char *env_gen = getenv("MK_PEN_GEN");       // (1: the general-geometry kernels on aligned geometries too, A/B runs)
     P.pen_gen = (!pen_aligned(L, PP) || (env_gen && atoi(env_gen) == 1)) ? 2 : 0;
-    P.pen_lh = 0;
-    if (pen_linear(L, PP, two_d)) {
-        P.pen_gen = 3;
-        P.pen_lh = two_d ? 2 : (int)L;
-        P.pen_bx = 1;
-        P.pen_bpp = (int)((PP + 511) / 512);
-    }
     // XCD-contiguous deal: an eighth of the plane's bricks per XCD; on a general geometry ceil(bpp / 8) with empty item slots
     // behind the last brick, from 64 bricks per plane on (below that the empty slots would idle whole XCDs)
     P.pen_per = (P.pen_bpp % 8 == 0) ? P.pen_bpp / 8 : ((P.pen_gen && P.pen_bpp >= 64) ? (P.pen_bpp + 7) / 8 : 0);
@@ -1300,7 +1280,6 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     // marched line by line: planes of M rows, cut into lines of 128 rows that have no +-L entries (the kernels are index based)
     int64_t L = h_stats[0], PP = h_stats[1];
     if (h_stats[2] > 7 || L <= 1 || PP < L) return drop();
-    const bool two_d = (L == PP);
     if (L == PP) {
         // (measured, tools/r06_march_sizes.py: CG on 2000^2 16.8 k passes per second on either format, on 4000^2 3.86 k on the
         //  windowed format 4 against 4.22 k marched: chosen automatically from four times the 3-D threshold on)
@@ -1309,15 +1288,13 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     }
     if (L >= PP || A->nrows % PP != 0 || A->nrows / PP < 2 || pen_bx_of(L) * pen_by_of(L, PP) > (1 << 24)) return drop();
     // partly empty bricks: at least half of the lanes must have rows (L = 132, 9 lines: 39 %; L = 37: 29 %)
-    const bool lin = pen_linear(L, PP, two_d);               // (linear bricks are full but for a plane's last one)
-    if (!lin && !pen_aligned(L, PP) && 2 * PP < 512 * pen_bx_of(L) * pen_by_of(L, PP)) return drop();
+    if (!pen_aligned(L, PP) && 2 * PP < 512 * pen_bx_of(L) * pen_by_of(L, PP)) return drop();
     // ... and chosen AUTOMATICALLY only where the march wins (tools/r06_march_sizes.py, profiles/r06_march_sizes.txt: CG passes
     // per second, windowed -> march): bricks at least 90 % full from the usual 2^21 rows on (250^3 2 901 -> 3 931, 500^3 430 -> 584),
     // bricks 78 % full (L = 200, 300, 400) only from 2^24 rows on (200^3, 8 M rows: 7 828 -> 6 506; 300^3 1 982 -> 2 220; 400^3
     // 884 -> 939)
-    if (!forced && !lin && !pen_aligned(L, PP) && 10 * PP < 9 * 512 * pen_bx_of(L) * pen_by_of(L, PP) && A->nrows < ((int64_t)1 << 24))
-        return drop();
-    const size_t slack = (size_t)(4 * L + 256 > 1024 ? 4 * L + 256 : 1024);              // rows past the end that a lane without rows may index (GEN)
+    if (!forced && !pen_aligned(L, PP) && 10 * PP < 9 * 512 * pen_bx_of(L) * pen_by_of(L, PP) && A->nrows < ((int64_t)1 << 24)) return drop();
+    const size_t slack = (size_t)(4 * L + 256);              // rows past the end that a lane without rows may index (GEN)
     if ((A->loc_lo != 0 && A->loc_lo != PP) || (A->loc_hi != 0 && A->loc_hi != PP)) return drop();   // (whole planes only)
     const PenSlab sl{A->nrows, A->loc_lo, A->loc_hi};
     // the dictionary (values only: no per-nonzero words)
@@ -1384,7 +1361,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
         P.d_pid = d_pid;
         P.d_sval = d_sval;
         P.npat = 0;
-        pencil_geometry(A, P, L, PP, two_d);
+        pencil_geometry(A, P, L, PP);
         return true;
     };
     if (!read_state()) return drop();
@@ -1417,7 +1394,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     P.d_dict = d_dict;
     P.ndict = ndict;
     P.npat = nkeys;
-    pencil_geometry(A, P, L, PP, two_d);
+    pencil_geometry(A, P, L, PP);
     return true;
 }
 
@@ -1677,7 +1654,7 @@ extern "C" int mk_csr_march_info(const mk_csr *A, int64_t *info, int32_t cap) {
     const bool on = mk_fmt_march(P->fmt);
     const int64_t v[MK_MARCH_INFO_LEN] = {on ? P->fmt : 0, P->pen_L, P->pen_P, P->pen_nz, P->pen_ny, P->pen_bx,
                                           P->pen_bx ? P->pen_bpp / P->pen_bx : 0, P->pen_zc, P->pen_chunks, P->pen_gen, P->pen_per,
-                                          P->npat, P->pen_lh};
+                                          P->npat};
     for (int k = 0; k < cap && k < MK_MARCH_INFO_LEN; ++k) info[k] = on ? v[k] : 0;
     return MK_OK;
 }

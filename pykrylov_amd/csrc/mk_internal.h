@@ -147,8 +147,7 @@ struct MkPlan {
     int pen_nz = 0, pen_bx = 0, pen_bpp = 0, pen_zc = 0, pen_chunks = 0;
     // general geometry (round 6): 2 = partly empty bricks / unaligned pairs (GEN kernels only), 0 = whole aligned bricks;
     // bricks per XCD of the XCD-contiguous deal (0: round robin); lines per plane
-    int pen_gen = 0, pen_per = 0, pen_ny = 0;               // (pen_gen 3: linear bricks of 512 consecutive rows, mk_spmv_fmt9l.h)
-    int pen_lh = 0;                                         // ... and their halo length: L, or 2 for a 5-point matrix (no +-L entries)
+    int pen_gen = 0, pen_per = 0, pen_ny = 0;
     // ... of one rank's slab of planes (columns localised to [own | plane below | plane above], mk_csr_localize mode 0): where
     // the neighbours' planes start in the product's input vector (-1: the slab has no such neighbour)
     int64_t pen_xlo = -1, pen_xhi = -1;

@@ -24,22 +24,15 @@ def march_info(op):
 
 
 def expected_geometry(L, P, two_d=False):
-    """(gen, bricks per line, brick rows) the builder must choose (csrc/mk_format.hip pencil_geometry / pen_linear): whole aligned
-    bricks -> 0; LINEAR bricks (3) where lines fill the 4 x 128 bricks to less than 90 % (and always for 5-point matrices), unless
-    MK_PEN_LIN=0; the general line bricks (2) otherwise."""
-    import os
+    """(gen, bricks per line, brick rows) the builder must choose (csrc/mk_format.hip pencil_geometry): whole aligned bricks -> 0,
+    anything else the general geometry (2)."""
     bx, by = -(-L // 128), -(-(-(-P // L)) // 4)
-    aligned = L % 128 == 0 and P % (4 * L) == 0
-    lin_env = os.environ.get("MK_PEN_LIN")
-    lin = P >= 512 and lin_env != "0" and (two_d or (2 <= L <= 512 and (lin_env == "1" or (not aligned and 10 * P < 9 * 512 * bx * by))))
-    if lin:
-        return 3, 1, -(-P // 512)
-    return (0 if aligned else 2), bx, by
+    return (0 if L % 128 == 0 and P % (4 * L) == 0 else 2), bx, by
 
 
 # (nx, ny, nz): line lengths below / above 128 and 256, odd lengths, planes of 5 .. 15 lines, plane counts that leave 1 .. 5
-# planes over after whole rounds of six.  The first ten fill the 4 x 128 bricks to 50 .. 85 % (linear bricks), the last six to
-# more than 90 % (general line bricks: partly empty last brick of a line, partly empty last group of lines, odd L, odd P)
+# planes over after whole rounds of six; bricks 50 .. 98 % full (partly empty last brick of a line, partly empty last group of
+# lines, odd L, odd P)
 GRIDS = [(100, 8, 8), (100, 9, 7), (200, 8, 5), (250, 7, 13), (101, 8, 5), (101, 9, 11), (129, 12, 4), (500, 5, 3), (384, 6, 9),
          (90, 13, 8), (250, 8, 5), (500, 8, 3), (128, 15, 5), (250, 15, 4), (255, 8, 5), (255, 15, 3)]
 
@@ -55,7 +48,7 @@ def test_general_grid_product_bit_exact(dims, fmt):
     info = march_info(op)
     assert info["fmt"] == fmt, info
     gen, bx, by = expected_geometry(dims[0], dims[0] * dims[1])
-    assert gen in (2, 3) and (info["L"], info["P"], info["planes"], info["gen"]) == (dims[0], dims[0] * dims[1], dims[2], gen), info
+    assert gen == 2 and (info["L"], info["P"], info["planes"], info["gen"]) == (dims[0], dims[0] * dims[1], dims[2], gen), info
     assert (info["bx"], info["by"]) == (bx, by), info
     assert np.array_equal(y, A.matvec(x))
     x[::7] = 0.0
@@ -128,12 +121,11 @@ def test_general_symmetric_band_format11(n, L, P, drop):
 
 
 def test_sparse_bricks_degrade():
-    """Line bricks less than half full and no linear bricks to take over (planes of 500 and of 185 rows: shorter than one linear
-    brick; 49 % and 18 % of the line bricks' lanes) -> the windowed formats keep the matrix, as does a matrix with offsets
-    outside the class."""
+    """Less than half of a brick's lanes with rows (L = 132 in planes of 9 lines: 39 %; L = 37: 29 %) -> the windowed formats
+    keep the matrix, as does a matrix with offsets outside the class."""
     from pykrylov_amd import CsrOperator, _lib
     rng = np.random.default_rng(1)
-    for A in (csr_ref.poisson3d(100, 5, 20), csr_ref.poisson3d(37, 5, 40), csr_ref.stencil27(100, 8, 4)):
+    for A in (csr_ref.poisson3d(132, 9, 8), csr_ref.poisson3d(37, 40, 6), csr_ref.stencil27(100, 8, 4)):
         for want in (9, 10):
             op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
             _lib.check(_lib.init().mk_csr_set_format(op.handle, want))
@@ -247,14 +239,3 @@ print(repr(out))
     assert [r[0] for r in res["0"]] == [0, 0] and [r[0] for r in res["1"]] == [2, 2]
     assert [r[1:] for r in res["0"]] == [r[1:] for r in res["1"]]
 
-
-def test_the_same_on_line_bricks_only():
-    """MK_PEN_LIN=0 keeps the 4 x 128 line bricks on every geometry (their partly empty bricks at 50 .. 85 % fill): the product,
-    band-matrix and CG cases of this file again in a child process (the switch is read once per process)."""
-    import os
-    import subprocess
-    import sys
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "general_grid_product or band or cg_on_a_general_grid or five_point"], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, MK_PEN_LIN="0"), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]

@@ -104,7 +104,7 @@ def test_generic_band_matrix_bit_exact(n, L, P, drop):
 def test_matrices_outside_the_class_degrade():
     from pykrylov_amd import CsrOperator, _lib
     rng = np.random.default_rng(1)
-    for A in (csr_ref.poisson3d(100, 5, 20),                  # planes shorter than a linear brick, line bricks 49 % full
+    for A in (csr_ref.poisson3d(132, 9, 8),                   # less than half of the bricks' lanes would have rows
               csr_ref.poisson2d(100),                         # one far stride, shorter than a brick line
               csr_ref.poisson3d_varcoef(128, 8, 8),           # > 256 distinct values (format 10's class: asked for 9 only)
               csr_ref.stencil27(128, 8, 4)):                  # 27 offsets
