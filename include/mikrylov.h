@@ -276,8 +276,8 @@ MK_API int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t *st
 MK_API int mk_csr_march_info(const mk_csr *A, int64_t *info, int32_t cap);
 
 /* y = A x   (K1; `self.op * p`, pykrylov/cg/cg.py:115 and every other solver).
- * x_dev must be 16-byte aligned and readable up to an even number of entries (one entry of slack when ncols is odd;
- * every buffer from mk_malloc has it).
+ * x_dev must be 16-byte aligned and readable ONE ENTRY PAST ITS END (the kernels read pairs; a pair may start at the last
+ * entry when a plane stride of the brick-march formats is odd): every buffer from mk_malloc has 16 bytes of slack.
  * Per row the products are added left to right with one rounding per multiply and per
  * add, so the result is bit-identical to a scalar CSR loop. */
 MK_API int mk_spmv(const mk_csr *A, const double *x_dev, double *y_dev);

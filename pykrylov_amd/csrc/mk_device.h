@@ -87,7 +87,7 @@ struct MkCsrView {
     // general geometry (round 6): pen_gen 2 = the plane is not tiled by whole aligned bricks (L % 128, P % 4L, odd strides): the GEN
     // kernels only; 1 = an aligned geometry whose launch has leftover planes: the GEN kernel where the epilogue has one (its
     // masked last round replaces the unpipelined planes); pen_per > 0: bricks per XCD of the XCD-contiguous deal;
-    // pen_xtop = the last index a 16-byte pair of the input vector may start at; pen_dump = where discarded rows are stored
+    // pen_xtop = the input vector's last entry (pair loads are clamped to it); pen_dump = where discarded rows are stored
     int pen_gen, pen_per;
     int64_t pen_xtop;
     double *pen_dump;
@@ -288,7 +288,7 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.pen_ya = v.pen_yb = 0;
         v.pen_gen = P->pen_gen;
         v.pen_per = P->pen_per;
-        v.pen_xtop = A->x_len() - 2;
+        v.pen_xtop = A->x_len() - 1;
         v.pen_dump = P->pen_gen ? mk_pen_dump() : nullptr;
     } else if (v.fmt == 3) {
         v.rt_cap = P->rt_cap;

@@ -61,8 +61,8 @@ struct MkHasFuse<Epi, std::void_t<decltype(std::declval<Epi &>().fuse_r)>> : std
 // natural index -- which is what makes the +-1 neighbours across line ends come out right, index based as everything here --
 // clamped into the vector, computes a row sum from whatever it found, and DISCARDS it: its stores go to a dump row, its term of
 // a fused dot is replaced by +0.0 (selects, no branch: the loop body stays one basic block).  Pairs start at any 8-byte
-// boundary (odd L or P): 16-byte accesses through an 8-byte-aligned type; a pair that would start at the vector's LAST entry
-// is loaded one entry lower and shifted.  The same masking runs a chunk's LEFTOVER planes (planes % R != 0) as one more
+// boundary (odd L or P): 16-byte accesses through an 8-byte-aligned type; a pair that starts at the vector's LAST entry reads
+// one entry of the slack every device buffer has behind it.  The same masking runs a chunk's LEFTOVER planes (planes % R != 0) as one more
 // pipelined round whose planes past the end are discarded, instead of one unpipelined plane after the other -- which is why
 // a slab's boundary launch takes this kernel on any geometry (mk_device.h).  Only epilogues that may meet format 11
 // (SYM_MARCH: plain products and CG) have GEN instantiations; they provide the masked pair hook
@@ -76,16 +76,15 @@ template <class Epi>
 struct MkHasRow2M<Epi, std::void_t<decltype(std::declval<Epi &>().row2_m((int64_t)0, mk_d2{}, mk_d2{}, false, false, (double *)nullptr,
                                                                          (double *)nullptr))>> : std::true_type {};
 
-// the pair v[idx], v[idx + 1]; `top` = the last index a pair may start at (idx == top + 1: only v[idx] exists, it comes back in .x)
+// the pair v[idx], v[idx + 1] of an input vector, idx clamped to `top` = the vector's last entry: a pair that STARTS there
+// reads one entry past the end -- every device buffer of this library has 16 bytes of slack behind it (mk_malloc, alloc_vec;
+// a slice of a longer vector has its neighbour there) and the second half is a row that does not exist, so it is discarded.
+// (No select on the loaded value: a fix-up after the load would pin a wait for it right behind the load.)
 template <bool NT>
 __device__ __forceinline__ mk_d2 mk_pen_ld2(const double *v, int64_t idx, int64_t top) {
-    const bool over = idx > top;
-    const mk_d2u *p = reinterpret_cast<const mk_d2u *>(v + (over ? top : idx));
-    mk_d2 t;
-    if constexpr (NT) t = __builtin_nontemporal_load(p);
-    else t = *p;
-    t.x = over ? t.y : t.x;
-    return t;
+    const mk_d2u *p = reinterpret_cast<const mk_d2u *>(v + (idx > top ? top : idx));
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 
 // one term of a row sum: s + v * x, x with its high word ANDed by m (0xffffffff: the row has the entry; 0: it has not, v = +0.0)
@@ -154,7 +153,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     const bool xdeal = GEN && A.pen_per > 0 && (gridDim.x & 7) == 0;
     const int64_t items = (int64_t)(xdeal ? 8 * A.pen_per : bpp) * (nch1 + nch2);
     const int64_t last = A.nrows - 1;
-    [[maybe_unused]] const int64_t xtop = A.pen_xtop;         // GEN: the last index a pair of the input vector may start at
+    [[maybe_unused]] const int64_t xtop = A.pen_xtop;         // GEN: the input vector's last entry (loads are clamped to it)
     [[maybe_unused]] double *gdump = GEN ? A.pen_dump + (int64_t)blockIdx.x * 512 + 2 * tid : nullptr;
     // a rank's slab (mk_csr_localize mode 0): the planes below plane 0 / above plane nz - 1 are the neighbours', received
     // behind the own rows of the input vector; on one device the march clamps into the grid (their entries are masked).
