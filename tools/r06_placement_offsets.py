@@ -17,7 +17,8 @@ from pykrylov_amd.generic import DeviceRun
 lib = _lib.init(0)
 m = int(sys.argv[1]); n = m ** 3
 if os.environ.get("USE_ARENA") == "1":
-    _lib.check(lib.mk_arena_reserve(7 * (8 * n + (8 << 20))))
+    extra = sum(int(v) for v in os.environ.get("MK_ARENA_SKEW", "0").split(","))
+    _lib.check(lib.mk_arena_reserve(7 * (8 * n + (8 << 20)) + extra))
 op = gallery.poisson3d(m)
 ones = _lib.DeviceArray.from_numpy(np.ones(n)); rhs = _lib.DeviceArray(n)
 op.spmv_device(ones.ptr, rhs.ptr)
@@ -36,8 +37,26 @@ def run(m, env):
     return line[0][7:] if line else "FAILED " + p.stderr[-300:]
 
 
+def big_skews(m):
+    """second series: skews of megabytes to a gigabyte between the vectors (the channel / bank hash takes upper address bits)"""
+    M = 1 << 20
+    print("# second series: large skews")
+    for sk in ([0, 16 * M, 32 * M, 48 * M, 64 * M], [0, 33 * M, 66 * M, 99 * M, 132 * M], [0, 100 * M, 200 * M, 300 * M, 400 * M],
+               [0, 0, 0, 0, 512 * M], [0, 0, 256 * M, 0, 512 * M], [0, 341 * M, 682 * M, 1023 * M, 1364 * M], [0, 1000 * M, 0, 0, 0],
+               [0, 7 * M + 4096, 14 * M + 8192, 21 * M + 12288, 28 * M + 16384]):
+        for rep in range(2):
+            print("arena, skew %-50s : %s" % (",".join(str(v) for v in sk),
+                                               run(m, {"MK_PLACEMENT_DRAWS": "1", "USE_ARENA": "1", "MK_ARENA_SKEW": ",".join(str(v) for v in sk)})),
+                  flush=True)
+    for rep in range(3):
+        print("separate allocations, draws off                                   : %s" % run(m, {"MK_PLACEMENT_DRAWS": "1"}), flush=True)
+
+
 if __name__ == "__main__":
     m = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    if len(sys.argv) > 2 and sys.argv[2] == "big":
+        big_skews(m)
+        sys.exit(0)
     K = 1024
     print("# CG %d^3, constant coefficients, fused passes; per configuration two processes" % m)
     for rep in range(3):
