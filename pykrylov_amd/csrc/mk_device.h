@@ -345,7 +345,7 @@ static inline bool mk_pen_split(const MkPlan *P, int *za, int *zb, bool thin = f
     *zb = hi_s;
     return true;
 }
-static inline bool mk_pen_tail_gen() {                      // (MK_PEN_TAIL_GEN=0: the unpipelined leftover planes of round 5, for A/B runs)
+static inline bool mk_pen_tail_gen() {                      // (MK_PEN_TAIL_GEN=0: round 5's split of a slab -- six + leftover boundary planes -- for A/B runs)
     static const char *env = getenv("MK_PEN_TAIL_GEN");
     return !env || atoi(env) != 0;
 }

@@ -239,3 +239,43 @@ print(repr(out))
     assert [r[0] for r in res["0"]] == [0, 0] and [r[0] for r in res["1"]] == [2, 2]
     assert [r[1:] for r in res["0"]] == [r[1:] for r in res["1"]]
 
+
+
+def test_automatic_choice_follows_the_measured_rule():
+    """No format forced (csrc/mk_format.hip pencil_plan; measurements: profiles/r06_march_sizes.txt): the march is taken from 2^21
+    rows on where the bricks are at least 90 % full -- aligned or not --, from 2^24 rows on where they are 50 .. 90 % full (L = 100:
+    78 %; CG on 200^3 is 17 % faster on the windowed format), and for 5-point matrices from 2^23 rows on; smaller matrices keep
+    the windowed formats.  Products stay bit-identical to the CSR gather path whatever was chosen."""
+    from pykrylov_amd import _lib, gallery
+    lib = _lib.init()
+    cases = [((384, 300, 20), 9, 0),          # 2.3 M rows, whole aligned bricks
+             ((250, 248, 40), 9, 2),          # 2.5 M rows, bricks 97.7 % full
+             ((100, 100, 1700), 9, 2),        # 17 M rows, bricks 78 % full: past 2^24 rows
+             ((100, 100, 300), 4, None),      # 3 M rows, bricks 78 % full: windowed
+             ((64, 64, 64), 4, None)]         # 262 k rows: windowed
+    for dims, want_fmt, want_gen in cases:
+        op = gallery.poisson3d(*dims)
+        n = op.shape[0]
+        x = _lib.DeviceArray.from_numpy(np.random.default_rng(1).standard_normal(n))
+        y = _lib.DeviceArray(n)
+        op.spmv_device(x.ptr, y.ptr)
+        info = march_info(op)
+        assert fmt_of(op) == want_fmt, (dims, fmt_of(op), info)
+        if want_gen is not None:
+            assert info["gen"] == want_gen and (info["L"], info["P"], info["planes"]) == (dims[0], dims[0] * dims[1], dims[2]), info
+        got = y.to_numpy()
+        _lib.check(lib.mk_csr_set_format(op.handle, 0))
+        op.spmv_device(x.ptr, y.ptr)
+        assert np.array_equal(got, y.to_numpy()), dims
+        for b in (x, y):
+            b.free()
+        op.free()
+    for m, want in ((2000, 4), (3000, 9)):    # 5-point: 4 M rows windowed, 9 M rows marched line by line
+        op = gallery.poisson2d(m)
+        x = _lib.DeviceArray.from_numpy(np.ones(m * m))
+        y = _lib.DeviceArray(m * m)
+        op.spmv_device(x.ptr, y.ptr)
+        assert fmt_of(op) == want, (m, fmt_of(op))
+        for b in (x, y):
+            b.free()
+        op.free()
