@@ -89,6 +89,7 @@ struct MkCsrView {
     // masked last round replaces the unpipelined planes); pen_per > 0: bricks per XCD of the XCD-contiguous deal;
     // pen_xtop = the input vector's last entry (pair loads are clamped to it); pen_dump = where discarded rows are stored
     int pen_gen, pen_per;
+    int pen_nol;                                            // the matrix has no +-L entries at all (a 5-point matrix: L is a fiction)
     int64_t pen_xtop;
     double *pen_dump;
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
@@ -288,6 +289,7 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.pen_ya = v.pen_yb = 0;
         v.pen_gen = P->pen_gen;
         v.pen_per = P->pen_per;
+        v.pen_nol = P->pen_nol;
         v.pen_xtop = A->x_len() - 1;
         v.pen_dump = P->pen_gen ? mk_pen_dump() : nullptr;
     } else if (v.fmt == 3) {

@@ -1280,6 +1280,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     // marched line by line: planes of M rows, cut into lines of 128 rows that have no +-L entries (the kernels are index based)
     int64_t L = h_stats[0], PP = h_stats[1];
     if (h_stats[2] > 7 || L <= 1 || PP < L) return drop();
+    const bool two_d = (L == PP);
     if (L == PP) {
         // (measured, tools/r06_march_sizes.py: CG on 2000^2 16.8 k passes per second on either format, on 4000^2 3.86 k on the
         //  windowed format 4 against 4.22 k marched: chosen automatically from four times the 3-D threshold on)
@@ -1362,6 +1363,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
         P.d_sval = d_sval;
         P.npat = 0;
         pencil_geometry(A, P, L, PP);
+        P.pen_nol = two_d ? 1 : 0;
         return true;
     };
     if (!read_state()) return drop();
@@ -1395,6 +1397,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     P.ndict = ndict;
     P.npat = nkeys;
     pencil_geometry(A, P, L, PP);
+    P.pen_nol = two_d ? 1 : 0;
     return true;
 }
 

@@ -148,6 +148,7 @@ struct MkPlan {
     // general geometry (round 6): 2 = partly empty bricks / unaligned pairs (GEN kernels only), 0 = whole aligned bricks;
     // bricks per XCD of the XCD-contiguous deal (0: round robin); lines per plane
     int pen_gen = 0, pen_per = 0, pen_ny = 0;
+    int pen_nol = 0;                                        // 5-point matrix marched line by line: no +-L entries
     // ... of one rank's slab of planes (columns localised to [own | plane below | plane above], mk_csr_localize mode 0): where
     // the neighbours' planes start in the product's input vector (-1: the slab has no such neighbour)
     int64_t pen_xlo = -1, pen_xhi = -1;

@@ -225,7 +225,8 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         [[maybe_unused]] const bool oka = !GEN || (cx < L && c < P), okb = !GEN || (cx + 1 < L && c + 1 < P);
         // halo row of this lane: lanes 0..127 the line below the brick, 128..255 the line above; lanes 0..7 also the row
         // west / east of brick line tid & 3 (lanes >= 8 load lane (tid & 7)'s edge row again and drop it into the dump row)
-        const int64_t hc = tid < 128 ? b0 - L + tid : b0 + 4 * L + (tid - 128);
+        // (a 5-point matrix marched line by line has no +-L entries: its halo-line loads go to the lane's own row -- an L1 hit)
+        const int64_t hc = (GEN && A.pen_nol) ? c : (tid < 128 ? b0 - L + tid : b0 + 4 * L + (tid - 128));
         const int64_t ec = b0 + (int64_t)(tid & 3) * L + ((tid & 4) ? 128 : -1);
         auto plane = [&](int p) -> mk_d2 {                    // the own rows of plane p (clamped into the grid: values of a
             // plane that does not exist are never multiplied; a slab's neighbour planes come from the received entries)
