@@ -200,13 +200,20 @@ MK_API int mk_csr_create_callback(int64_t nrows, int64_t ncols, mk_matvec_fn fn,
  *      explicitly are also applied to matrices formats 1 .. 5 would have served;
  *   3  plain CSR for matrices without a window cover whose x is longer than an L2: the tile's stream is held in LDS
  *      and the gathers of all workgroups walk x slice by slice (same arrays as format 0);
- *   9  z-marching bricks for 7-point-class matrices (round 5): every column offset in {0, +-1, +-L, +-P} with
- *      L % 128 == 0, P % 4L == 0, nrows % P == 0 (the 7-point stencil of an nx x ny x nz grid, L = nx, P = nx ny, any
- *      boundary treatment) and <= 256 distinct values: ONE BYTE per row names its pattern {7 values, presence mask}; a
- *      workgroup owns a brick of 4 lines x 128 rows and marches through the planes with the planes z-1, z, z+1 of its own
- *      rows in registers, so that every x entry is loaded once per product (format 4 requests each five times).  Chosen
- *      automatically for single-device matrices of at least 2^21 rows (MK_PENCIL_MIN_ROWS); asked for explicitly it is
- *      applied to any matrix of the class.  Matrices outside the class degrade to 8 and below.
+ *   9  z-marching bricks for 7-point-class matrices: every column offset in {0, +-1, +-L, +-P}, nrows % P == 0 (the 7-point
+ *      stencil of ANY nx x ny x nz grid, L = nx, P = nx ny, any boundary treatment; any band matrix of that shape; a 5-point
+ *      matrix with one far stride M as L = 128, P = M) and <= 256 distinct values: ONE BYTE per row names its pattern
+ *      {7 values, presence mask}; a workgroup owns a brick of 4 lines x 128 rows and marches through the planes with the
+ *      planes z-1, z, z+1 of its own rows in registers, so that every x entry is loaded once per product (format 4
+ *      requests each five times).  Round 6: lines that are no multiple of 128 rows, planes that are no multiple of four
+ *      lines and odd strides are served by general-geometry kernels whose partly empty bricks discard the rows that do not
+ *      exist (mk_csr_march_info); at least half of the bricks' lanes must have rows.  General-geometry kernels exist for
+ *      plain products and CG; any other loop on such a matrix runs the CSR gather kernel on the same arrays (same row sums
+ *      bit for bit; its fused dots then follow tile order 0 over the march's grid, not the brick order).  Chosen
+ *      AUTOMATICALLY from 2^21 rows on (MK_PENCIL_MIN_ROWS) where the bricks are at least 90 % full, from 2^24 rows on
+ *      where they are 50 .. 90 % full, for 5-point matrices from 2^23 rows on -- where it was measured to win
+ *      (profiles/r06_march_sizes.txt) --, and only while the last solver created on the matrix is CG or none; asked for
+ *      explicitly it is applied to any matrix of the class.  Matrices outside the class degrade to 8 and below.
  *  10  format 9's march for matrices of the class WITHOUT a value dictionary (variable-coefficient stencils): the byte per
  *      row is its 7-bit presence mask and the values are streamed from seven position-major arrays (56 bytes per row,
  *      +0.0 where a row has no entry) -- what format 5 streams, with every x entry loaded once.  Chosen automatically

@@ -995,7 +995,8 @@ bool cover_build(const mk_csr *A, MkPlan &P, bool wide) {
 
 // ------------------------------------------------------------------------------------------------ fmt 9
 // z-marching bricks (mk_spmv_fmt9.h): is the matrix 7-point class -- every column offset in {0, +-1, +-L, +-P} -- with
-// strides the brick geometry can tile (L % 128 == 0, P % 4L == 0, nrows % P == 0) and <= 256 distinct values?  Then a row
+// strides the brick geometry can tile (nrows % P == 0; whole aligned bricks when L % 128 == 0 and P % 4L == 0, partly empty
+// ones -- the general-geometry kernels -- otherwise, pencil_plan) and <= 256 distinct values?  Then a row
 // is described EXACTLY by a 63-bit key, 9 bits per offset in column order: 0 = no entry, 1 + the value's dictionary code
 // otherwise.  Distinct keys (<= 256) are collected in the open-addressing set the dictionary uses, numbered in ascending
 // order (deterministic), and every row gets the number of its key: no hashing, nothing to verify.

@@ -2,8 +2,9 @@
 #pragma once
 // (included by mk_device.h: one SpMV loop per storage format behind the same Epi / Gate / row_x interface)
 //
-// fmt 9 (round 5).  A matrix whose column offsets all lie in {0, +-1, +-L, +-P} with L a multiple of 128, P a multiple of
-// 4 L and nrows a multiple of P -- the 7-point stencil of an nx x ny x nz grid (L = nx, P = nx ny), any boundary
+// fmt 9 (round 5; any grid side since round 6, see GENERAL GEOMETRY below -- this paragraph describes whole aligned bricks: L a
+// multiple of 128, P a multiple of 4 L).  A matrix whose column offsets all lie in {0, +-1, +-L, +-P} with nrows a multiple of
+// P -- the 7-point stencil of an nx x ny x nz grid (L = nx, P = nx ny), any boundary
 // treatment, any band matrix of that shape -- and whose values come from <= 256 distinct bit patterns is stored as ONE
 // BYTE PER ROW (the number of the row's pattern) plus a table of 64 bytes per pattern: {7 values in column order, +0.0
 // where the row has no entry, a 7-bit presence mask}.  Same data volume as fmt 4; what changes is how x is read.
