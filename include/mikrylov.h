@@ -274,14 +274,12 @@ MK_API int mk_csr_pencil_info(const mk_csr *A, int64_t *stride_line, int64_t *st
  *   [7] planes per chunk                       [8] chunks                    [9] 2 = general geometry (partly empty bricks, pairs
  *   at any 8-byte boundary: a lane whose row does not exist -- in-line position >= L or in-plane index >= P -- discards its
  *   row sum), 0 = whole aligned bricks          [10] per: bricks per XCD of the XCD-contiguous deal, 0 = round robin
- *   [11] row patterns (format 9)                [12] W: columns per brick line -- 128, 64 or 32; a brick is 512 / W lines x W rows
- *   (general geometries take the shape that fills the bricks best; [5] = ceil(L / W), [6] = ceil(lines / (512 / W))); lane t of a
- *   workgroup owns the rows (2 t / W) L + 2 t % W and + 1 of its brick.
+ *   [11] row patterns (format 9).
  * Item i of a launch whose grid is a multiple of 8 with per > 0: brick (i % 8) per + (i / 8) % per of chunk (i / 8) / per
  * (8 per item slots per chunk; a slot whose brick number is >= bricks per plane is empty); otherwise brick i % bpp of
- * chunk i / bpp.  Brick j starts at row (j / bx) (512 / W) L + (j % bx) W of a plane.  A 5-point matrix (one far stride M) is
+ * chunk i / bpp.  Brick j starts at row (j / bx) 4L + (j % bx) 128 of a plane.  A 5-point matrix (one far stride M) is
  * reported as L = 128, P = M: it is marched line by line.  At most `cap` entries are written (MK_MARCH_INFO_LEN exist). */
-#define MK_MARCH_INFO_LEN 13
+#define MK_MARCH_INFO_LEN 12
 MK_API int mk_csr_march_info(const mk_csr *A, int64_t *info, int32_t cap);
 
 /* y = A x   (K1; `self.op * p`, pykrylov/cg/cg.py:115 and every other solver).

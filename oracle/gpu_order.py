@@ -121,29 +121,27 @@ def spmv_tile_order(ntiles, grid=None, tile_map=1):
     return order
 
 
-def pencil_partials(w, y, grid, L, P, nz, zc, chunks, gen=0, per=-1, W=128):
+def pencil_partials(w, y, grid, L, P, nz, zc, chunks, gen=0, per=-1):
     """Brick march (csrc/mk_spmv_fmt9.h; storage formats 9 / 10 / 11): workgroup b takes the (brick, chunk) items b, b + grid,
-    ...  A brick is NL = 512 / W lines x W rows (W = 128; 64 or 32 where that fills the bricks of a general geometry better).  A
-    plane of P rows is cut into lines of L rows, a line into bx = ceil(L / W) bricks, lines are grouped in NLs:
-    bpp = bx * ceil(ceil(P / L) / NL) bricks per plane, brick j starting at row (j // bx) NL L + (j % bx) W of a plane.  With
+    ...  A plane of P rows is cut into lines of L rows, a line into bx = ceil(L / 128) bricks, lines are grouped in fours:
+    bpp = bx * ceil(ceil(P / L) / 4) bricks per plane, brick j starting at row (j // bx) 4 L + (j % bx) 128 of a plane.  With
     `per` > 0 and a grid that is a multiple of 8 the items are dealt XCD-contiguously: item i is brick (i % 8) per +
     (i // 8) % per of chunk (i // 8) // per -- 8 per item slots per chunk, a slot whose brick number is >= bpp is empty --,
     otherwise brick i % bpp of chunk i // bpp (per < 0: round 5's rule, per = bpp / 8 when that is whole).  Lane (wave v,
-    lane l; t = 64 v + l) owns the rows z P + c and z P + c + 1, c = brick start + (2 t // W) L + 2 t % W, and adds their terms plane by plane through
+    lane l) owns the rows z P + c and z P + c + 1, c = brick start + v L + 2 l, and adds their terms plane by plane through
     the chunk, row c first; on a general geometry (`gen`) a row that does not exist -- in-line position >= L or in-plane
     index >= P -- adds +0.0, which leaves the running sum unchanged bit for bit."""
-    pad = 16 * L + 512
+    pad = 4 * L + 256
     prod = np.zeros((nz, P + pad))
     prod[:, :P] = (np.asarray(w, dtype=np.float64) * np.asarray(y, dtype=np.float64)).reshape(nz, P)
-    NL = 512 // W                                            # brick shape (general geometries): NL lines x W rows, W = 128, 64 or 32
-    bx = (L + W - 1) // W
-    bpp = bx * (((P + L - 1) // L + NL - 1) // NL)
+    bx = (L + 127) // 128
+    bpp = bx * (((P + L - 1) // L + 3) // 4)
     if per < 0:
         per = bpp // 8 if bpp % 8 == 0 else 0
     xdeal = per > 0 and grid % 8 == 0
     items = (8 * per if xdeal else bpp) * chunks
-    lane_x = (2 * np.arange(BLOCK)) % W                      # lane t: column within the brick ...
-    lane_c = ((2 * np.arange(BLOCK)) // W) * L + lane_x      # ... and in-plane offset of its first row from the brick's
+    lane_c = (np.arange(4)[:, None] * L + 2 * np.arange(64)[None, :]).reshape(-1)       # lane t = 64 v + l
+    lane_x = np.tile(2 * np.arange(64), 4)                                              # position in the brick's 128 columns
     acc = np.zeros((grid, BLOCK))
     for first in range(0, items, grid):                      # round k of every workgroup (vectorised over workgroups)
         it = np.arange(first, min(first + grid, items))
@@ -156,9 +154,9 @@ def pencil_partials(w, y, grid, L, P, nz, zc, chunks, gen=0, per=-1, W=128):
             bi, ch = it % bpp, it // bpp
         if len(it) == 0:
             continue
-        b0 = (bi // bx) * NL * L + (bi % bx) * W
+        b0 = (bi // bx) * 4 * L + (bi % bx) * 128
         cols = b0[:, None] + lane_c[None, :]                 # (workgroups, 256): in-plane index of row c
-        cx = (bi % bx)[:, None] * W + lane_x[None, :]
+        cx = (bi % bx)[:, None] * 128 + lane_x[None, :]
         oka = (cx < L) & (cols < P)
         okb = (cx + 1 < L) & (cols + 1 < P)
         cols = np.minimum(cols, P + pad - 2)
@@ -201,10 +199,10 @@ def launch_geometry(op):
     from pykrylov_amd import _lib
     g, m = ctypes.c_int32(), ctypes.c_int32()
     _lib.check(_lib.init().mk_csr_launch_info(op.handle, ctypes.byref(g), ctypes.byref(m)))
-    info = (ctypes.c_int64 * 13)()
-    _lib.check(_lib.init().mk_csr_march_info(op.handle, info, 13))
+    info = (ctypes.c_int64 * 12)()
+    _lib.check(_lib.init().mk_csr_march_info(op.handle, info, 12))
     if info[0]:                                               # storage formats 9 / 10 / 11: brick march instead of 256-row tiles
-        return g.value, ("pencil", info[1], info[2], info[3], info[7], info[8], info[9], info[10], info[12])
+        return g.value, ("pencil", info[1], info[2], info[3], info[7], info[8], info[9], info[10])
     if m.value in (3, 4):                                     # (these orders have parameters)
         o, s, p = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.init().mk_csr_tile_order(op.handle, ctypes.byref(o), ctypes.byref(s), ctypes.byref(p), None))

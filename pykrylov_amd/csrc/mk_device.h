@@ -90,7 +90,6 @@ struct MkCsrView {
     // pen_xtop = the input vector's last entry (pair loads are clamped to it); pen_dump = where discarded rows are stored
     int pen_gen, pen_per;
     int pen_nol;                                            // the matrix has no +-L entries at all (a 5-point matrix: L is a fiction)
-    int pen_w, pen_wsh;                                     // GEN: columns per brick line (128, 64 or 32; 512 / pen_w lines per brick), log2
     int64_t pen_xtop;
     double *pen_dump;
     // resident tiles (fmt 3): LDS capacity per tile in nonzeros (multiple of 256), column phases and their width
@@ -291,8 +290,6 @@ static inline MkCsrView mk_view(const mk_csr *A) {
         v.pen_gen = P->pen_gen;
         v.pen_per = P->pen_per;
         v.pen_nol = P->pen_nol;
-        v.pen_w = P->pen_w;
-        v.pen_wsh = P->pen_w == 32 ? 5 : (P->pen_w == 64 ? 6 : 7);
         v.pen_xtop = A->x_len() - 1;
         v.pen_dump = P->pen_gen ? mk_pen_dump() : nullptr;
     } else if (v.fmt == 3) {

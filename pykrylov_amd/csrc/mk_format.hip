@@ -1211,42 +1211,21 @@ int64_t pencil_min_rows() {
 }
 
 // true: P holds format 9.  false: the matrix is not of the class (P untouched apart from freed scratch).
+// bricks per line, brick rows per plane (the last brick of a line / the last group of four lines may be partly empty)
+static inline int64_t pen_bx_of(int64_t L) { return (L + 127) / 128; }
+static inline int64_t pen_by_of(int64_t L, int64_t PP) { return ((PP + L - 1) / L + 3) / 4; }
 // whole aligned bricks (round 5's geometry; the vectors' 16-byte alignment is the C ABI's)?
 static inline bool pen_aligned(int64_t L, int64_t PP) { return L % 128 == 0 && PP % (4 * L) == 0; }
-static inline bool pen_aligned_128(int64_t L, int64_t PP) { return pen_aligned(L, PP); }
-// bricks per line, brick rows per plane (the last brick of a line / the last group of lines may be partly empty) for bricks of
-// 512 / W lines x W rows
-static inline int64_t pen_bx_of(int64_t L, int64_t W = 128) { return (L + W - 1) / W; }
-static inline int64_t pen_by_of(int64_t L, int64_t PP, int64_t W = 128) { return ((PP + L - 1) / L + 512 / W - 1) / (512 / W); }
-// BRICK SHAPE of a general geometry: 4 x 128 unless 8 x 64 or 16 x 32 fills the bricks at least 5 points better (L = 300: 78 % ->
-// 92 %; L = 200: 78 % -> 86 % with 32-row pieces; L = 528: 82 % -> 92 %).  MK_PEN_W = 128 / 64 / 32 fixes it (A/B runs).
-static inline int pen_shape(int64_t L, int64_t PP) {
-    static const char *env = getenv("MK_PEN_W");
-    if (env && (atoi(env) == 128 || atoi(env) == 64 || atoi(env) == 32)) return atoi(env);
-    if (pen_aligned_128(L, PP)) return 128;
-    int best = 128;
-    double fb = (double)PP / (512.0 * pen_bx_of(L, 128) * pen_by_of(L, PP, 128));
-    for (int W : {64, 32}) {
-        const double f = (double)PP / (512.0 * pen_bx_of(L, W) * pen_by_of(L, PP, W));
-        if (f > fb + 0.05) {
-            best = W;
-            fb = f;
-        }
-    }
-    return best;
-}
 
-
-void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP, bool two_d) {
+void pencil_geometry(const mk_csr *A, MkPlan &P, int64_t L, int64_t PP) {
     P.pen_L = L;
     P.pen_P = PP;
     P.pen_nz = (int)(A->nrows / PP);
     P.pen_ny = (int)((PP + L - 1) / L);
+    P.pen_bx = (int)pen_bx_of(L);
+    P.pen_bpp = (int)(pen_bx_of(L) * pen_by_of(L, PP));
     static const char *env_gen = getenv("MK_PEN_GEN");       // (1: the general-geometry kernels on aligned geometries too, A/B runs)
     P.pen_gen = (!pen_aligned(L, PP) || (env_gen && atoi(env_gen) == 1)) ? 2 : 0;
-    P.pen_w = (P.pen_gen && !two_d) ? pen_shape(L, PP) : 128;     // (the aligned kernels know 4 x 128 bricks only)
-    P.pen_bx = (int)pen_bx_of(L, P.pen_w);
-    P.pen_bpp = (int)(pen_bx_of(L, P.pen_w) * pen_by_of(L, PP, P.pen_w));
     // XCD-contiguous deal: an eighth of the plane's bricks per XCD; on a general geometry ceil(bpp / 8) with empty item slots
     // behind the last brick, from 64 bricks per plane on (below that the empty slots would idle whole XCDs)
     P.pen_per = (P.pen_bpp % 8 == 0) ? P.pen_bpp / 8 : ((P.pen_gen && P.pen_bpp >= 64) ? (P.pen_bpp + 7) / 8 : 0);
@@ -1309,17 +1288,15 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
         if (!forced && A->nrows < 4 * pencil_min_rows()) return drop();
         L = 128;
     }
-    if (L >= PP || A->nrows % PP != 0 || A->nrows / PP < 2 || pen_bx_of(L, 32) * pen_by_of(L, PP, 128) > (1 << 24)) return drop();
+    if (L >= PP || A->nrows % PP != 0 || A->nrows / PP < 2 || pen_bx_of(L) * pen_by_of(L, PP) > (1 << 24)) return drop();
     // partly empty bricks: at least half of the lanes must have rows (L = 132, 9 lines: 39 %; L = 37: 29 %)
-    const int64_t Wb = (pen_aligned(L, PP) || two_d) ? 128 : pen_shape(L, PP);
-    const int64_t slots = 512 * pen_bx_of(L, Wb) * pen_by_of(L, PP, Wb);      // rows the bricks of a plane have room for
-    if (!pen_aligned(L, PP) && 2 * PP < slots) return drop();
+    if (!pen_aligned(L, PP) && 2 * PP < 512 * pen_bx_of(L) * pen_by_of(L, PP)) return drop();
     // ... and chosen AUTOMATICALLY only where the march wins (tools/r06_march_sizes.py, profiles/r06_march_sizes.txt: CG passes
     // per second, windowed -> march): bricks at least 90 % full from the usual 2^21 rows on (250^3 2 901 -> 3 931, 500^3 430 -> 584),
     // bricks 78 % full (L = 200, 300, 400) only from 2^24 rows on (200^3, 8 M rows: 7 828 -> 6 506; 300^3 1 982 -> 2 220; 400^3
     // 884 -> 939)
-    if (!forced && !pen_aligned(L, PP) && 10 * PP < 9 * slots && A->nrows < ((int64_t)1 << 24)) return drop();
-    const size_t slack = (size_t)(16 * L + 512);              // rows past the end that a lane without rows may index (GEN: bricks of up to 16 lines)
+    if (!forced && !pen_aligned(L, PP) && 10 * PP < 9 * 512 * pen_bx_of(L) * pen_by_of(L, PP) && A->nrows < ((int64_t)1 << 24)) return drop();
+    const size_t slack = (size_t)(4 * L + 256);              // rows past the end that a lane without rows may index (GEN)
     if ((A->loc_lo != 0 && A->loc_lo != PP) || (A->loc_hi != 0 && A->loc_hi != PP)) return drop();   // (whole planes only)
     const PenSlab sl{A->nrows, A->loc_lo, A->loc_hi};
     // the dictionary (values only: no per-nonzero words)
@@ -1386,7 +1363,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
         P.d_pid = d_pid;
         P.d_sval = d_sval;
         P.npat = 0;
-        pencil_geometry(A, P, L, PP, two_d);
+        pencil_geometry(A, P, L, PP);
         P.pen_nol = two_d ? 1 : 0;
         return true;
     };
@@ -1420,7 +1397,7 @@ bool pencil_plan(const mk_csr *A, MkPlan &P, bool forced, int want) {
     P.d_dict = d_dict;
     P.ndict = ndict;
     P.npat = nkeys;
-    pencil_geometry(A, P, L, PP, two_d);
+    pencil_geometry(A, P, L, PP);
     P.pen_nol = two_d ? 1 : 0;
     return true;
 }
@@ -1681,7 +1658,7 @@ extern "C" int mk_csr_march_info(const mk_csr *A, int64_t *info, int32_t cap) {
     const bool on = mk_fmt_march(P->fmt);
     const int64_t v[MK_MARCH_INFO_LEN] = {on ? P->fmt : 0, P->pen_L, P->pen_P, P->pen_nz, P->pen_ny, P->pen_bx,
                                           P->pen_bx ? P->pen_bpp / P->pen_bx : 0, P->pen_zc, P->pen_chunks, P->pen_gen, P->pen_per,
-                                          P->npat, P->pen_w};
+                                          P->npat};
     for (int k = 0; k < cap && k < MK_MARCH_INFO_LEN; ++k) info[k] = on ? v[k] : 0;
     return MK_OK;
 }

@@ -149,7 +149,6 @@ struct MkPlan {
     // bricks per XCD of the XCD-contiguous deal (0: round robin); lines per plane
     int pen_gen = 0, pen_per = 0, pen_ny = 0;
     int pen_nol = 0;                                        // 5-point matrix marched line by line: no +-L entries
-    int pen_w = 128;                                        // columns per brick line: 128 (4 lines per brick), 64 (8) or 32 (16); GEN only
     // ... of one rank's slab of planes (columns localised to [own | plane below | plane above], mk_csr_localize mode 0): where
     // the neighbours' planes start in the product's input vector (-1: the slab has no such neighbour)
     int64_t pen_xlo = -1, pen_xhi = -1;

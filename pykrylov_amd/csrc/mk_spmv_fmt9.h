@@ -144,15 +144,6 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     constexpr bool RPF = !XPF && MkHasRowPf<Epi>::value;
     static_assert(!GEN || !(XPF || RPF), "general geometry: plain products and CG only (no prefetched epilogue operands)");
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    // BRICK SHAPE (GEN, round 6): 4 lines x 128 rows, or -- where that leaves lanes idle (L = 300: 78 % full) -- 8 x 64 or 16 x 32
-    // (L = 300 in 64-row pieces: 94 %); the builder picks the fullest (mk_format.hip pencil_geometry).  A run-time parameter: the
-    // lane -> (line, column) map, the LDS row stride and the halo / edge lanes follow it, the loop body does not change.
-    const int BW = GEN ? A.pen_w : 128, bwsh = GEN ? A.pen_wsh : 7;       // columns per brick line, log2
-    const int NL = 512 >> bwsh, nlsh = 9 - bwsh;                          // lines per brick, log2
-    const int RSv = GEN ? BW + 4 : RS;                                    // LDS row: [1] west edge, [2 .. BW + 1] rows, [BW + 2] east edge
-    const int BUFv = GEN ? (NL + 2) * RSv : BUF;                          // doubles per plane image
-    const int lw = GEN ? (2 * tid) >> bwsh : w, lc2 = GEN ? (2 * tid) & (BW - 1) : 2 * l;   // this lane's brick line and column
-    [[maybe_unused]] const int VBv = GEN ? (NL + 2) * BW + NL * RSv : MK_PEN_VB;          // SYM: doubles per buffer of the value image
     const int64_t L = A.pen_L, P = A.pen_P;
     const int nz = A.pen_nz, bx = A.pen_bx, bpp = A.pen_bpp, zc = A.pen_zc;
     // this launch's planes: [pen_za, pen_zb) and [pen_ya, pen_yb) in chunks of zc (a whole product: [0, nz) and nothing)
@@ -187,17 +178,15 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
     }
     constexpr int VD = 2;                                    // STREAM: planes of values in flight (slot = plane parity)
     [[maybe_unused]] mk_d2 vr[STREAM ? VD : 1][7];
-    // (lanes 0 .. BW - 1: the halo line below the brick, BW .. 2 BW - 1: the line above; lanes 0 .. 2 NL - 1 also the rows west / east
-    //  of brick line tid % NL; every other lane drops what it loaded into the dump rows behind the two images)
-    double *cdst = smem + (1 + lw) * RSv + 2 + lc2;
-    double *hdst = tid < 2 * BW ? smem + (tid < BW ? 0 : NL + 1) * RSv + 2 + (tid & (BW - 1)) : smem + 2 * BUF + tid;
-    double *edst = tid < 2 * NL ? smem + (1 + (tid & (NL - 1))) * RSv + (((tid >> nlsh) & 1) ? BW + 2 : 1) : smem + 2 * BUF + tid;
+    double *cdst = smem + (1 + w) * RS + 2 + 2 * l;
+    double *hdst = smem + (tid < 128 ? 0 : 5) * RS + 2 + (tid & 127);
+    double *edst = tid < 8 ? smem + (1 + (tid & 3)) * RS + ((tid & 4) ? 130 : 1) : smem + 2 * BUF + tid;
     // SYM: the value image (per buffer: +L values [6][128] -- line 0 the halo line below the brick, 1..4 the brick's lines, 5 a
     // dump line -- then +1 values [4][RS] with the west edge row's at [1])
     [[maybe_unused]] double *vimg = smem + MK_PEN_LDS;
-    [[maybe_unused]] double *vl_own = vimg + (1 + lw) * BW + lc2, *vl_halo = vimg + (tid < BW ? 0 : NL + 1) * BW + (tid & (BW - 1));
-    [[maybe_unused]] double *vw_own = vimg + (NL + 2) * BW + lw * RSv + 2 + lc2;
-    [[maybe_unused]] double *vw_edge = tid < NL ? vimg + (NL + 2) * BW + tid * RSv + 1 : vimg + (NL + 1) * BW + (tid & (BW - 1));
+    [[maybe_unused]] double *vl_own = vimg + (1 + w) * 128 + 2 * l, *vl_halo = vimg + (tid < 128 ? 0 : 5) * 128 + (tid & 127);
+    [[maybe_unused]] double *vw_own = vimg + 6 * 128 + w * RS + 2 + 2 * l;
+    [[maybe_unused]] double *vw_edge = tid < 4 ? vimg + 6 * 128 + tid * RS + 1 : vimg + 5 * 128 + (tid & 127);
     [[maybe_unused]] const double *sv4 = SYM ? A.sval + A.nrows : nullptr, *sv5 = SYM ? A.sval + 2 * A.nrows : nullptr,
                                   *sv6 = SYM ? A.sval + 3 * A.nrows : nullptr;     // (+1, +L, +P values; the diagonal's lead the block)
     [[maybe_unused]] mk_d2 vlo{0.0, 0.0};                    // SYM: the +P values of the plane before = this plane's -P values
@@ -230,16 +219,16 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
         }
         const int zlim = chunk < nch1 ? A.pen_zb : A.pen_yb;
         const int z0 = chunk < nch1 ? A.pen_za + chunk * zc : A.pen_ya + (chunk - nch1) * zc, z1 = (z0 + zc < zlim) ? z0 + zc : zlim;
-        const int64_t b0 = (int64_t)(bi / bx) * NL * L + (int64_t)(bi % bx) * BW;    // the brick's first row in plane 0
-        const int64_t c = b0 + (int64_t)lw * L + lc2;                                 // this lane's rows c, c + 1 (in-plane index)
+        const int64_t b0 = (int64_t)(bi / bx) * 4 * L + (int64_t)(bi % bx) * 128;    // the brick's first row in plane 0
+        const int64_t c = b0 + (int64_t)w * L + 2 * l;                                // this lane's rows c, c + 1 (in-plane index)
         // GEN: do this lane's rows exist?  (in-line position below L, in-plane index below P; okb implies oka)
-        [[maybe_unused]] const int cx = (bi % bx) * BW + lc2;
+        [[maybe_unused]] const int cx = (bi % bx) * 128 + 2 * l;
         [[maybe_unused]] const bool oka = !GEN || (cx < L && c < P), okb = !GEN || (cx + 1 < L && c + 1 < P);
         // halo row of this lane: lanes 0..127 the line below the brick, 128..255 the line above; lanes 0..7 also the row
         // west / east of brick line tid & 3 (lanes >= 8 load lane (tid & 7)'s edge row again and drop it into the dump row)
         // (a 5-point matrix marched line by line has no +-L entries: its halo-line loads go to the lane's own row -- an L1 hit)
-        const int64_t hc = ((GEN && A.pen_nol) || tid >= 2 * BW) ? c : (tid < BW ? b0 - L + tid : b0 + (int64_t)NL * L + (tid - BW));
-        const int64_t ec = b0 + (int64_t)(tid & (NL - 1)) * L + (((tid >> nlsh) & 1) ? BW : -1);
+        const int64_t hc = (GEN && A.pen_nol) ? c : (tid < 128 ? b0 - L + tid : b0 + 4 * L + (tid - 128));
+        const int64_t ec = b0 + (int64_t)(tid & 3) * L + ((tid & 4) ? 128 : -1);
         auto plane = [&](int p) -> mk_d2 {                    // the own rows of plane p (clamped into the grid: values of a
             // plane that does not exist are never multiplied; a slab's neighbour planes come from the received entries)
             const int64_t o = p < 0 ? off_lo : (p > nz - 1 ? off_hi : (int64_t)p * P);
@@ -366,7 +355,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             xm.x = epi.xin(xm_.x); xm.y = epi.xin(xm_.y);
             xc.x = epi.xin(xc_.x); xc.y = epi.xin(xc_.y);
             xp.x = epi.xin(xp_.x); xp.y = epi.xin(xp_.y);
-            [[maybe_unused]] const int vbo = bo ? VBv : 0;
+            [[maybe_unused]] const int vbo = (bo / BUF) * MK_PEN_VB;
             if constexpr (SYM) {                             // own values now, the three lower ones after the barrier
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
@@ -415,10 +404,10 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
             reload();
             __syncthreads();
             const double *row = cdst + bo;
-            const mk_d2 lo = *reinterpret_cast<const mk_d2 *>(row - RSv), up = *reinterpret_cast<const mk_d2 *>(row + RSv);
+            const mk_d2 lo = *reinterpret_cast<const mk_d2 *>(row - RS), up = *reinterpret_cast<const mk_d2 *>(row + RS);
             const double we = row[-1], ea = row[2];
             if constexpr (SYM) {
-                const mk_d2 vl = *reinterpret_cast<const mk_d2 *>(vl_own + vbo - BW);     // the line below this lane's
+                const mk_d2 vl = *reinterpret_cast<const mk_d2 *>(vl_own + vbo - 128);    // the line below this lane's
                 va[1] = mk_pen_sel(vl.x, ma[1]);
                 vb[1] = mk_pen_sel(vl.y, mb[1]);
                 va[2] = mk_pen_sel(vw_own[vbo - 1], ma[2]);  // a(c, c - 1) = row c - 1's +1 value
@@ -523,7 +512,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                     const int zz = z + d;
                     [[maybe_unused]] const bool live = !GEN || zz < z1;
                     if constexpr (FUSE) transform(ring[(d + 2) % R], rr[(d + 1) % H], xx[(d + 1) % H], zz + 1, true, live);
-                    step(zz, (d & 1) * BUFv, ring[d], ring[(d + 1) % R], ring[(d + 2) % R], halo_val(hreg[d % H], hr[FUSE ? d % H : 0]),
+                    step(zz, (d & 1) * BUF, ring[d], ring[(d + 1) % R], ring[(d + 2) % R], halo_val(hreg[d % H], hr[FUSE ? d % H : 0]),
                          halo_val(ereg[d % H], er[FUSE ? d % H : 0]), pidr[d % H], vr[STREAM ? d % VD : 0], hvr[SYM ? d % H : 0],
                          evr[SYM ? d % H : 0], [&]() {
                              __builtin_amdgcn_sched_barrier(0);   // (the slots' last uses stay ABOVE their reloads)
@@ -553,7 +542,7 @@ __device__ __forceinline__ void mk_spmv_tiles_fmt9(const MkCsrView &A, const dou
                 transform(xp, rc, xcn, zz + 1, true);
             }
             vals(zz, 0);
-            step(zz, ((zz - zfull) & 1) * BUFv, xm, xc, xp, halo_val(hreg[0], hr[0]), halo_val(ereg[0], er[0]), pidr[0], vr[0], hvr[0], evr[0],
+            step(zz, ((zz - zfull) & 1) * BUF, xm, xc, xp, halo_val(hreg[0], hr[0]), halo_val(ereg[0], er[0]), pidr[0], vr[0], hvr[0], evr[0],
                  [] {}, [] {});
         }
         __syncthreads();                                     // the next item's first plane image overwrites this LDS

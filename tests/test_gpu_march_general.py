@@ -17,55 +17,29 @@ pytestmark = pytest.mark.gpu
 
 def march_info(op):
     from pykrylov_amd import _lib
-    info = (ctypes.c_int64 * 13)()
-    _lib.check(_lib.init().mk_csr_march_info(op.handle, info, 13))
-    keys = ("fmt", "L", "P", "planes", "lines", "bx", "by", "zc", "chunks", "gen", "per", "patterns", "W")
+    info = (ctypes.c_int64 * 12)()
+    _lib.check(_lib.init().mk_csr_march_info(op.handle, info, 12))
+    keys = ("fmt", "L", "P", "planes", "lines", "bx", "by", "zc", "chunks", "gen", "per", "patterns")
     return dict(zip(keys, list(info)))
 
 
 def expected_geometry(L, P, two_d=False):
-    """(gen, bricks per line, brick rows, W) the builder must choose (csrc/mk_format.hip pencil_geometry / pen_shape): whole aligned
-    bricks -> 0 with 4 x 128 bricks; anything else the general geometry (2) with the brick shape -- 4 x 128, 8 x 64 or 16 x 32 --
-    that fills the bricks best (a narrower shape must gain at least 5 points; MK_PEN_W fixes it)."""
-    import os
-    ny = -(-P // L)
-    if L % 128 == 0 and P % (4 * L) == 0:
-        return 0, L // 128, ny // 4, 128
-    fill = lambda W: P / (512.0 * -(-L // W) * -(-ny // (512 // W)))   # noqa: E731
-    W, fb = 128, fill(128)
-    env = os.environ.get("MK_PEN_W")
-    if env in ("128", "64", "32"):
-        W = int(env)
-    elif not two_d:
-        for cand in (64, 32):
-            if fill(cand) > fb + 0.05:
-                W, fb = cand, fill(cand)
-    return 2, -(-L // W), -(-ny // (512 // W)), W
-
-
-def skip_if_forced_shape_is_too_empty(L, P):
-    """Under MK_PEN_W (the child runs of test_every_brick_shape_on_every_grid) a grid whose lines fill the forced shape's bricks to
-    less than half is -- correctly -- left to the windowed formats: nothing to test there."""
-    import os
-    if os.environ.get("MK_PEN_W") in ("128", "64", "32"):
-        _, bx, by, W = expected_geometry(L, P)
-        if 2 * P < 512 * bx * by:
-            pytest.skip("bricks of %d columns would be less than half full" % W)
+    """(gen, bricks per line, brick rows) the builder must choose (csrc/mk_format.hip pencil_geometry): whole aligned bricks -> 0,
+    anything else the general geometry (2)."""
+    bx, by = -(-L // 128), -(-(-(-P // L)) // 4)
+    return (0 if L % 128 == 0 and P % (4 * L) == 0 else 2), bx, by
 
 
 # (nx, ny, nz): line lengths below / above 128 and 256, odd lengths, planes of 5 .. 15 lines, plane counts that leave 1 .. 5
 # planes over after whole rounds of six; bricks 50 .. 98 % full (partly empty last brick of a line, partly empty last group of
 # lines, odd L, odd P)
 GRIDS = [(100, 8, 8), (100, 9, 7), (200, 8, 5), (250, 7, 13), (101, 8, 5), (101, 9, 11), (129, 12, 4), (500, 5, 3), (384, 6, 9),
-         (90, 13, 8), (250, 8, 5), (500, 8, 3), (128, 15, 5), (250, 15, 4), (255, 8, 5), (255, 15, 3),
-         # ... and grids whose lines fill 8 x 64 or 16 x 32 bricks better than 4 x 128 (78 % -> 89 .. 96 %; odd L among them)
-         (300, 16, 5), (200, 32, 3), (400, 16, 4), (301, 24, 3), (203, 48, 2)]
+         (90, 13, 8), (250, 8, 5), (500, 8, 3), (128, 15, 5), (250, 15, 4), (255, 8, 5), (255, 15, 3)]
 
 
 @pytest.mark.parametrize("dims", GRIDS)
 @pytest.mark.parametrize("fmt", [9, 10, 11])
 def test_general_grid_product_bit_exact(dims, fmt):
-    skip_if_forced_shape_is_too_empty(dims[0], dims[0] * dims[1])
     A = csr_ref.poisson3d(*dims) if fmt == 9 else csr_ref.poisson3d_varcoef(*dims, seed=3)
     op = op9(A, fmt=fmt)
     rng = np.random.default_rng(3)
@@ -73,9 +47,9 @@ def test_general_grid_product_bit_exact(dims, fmt):
     y = op * x
     info = march_info(op)
     assert info["fmt"] == fmt, info
-    gen, bx, by, W = expected_geometry(dims[0], dims[0] * dims[1])
+    gen, bx, by = expected_geometry(dims[0], dims[0] * dims[1])
     assert gen == 2 and (info["L"], info["P"], info["planes"], info["gen"]) == (dims[0], dims[0] * dims[1], dims[2], gen), info
-    assert (info["bx"], info["by"], info["W"]) == (bx, by, W), info
+    assert (info["bx"], info["by"]) == (bx, by), info
     assert np.array_equal(y, A.matvec(x))
     x[::7] = 0.0
     x[5::11] *= 1e300
@@ -107,7 +81,6 @@ def test_general_band_matrix_bit_exact(n, L, P, drop):
     """No grid geometry: +-1 entries across line ends (a lane past the end of its line holds the NEXT line's first rows: the
     natural index), any subset of the offsets, P not a multiple of L, odd strides, zeros / negative zero / denormals among the
     values, an infinity in x next to entries a row does not have."""
-    skip_if_forced_shape_is_too_empty(L, P)
     rng = np.random.default_rng(n)
     A = banded7(n, L, P, rng, drop=drop)
     for fmt in (9, 10):
@@ -131,7 +104,6 @@ def test_general_band_matrix_bit_exact(n, L, P, drop):
 
 @pytest.mark.parametrize("n,L,P,drop", [(700 * 9, 100, 700, 0.3), (909 * 7, 101, 909, 0.0), (2000 * 6, 250, 2000, 0.4), (3825 * 4, 255, 3825, 0.2)])
 def test_general_symmetric_band_format11(n, L, P, drop):
-    skip_if_forced_shape_is_too_empty(L, P)
     rng = np.random.default_rng(n + 1)
     A = sym_banded(n, L, P, rng, drop=drop)
     op = op9(A, fmt=11)
@@ -149,12 +121,11 @@ def test_general_symmetric_band_format11(n, L, P, drop):
 
 
 def test_sparse_bricks_degrade():
-    """Less than half of a brick's lanes with rows in EVERY brick shape (L = 132 in planes of 9 lines: 39 / 39 / 46 % for 4 x 128,
-    8 x 64, 16 x 32; L = 37 in planes of 9 lines: 22 / 33 / 33 %) -> the windowed formats keep the matrix, as does a matrix with
-    offsets outside the class."""
+    """Less than half of a brick's lanes with rows (L = 132 in planes of 9 lines: 39 %; L = 37: 29 %) -> the windowed formats
+    keep the matrix, as does a matrix with offsets outside the class."""
     from pykrylov_amd import CsrOperator, _lib
     rng = np.random.default_rng(1)
-    for A in (csr_ref.poisson3d(132, 9, 8), csr_ref.poisson3d(37, 9, 30), csr_ref.stencil27(100, 8, 4)):
+    for A in (csr_ref.poisson3d(132, 9, 8), csr_ref.poisson3d(37, 40, 6), csr_ref.stencil27(100, 8, 4)):
         for want in (9, 10):
             op = CsrOperator(A.indptr, A.indices, A.data, A.shape)
             _lib.check(_lib.init().mk_csr_set_format(op.handle, want))
@@ -164,13 +135,12 @@ def test_sparse_bricks_degrade():
 
 
 @pytest.mark.parametrize("dims,fmt", [((100, 9, 7), 9), ((250, 7, 13), 9), ((101, 9, 11), 11), ((200, 8, 20), 11), ((250, 8, 13), 9),
-                                      ((255, 15, 8), 11), ((500, 8, 7), 11), ((300, 16, 8), 9), ((200, 32, 7), 11), ((301, 24, 7), 11)])
+                                      ((255, 15, 8), 11), ((500, 8, 7), 11)])
 def test_cg_on_a_general_grid_bit_exact_fused_and_unfused(dims, fmt, monkeypatch):
     """CG with <p, Ap> fused into the march of a general geometry: history, iterate and matvec count equal the oracle run in
     the march's summation order bit for bit, and the fused passes (x / p update inside the next product kernel) equal the
     three-kernel passes bit for bit -- default stopping, matvec_max cutting the run short, an initial guess."""
     from pykrylov_amd import CG
-    skip_if_forced_shape_is_too_empty(dims[0], dims[0] * dims[1])
     A = csr_ref.poisson3d(*dims) if fmt == 9 else csr_ref.poisson3d_varcoef(*dims, seed=5)
     n = A.shape[0]
     rng = np.random.default_rng(4)
@@ -309,16 +279,3 @@ def test_automatic_choice_follows_the_measured_rule():
         for b in (x, y):
             b.free()
         op.free()
-
-
-@pytest.mark.parametrize("W", ["64", "32"])
-def test_every_brick_shape_on_every_grid(W):
-    """MK_PEN_W fixes the brick shape (8 x 64 or 16 x 32) on every general geometry, whatever it fills best: the product, band-matrix,
-    format-11 and CG cases of this file again in a child process (the switch is read once per process)."""
-    import os
-    import subprocess
-    import sys
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
-                        "general_grid_product or band or cg_on_a_general_grid or five_point"], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, MK_PEN_W=W), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
