@@ -34,7 +34,8 @@ def expected_geometry(L, P, two_d=False):
 # planes over after whole rounds of six; bricks 50 .. 98 % full (partly empty last brick of a line, partly empty last group of
 # lines, odd L, odd P)
 GRIDS = [(100, 8, 8), (100, 9, 7), (200, 8, 5), (250, 7, 13), (101, 8, 5), (101, 9, 11), (129, 12, 4), (500, 5, 3), (384, 6, 9),
-         (90, 13, 8), (250, 8, 5), (500, 8, 3), (128, 15, 5), (250, 15, 4), (255, 8, 5), (255, 15, 3)]
+         (90, 13, 8), (250, 8, 5), (500, 8, 3), (128, 15, 5), (250, 15, 4), (255, 8, 5), (255, 15, 3),
+         (300, 16, 5), (200, 32, 3), (400, 16, 4), (301, 24, 3), (203, 48, 2)]
 
 
 @pytest.mark.parametrize("dims", GRIDS)
