@@ -285,6 +285,10 @@ class DeviceRun(object):
             return 1
         if self._quick_draws and not self._auto_draw_class():
             return 1
+        # the search costs about 65 passes' worth of time and buys 3-9 % per pass: it pays after about a thousand passes, so a
+        # caller whose iteration budget is below that keeps the first solver object
+        if self._quick_draws and 0 < int(self._params.matvec_max) < 1000:
+            return 1
         return min(want, 8)
 
     def _apply_precon(self, handle):
